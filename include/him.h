@@ -1,0 +1,190 @@
+/*
+ * him.h -- C ABI of libhim_hip.so: the MI355X (gfx950 / CDNA4) kernels under the mask2image
+ * (layout-to-image GAN) training hot path of xcyan/neurips18_hierchical_image_manipulation.
+ *
+ * The reference has NO native/FFI boundary (it is 100 % Python on stock torch.nn modules); the
+ * boundary this header defines sits directly beneath the reference's Python operator surface.  Each
+ * entry point names the reference call sites it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - plain C, `extern "C"`; raw DEVICE pointers + sizes; no torch / hip types in signatures
+ *     (`stream` is a hipStream_t passed as void*; NULL = the null stream).
+ *   - every call is asynchronous on `stream`, never synchronises, never allocates: the caller owns
+ *     all memory, including the scratch `ws` whose size the matching *_ws() query returns.
+ *   - all tensors are fp32, NCHW, contiguous unless a (ptr, total-channels, first-channel) "channel
+ *     slice" triple says otherwise.
+ *   - return 0 on success, a negative HIM_E_* code on failure; him_last_error() (thread local) says why.
+ */
+#ifndef HIM_H_
+#define HIM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIM_OK 0
+#define HIM_E_INVALID (-1)   /* bad descriptor / argument */
+#define HIM_E_WORKSPACE (-2) /* ws too small */
+#define HIM_E_LAUNCH (-3)    /* HIP launch / runtime error */
+#define HIM_E_UNSUPPORTED (-4)
+
+/* activations fused into epilogues / norm kernels */
+#define HIM_ACT_NONE 0
+#define HIM_ACT_RELU 1  /* nn.ReLU        (models/Pix2Pix_NET.py:70) */
+#define HIM_ACT_LRELU 2 /* nn.LeakyReLU(0.2) (models/Discriminator_NET.py:73) */
+#define HIM_ACT_TANH 3  /* nn.Tanh        (models/Pix2Pix_NET.py:91) */
+
+#define HIM_PAD_ZERO 0    /* Conv2d(padding=p) */
+#define HIM_PAD_REFLECT 1 /* nn.ReflectionPad2d(p) followed by Conv2d(padding=0) */
+
+const char* him_version(void);
+const char* him_arch(void); /* "gfx950" */
+const char* him_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Conv2d family: fp32-MFMA (v_mfma_f32_32x32x2_f32) implicit GEMM, LDS-staged tiles.
+ * Replaces nn.Conv2d (+ the nn.ReflectionPad2d in front of it, + bias, + the activation behind it)
+ * at models/Pix2Pix_NET.py:74,78-79,91; models/layer_util.py:333-378 (ResnetBlock);
+ * models/Discriminator_NET.py:69-93; models/layer_util.py:380-411 (Vgg19 conv3+ReLU).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct HimConv2d {
+  int B, Cin, H, W;   /* input  (B,Cin,H,W) */
+  int Cout, KH, KW;   /* weight (Cout,Cin,KH,KW) */
+  int stride, pad;    /* symmetric stride / padding */
+  int pad_mode;       /* HIM_PAD_ZERO | HIM_PAD_REFLECT */
+  int OH, OW;         /* output (B,Cout,OH,OW); must equal (H+2p-K)/s+1 */
+  int act;            /* epilogue activation applied by *_fwd */
+  float slope;        /* LeakyReLU negative slope */
+} HimConv2d;
+
+/* y = act(conv(x, w) + bias); bias may be NULL. */
+int him_conv2d_fwd(const HimConv2d* d, const float* x, const float* w, const float* bias, float* y,
+                   void* stream);
+/* dx = conv^T(dy, w); dy is the gradient w.r.t. the PRE-activation output (see him_act_bwd). */
+size_t him_conv2d_bwd_data_ws(const HimConv2d* d);
+int him_conv2d_bwd_data(const HimConv2d* d, const float* dy, const float* w, float* dx, void* ws,
+                        size_t ws_bytes, void* stream);
+/* dw (+)= x (*) dy, dbias (+)= sum dy (dbias may be NULL).  accumulate!=0 adds into dw/dbias
+ * (this is how the flat gradient arena receives several contributions per step). */
+size_t him_conv2d_bwd_weight_ws(const HimConv2d* d);
+int him_conv2d_bwd_weight(const HimConv2d* d, const float* x, const float* dy, float* dw, float* dbias,
+                          int accumulate, void* ws, size_t ws_bytes, void* stream);
+
+/* nn.ConvTranspose2d(k3,s2,p1,op1)+bias(+act): models/Pix2Pix_NET.py:89-90,185-188.
+ * Computed as stride-phase sub-convolutions (no zero insertion). weight is (Cin,Cout,KH,KW). */
+typedef struct HimDeconv2d {
+  int B, Cin, H, W;
+  int Cout, KH, KW;
+  int stride, pad, out_pad;
+  int OH, OW; /* (H-1)*s - 2p + K + out_pad */
+  int act;
+  float slope;
+} HimDeconv2d;
+size_t him_deconv2d_fwd_ws(const HimDeconv2d* d);
+int him_deconv2d_fwd(const HimDeconv2d* d, const float* x, const float* w, const float* bias, float* y,
+                     void* ws, size_t ws_bytes, void* stream);
+int him_deconv2d_bwd_data(const HimDeconv2d* d, const float* dy, const float* w, float* dx, void* stream);
+size_t him_deconv2d_bwd_weight_ws(const HimDeconv2d* d);
+int him_deconv2d_bwd_weight(const HimDeconv2d* d, const float* x, const float* dy, float* dw, float* dbias,
+                            int accumulate, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * InstanceNorm2d(affine=False, eps) fused with the activation behind it and, for the second half of a
+ * ResnetBlock, the residual add.  Replaces get_norm_layer('instance') models/layer_util.py:19-26 and
+ * the `x + conv_block(x)` of models/layer_util.py:376-378.  Per-(n,c) reductions are wave64 shuffles.
+ *   fwd: mean/rstd[planes] written; y = act((x-mean)*rstd) (+ residual when residual!=NULL)
+ *   bwd: dz = dy*act'(xhat); dx = rstd*(dz - mean(dz) - xhat*mean(dz*xhat))
+ * ------------------------------------------------------------------------------------------- */
+int him_instnorm_fwd(const float* x, const float* residual, float* y, float* mean, float* rstd,
+                     int planes, int hw, float eps, int act, float slope, void* stream);
+int him_instnorm_bwd(const float* x, const float* mean, const float* rstd, const float* dy, float* dx,
+                     int planes, int hw, int act, float slope, void* stream);
+
+/* dz = dy * act'(.) expressed through the activation OUTPUT y (ReLU/LeakyReLU/Tanh epilogues). */
+int him_act_bwd(const float* y, const float* dy, float* dz, size_t n, int act, float slope, void* stream);
+/* out = a + b  (gradient fan-in, residual adds) */
+int him_add(const float* a, const float* b, float* out, size_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Input encoding: models/pix2pixHD_condImg_model.py:144-174 (+ :285-291 get_edges,
+ * models/pix2pixHD_condImgColor_model.py:147-186).  All write into a channel slice
+ * [c0, c0+n) of a (B,Ctot,H,W) destination so torch.cat never materialises.
+ * ------------------------------------------------------------------------------------------- */
+int him_onehot(const float* label, float* dst, int B, int label_nc, int Ctot, int c0, int hw, void* stream);
+int him_edges(const float* inst, float* dst, int B, int H, int W, int Ctot, int c0, void* stream);
+/* per-image masked mean colour, times noise (B,3) (NULL = 1), clamped to [-1,1]  -> emb (B,3) */
+int him_masked_mean(const float* image, const float* obj_mask, const float* noise, float* emb, int B,
+                    int hw, void* stream);
+/* dst[:, c0:c0+3] = emb[b,c] * mask[b]   (encode_global_embedding) */
+int him_tile_embed(const float* emb, const float* mask, float* dst, int B, int Ctot, int c0, int hw,
+                   void* stream);
+
+/* dst[:, cd0:cd0+n] = f(mask) * src[:, cs0:cs0+n]; mask (B,1,HW) or NULL;
+ * mask_mode 0: f=1, 1: f=mask, 2: f=1-mask.  Implements torch.cat / slicing / `x*mask.repeat(...)`
+ * (pix2pixHD_condImg_model.py:165-166,176-186,229-233) and their backward passes. */
+int him_copy_channels(const float* src, int Csrc, int cs0, float* dst, int Cdst, int cd0, int n, int B,
+                      int hw, const float* mask, int mask_mode, int accumulate, void* stream);
+/* out = (1-m)*a + m*b with a, b channel slices: output gate models/Pix2Pix_NET.py:96-99,242-245 and the
+ * two-stream fusion :215-217.  m is (B,1,HW). */
+int him_blend(const float* a, int Ca, int ca0, const float* b, int Cb, int cb0, const float* m, float* out,
+              int B, int C, int hw, void* stream);
+
+/* nn.AvgPool2d(3, stride=2, padding=1, count_include_pad=False): models/Discriminator_NET.py:31-32. */
+int him_avgpool3s2_fwd(const float* x, float* y, int planes, int H, int W, int OH, int OW, void* stream);
+int him_avgpool3s2_bwd(const float* dy, float* dx, int planes, int H, int W, int OH, int OW, void* stream);
+/* nn.MaxPool2d(k, k): VGG19 2x2 pools (models/layer_util.py:383) and the 2^n mask pool
+ * (models/Pix2Pix_NET.py:134). bwd routes to the first maximum in row-major window order. */
+int him_maxpool_fwd(const float* x, float* y, int planes, int H, int W, int k, void* stream);
+int him_maxpool_bwd(const float* x, const float* dy, float* dx, int planes, int H, int W, int k, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Losses: models/losses.py:40-50 (LSGAN MSE vs a constant), nn.L1Loss pairs of
+ * pix2pixHD_condImg_model.py:235-251 and models/losses.py:75-82.  Deterministic two-stage reductions.
+ *   *_fwd : out[0] = mean(...)     (device scalar)
+ *   *_bwd : d(in) (+)= g[0] * d mean / d in     (g = device scalar upstream gradient)
+ * ------------------------------------------------------------------------------------------- */
+size_t him_reduce_ws(size_t n);
+int him_l1_mean_fwd(const float* a, const float* b, size_t n, float* out, void* ws, size_t ws_bytes,
+                    void* stream);
+int him_l1_mean_bwd(const float* a, const float* b, size_t n, const float* g, float* da, int accumulate,
+                    void* stream);
+int him_mse_const_fwd(const float* x, size_t n, float target, float* out, void* ws, size_t ws_bytes,
+                      void* stream);
+int him_mse_const_bwd(const float* x, size_t n, float target, const float* g, float* dx, int accumulate,
+                      void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * torch.optim.Adam (betas=(beta1,0.999), eps 1e-8, no weight decay) over a flat parameter arena:
+ * pix2pixHD_condImg_model.py:135-139 + the .step() calls of train_mask2image.py:80,86.
+ * `step` is the 1-based step count (bias correction is computed on the host in double, as torch does).
+ * ------------------------------------------------------------------------------------------- */
+int him_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
+                  float beta2, float eps, int step, void* stream);
+int him_fill(float* p, size_t n, float value, void* stream);
+int him_scale(float* p, size_t n, float s, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Spectral norm power iteration, Ip = 1: models/sn_utils.py:8-25,62-67.
+ *   v = l2n(u W), u' = l2n(W v^T), sigma = u' W v^T, with NOTHING detached: the backward
+ *   differentiates through both normalisations.
+ *   fwd: v_out[cols], u_out[rows], sigma_out[1]; scratch t[rows], s[cols] live in ws.
+ *   bwd: dW (+)= g_sigma * d sigma / dW   given the saved u (input), v_out, u_out.
+ * ------------------------------------------------------------------------------------------- */
+size_t him_sn_ws(int rows, int cols);
+int him_sn_power_iter_fwd(const float* W, const float* u, int rows, int cols, float* v_out, float* u_out,
+                          float* sigma_out, void* ws, size_t ws_bytes, void* stream);
+int him_sn_power_iter_bwd(const float* W, const float* u, const float* v_out, const float* u_out,
+                          const float* sigma, const float* g_sigma, int rows, int cols, float* dW,
+                          int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* out = W / sigma[0] ; and the W-side of its backward: dW (+)= dWbar/sigma, dsigma = -sum(dWbar*W)/sigma^2 */
+int him_div_scalar_fwd(const float* W, const float* sigma, float* out, size_t n, void* stream);
+int him_div_scalar_bwd(const float* W, const float* sigma, const float* dout, float* dW, float* dsigma,
+                       size_t n, int accumulate, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIM_H_ */

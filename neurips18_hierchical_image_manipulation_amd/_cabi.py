@@ -1,0 +1,124 @@
+"""ctypes binding of libhim_hip.so (the C ABI declared in include/him.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call fails the product raises.
+The oracle (``oracle/``) is never imported from here.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libhim_hip.so')
+
+c_float_p = C.c_void_p  # raw device pointers travel as integers
+c_int, c_size_t, c_float, c_void_p = C.c_int, C.c_size_t, C.c_float, C.c_void_p
+
+
+class HimConv2d(C.Structure):
+    _fields_ = [(n, c_int) for n in ('B', 'Cin', 'H', 'W', 'Cout', 'KH', 'KW', 'stride', 'pad', 'pad_mode',
+                                     'OH', 'OW', 'act')] + [('slope', c_float)]
+
+
+class HimDeconv2d(C.Structure):
+    _fields_ = [(n, c_int) for n in ('B', 'Cin', 'H', 'W', 'Cout', 'KH', 'KW', 'stride', 'pad', 'out_pad',
+                                     'OH', 'OW', 'act')] + [('slope', c_float)]
+
+
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+PAD_ZERO, PAD_REFLECT = 0, 1
+
+P = c_void_p
+_CONV, _DECONV = C.POINTER(HimConv2d), C.POINTER(HimDeconv2d)
+
+# name -> (restype, argtypes); int-returning entries are error-checked by the wrapper
+_SIGS = {
+    'him_version': (C.c_char_p, []),
+    'him_arch': (C.c_char_p, []),
+    'him_last_error': (C.c_char_p, []),
+    'him_conv2d_fwd': (c_int, [_CONV, P, P, P, P, P]),
+    'him_conv2d_bwd_data_ws': (c_size_t, [_CONV]),
+    'him_conv2d_bwd_data': (c_int, [_CONV, P, P, P, P, c_size_t, P]),
+    'him_conv2d_bwd_weight_ws': (c_size_t, [_CONV]),
+    'him_conv2d_bwd_weight': (c_int, [_CONV, P, P, P, P, c_int, P, c_size_t, P]),
+    'him_deconv2d_fwd_ws': (c_size_t, [_DECONV]),
+    'him_deconv2d_fwd': (c_int, [_DECONV, P, P, P, P, P, c_size_t, P]),
+    'him_deconv2d_bwd_data': (c_int, [_DECONV, P, P, P, P]),
+    'him_deconv2d_bwd_weight_ws': (c_size_t, [_DECONV]),
+    'him_deconv2d_bwd_weight': (c_int, [_DECONV, P, P, P, P, c_int, P, c_size_t, P]),
+    'him_instnorm_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_float, c_int, c_float, P]),
+    'him_instnorm_bwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_float, P]),
+    'him_act_bwd': (c_int, [P, P, P, c_size_t, c_int, c_float, P]),
+    'him_add': (c_int, [P, P, P, c_size_t, P]),
+    'him_onehot': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'him_edges': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'him_masked_mean': (c_int, [P, P, P, P, c_int, c_int, P]),
+    'him_tile_embed': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    'him_copy_channels': (c_int, [P, c_int, c_int, P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, P]),
+    'him_blend': (c_int, [P, c_int, c_int, P, c_int, c_int, P, P, c_int, c_int, c_int, P]),
+    'him_avgpool3s2_fwd': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'him_avgpool3s2_bwd': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'him_maxpool_fwd': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    'him_maxpool_bwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    'him_reduce_ws': (c_size_t, [c_size_t]),
+    'him_l1_mean_fwd': (c_int, [P, P, c_size_t, P, P, c_size_t, P]),
+    'him_l1_mean_bwd': (c_int, [P, P, c_size_t, P, P, c_int, P]),
+    'him_mse_const_fwd': (c_int, [P, c_size_t, c_float, P, P, c_size_t, P]),
+    'him_mse_const_bwd': (c_int, [P, c_size_t, c_float, P, P, c_int, P]),
+    'him_adam_step': (c_int, [P, P, P, P, c_size_t, c_float, c_float, c_float, c_float, c_int, P]),
+    'him_fill': (c_int, [P, c_size_t, c_float, P]),
+    'him_scale': (c_int, [P, c_size_t, c_float, P]),
+    'him_sn_ws': (c_size_t, [c_int, c_int]),
+    'him_sn_power_iter_fwd': (c_int, [P, P, c_int, c_int, P, P, P, P, c_size_t, P]),
+    'him_sn_power_iter_bwd': (c_int, [P, P, P, P, P, P, c_int, c_int, P, c_int, P, c_size_t, P]),
+    'him_div_scalar_fwd': (c_int, [P, P, P, c_size_t, P]),
+    'him_div_scalar_bwd': (c_int, [P, P, P, P, P, c_size_t, c_int, P, c_size_t, P]),
+}
+
+EXPORTS = sorted(_SIGS)
+
+
+class HimError(RuntimeError):
+    pass
+
+
+class _Lib(object):
+    def __init__(self):
+        self._dll = None
+
+    def _load(self):
+        if self._dll is not None:
+            return self._dll
+        if not os.path.isfile(LIB_PATH):
+            raise HimError('libhim_hip.so not built (%s): run `python -c "import __graft_entry__ as g; g.build()"` '
+                           'or `make -C neurips18_hierchical_image_manipulation_amd/csrc` -- there is no CPU '
+                           'fallback' % LIB_PATH)
+        dll = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(dll, name)          # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        self._dll = dll
+        return dll
+
+    def __getattr__(self, name):
+        if name.startswith('_') or name not in _SIGS:
+            raise AttributeError(name)
+        dll = self._load()
+        fn = getattr(dll, name)
+        if _SIGS[name][0] is not c_int:
+            return fn
+
+        def checked(*a):
+            rc = fn(*a)
+            if rc != 0:
+                raise HimError('%s failed (%d): %s' % (name, rc, dll.him_last_error().decode()))
+            return rc
+        checked.__name__ = name
+        self.__dict__[name] = checked
+        return checked
+
+
+lib = _Lib()
+
+
+def loaded_path():
+    lib._load()
+    return LIB_PATH

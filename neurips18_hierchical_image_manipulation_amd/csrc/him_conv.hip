@@ -1,0 +1,821 @@
+// Conv2d / ConvTranspose2d forward, data-gradient and weight-gradient for gfx950 (MI355X).
+//
+// All three are implicit GEMMs on the exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32
+// (157 TFLOP/s peak, bit-for-bit an fmaf chain), 256-thread workgroups = 4 wave64, LDS-staged
+// double-buffered tiles with the next K-step's global loads in flight during the MFMAs.
+//
+//   gconv  : D[m][n]  = sum_k A[m][k] * gather(src)[k][n]       n = (b, y, x) output positions
+//            forward conv        : A = W (Cout x Cin*KH*KW), gather = im2col with zero/reflect pad
+//            data gradient       : A = W regrouped per stride phase (Cin x Cout*taps),
+//                                  gather = shifted dY; one launch covers the s*s output phases
+//            transposed-conv fwd : identical to the data gradient of its adjoint conv (+bias+act)
+//   wgrad  : dW[m][n'] = sum_{k=(b,oy,ox)} dY[m][k] * gather(x)[k][n']   with split-K slabs and a
+//            fixed-order slab reduction (deterministic).
+//
+// Layout facts used below (cdna_hip_programming.md section 3): for mfma_f32_32x32x2f32 lane l holds
+// A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; accumulator register r of lane l is
+// D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31]  -> putting the spatial index on j makes every accumulator
+// register a 128-byte coalesced NCHW row segment.
+#include <algorithm>
+
+#include "him_common.h"
+
+namespace him {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ==============================================================================================
+// gconv
+// ==============================================================================================
+struct GPhase {
+  const float* A;  // [M][K] row-major
+  int K;           // C2*JH*JW
+  int JH, JW;
+  FastDiv fJHJW, fJW;
+  int NA, NC;      // output sub-grid of this phase
+  int oy0, ox0;    // dest origin (dest y = oy0 + oys*a)
+  int offy, offx;  // source origin (src y = a*sy + jh*dy + offy)
+};
+
+struct GConvP {
+  const float* src;   // [B][C2][SH][SW]
+  float* dst;         // [B][M][DH][DW]
+  const float* bias;  // [M] or null
+  int M, C2, B, SH, SW, DH, DW;
+  int oys, oxs, sy, sx, dy, dx;
+  int pad_mode, act;
+  float slope;
+  int nphase;
+  GPhase ph[4];
+};
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void gconv_kernel(const GConvP p) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 16;
+  constexpr int LDA = BK + 1;
+  constexpr int A_PER_T = BM * BK / 256;
+  constexpr int KPT = BK * BN / 256;  // k values per thread in the gathered tile
+  static_assert(WM * WN == 4, "4 waves");
+  static_assert(BN % 64 == 0, "k must be wave-uniform in the gather");
+  __shared__ float sA[2][BM * LDA];
+  __shared__ float sB[2][BK * BN];
+
+  const GPhase& ph = p.ph[blockIdx.z];
+  const int plane = ph.NA * ph.NC;
+  const int Ntot = p.B * plane;
+  const int n0 = blockIdx.x * BN;
+  if (n0 >= Ntot) return;
+  const int m0 = blockIdx.y * BM;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int K = ph.K;
+  const float* __restrict__ A = ph.A;
+
+  // ---- gather coordinates of this thread's column ----
+  const int nl = t % BN;
+  const int kg = __builtin_amdgcn_readfirstlane(t / BN);
+  const int n = n0 + nl;
+  const bool nvalid = n < Ntot;
+  int b = 0, a = 0, c = 0;
+  if (nvalid) {
+    b = n / plane;
+    const int r = n - b * plane;
+    a = r / ph.NC;
+    c = r - a * ph.NC;
+  }
+  const int by = a * p.sy + ph.offy, bx = c * p.sx + ph.offx;
+  const int SH = p.SH, SW = p.SW;
+  const float* __restrict__ srcb = p.src + (size_t)b * p.C2 * SH * SW;
+  const int JHJW = ph.JH * ph.JW, JW = ph.JW;
+  const FastDiv fJHJW = ph.fJHJW, fJW = ph.fJW;
+  const int ddy = p.dy, ddx = p.dx;
+  const bool reflect = p.pad_mode == HIM_PAD_REFLECT;
+
+  float ra[A_PER_T], rb[KPT];
+
+  auto loadA = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) {
+      const int e = t + i * 256;
+      const int row = e / BK, kk = e % BK;
+      const int m = m0 + row, k = k0 + kk;
+      ra[i] = (m < p.M && k < K) ? A[(size_t)m * K + k] : 0.f;
+    }
+  };
+  auto loadB = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const int k = k0 + kg * KPT + i;  // wave-uniform
+      float v = 0.f;
+      if (k < K && nvalid) {
+        const int c2 = (int)fdiv((uint32_t)k, fJHJW);
+        const int r = k - c2 * JHJW;
+        const int jh = (int)fdiv((uint32_t)r, fJW);
+        const int jw = r - jh * JW;
+        int iy = by + jh * ddy, ix = bx + jw * ddx;
+        if (reflect) {
+          iy = iy < 0 ? -iy : iy;
+          iy = iy >= SH ? 2 * (SH - 1) - iy : iy;
+          ix = ix < 0 ? -ix : ix;
+          ix = ix >= SW ? 2 * (SW - 1) - ix : ix;
+          v = srcb[((size_t)c2 * SH + iy) * SW + ix];
+        } else if ((unsigned)iy < (unsigned)SH && (unsigned)ix < (unsigned)SW) {
+          v = srcb[((size_t)c2 * SH + iy) * SW + ix];
+        }
+      }
+      rb[i] = v;
+    }
+  };
+  auto storeAB = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) {
+      const int e = t + i * 256;
+      sA[buf][(e / BK) * LDA + (e % BK)] = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) sB[buf][(kg * KPT + i) * BN + nl] = rb[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int nk = (K + BK - 1) / BK;
+  loadA(0);
+  loadB(0);
+  storeAB(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) {
+      loadA((kt + 1) * BK);
+      loadB((kt + 1) * BK);
+    }
+    const float* __restrict__ pa = &sA[buf][(wm * TM * 32 + l31) * LDA + lh];
+    const float* __restrict__ pb = &sB[buf][lh * BN + wn * TN * 32 + l31];
+#pragma unroll
+    for (int kp = 0; kp < BK / 2; ++kp) {
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = pa[i * 32 * LDA + kp * 2];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = pb[kp * 2 * BN + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) storeAB(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias + activation, coalesced NCHW stores ----
+  const int act = p.act;
+  const float slope = p.slope;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int nn = n0 + wn * TN * 32 + j * 32 + l31;
+    if (nn >= Ntot) continue;
+    const int bb = nn / plane;
+    const int r2 = nn - bb * plane;
+    const int aa = r2 / ph.NC, cc = r2 - aa * ph.NC;
+    const int oy = ph.oy0 + p.oys * aa, ox = ph.ox0 + p.oxs * cc;
+    float* __restrict__ out = p.dst + ((size_t)bb * p.M * p.DH + oy) * p.DW + ox;
+    const size_t mstride = (size_t)p.DH * p.DW;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < p.M) {
+          float v = acc[i][j][r];
+          if (p.bias) v += p.bias[m];
+          out[(size_t)m * mstride] = apply_act(v, act, slope);
+        }
+      }
+    }
+  }
+}
+
+static int launch_gconv(const GConvP& p, hipStream_t st) {
+  long long maxN = 0;
+  for (int i = 0; i < p.nphase; ++i) {
+    long long n = (long long)p.B * p.ph[i].NA * p.ph[i].NC;
+    if (n > maxN) maxN = n;
+  }
+  if (maxN == 0 || p.M <= 0) return HIM_OK;
+  dim3 block(256);
+  if (p.M <= 32) {
+    dim3 grid(cdiv(maxN, 256), cdiv(p.M, 32), p.nphase);
+    hipLaunchKernelGGL((gconv_kernel<1, 4, 1, 2>), grid, block, 0, st, p);
+  } else if (p.M <= 64) {
+    dim3 grid(cdiv(maxN, 128), cdiv(p.M, 64), p.nphase);
+    hipLaunchKernelGGL((gconv_kernel<1, 4, 2, 1>), grid, block, 0, st, p);
+  } else {
+    const long long tiles128 = (long long)cdiv(maxN, 128) * cdiv(p.M, 128) * p.nphase;
+    if (tiles128 >= 768) {
+      dim3 grid(cdiv(maxN, 128), cdiv(p.M, 128), p.nphase);
+      hipLaunchKernelGGL((gconv_kernel<2, 2, 2, 2>), grid, block, 0, st, p);
+    } else {
+      dim3 grid(cdiv(maxN, 64), cdiv(p.M, 128), p.nphase);
+      hipLaunchKernelGGL((gconv_kernel<2, 2, 2, 1>), grid, block, 0, st, p);
+    }
+  }
+  return check_launch("gconv");
+}
+
+// ---- weight regrouping for the data gradient: Wt_phase[ci][(co, jh, jw)] = W[co][ci][ph+s*jh][pw+s*jw]
+struct WTransP {
+  const float* W;  // [Co][Ci][KH][KW]
+  float* Wt;
+  int Co, Ci, KH, KW, s;
+  int nphase;
+  int ph[4], pw[4], JH[4], JW[4];
+  long long off[5];  // element offsets of each phase block, off[nphase] = total
+};
+
+__global__ void wtrans_kernel(const WTransP p) {
+  const long long total = p.off[p.nphase];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    int q = 0;
+    while (q + 1 < p.nphase && i >= p.off[q + 1]) ++q;
+    const long long li = i - p.off[q];
+    const int taps = p.JH[q] * p.JW[q];
+    const int Kq = p.Co * taps;
+    const int ci = (int)(li / Kq);
+    const int k = (int)(li - (long long)ci * Kq);
+    const int co = k / taps;
+    const int r = k - co * taps;
+    const int jh = r / p.JW[q], jw = r - jh * p.JW[q];
+    const int kh = p.ph[q] + p.s * jh, kw = p.pw[q] + p.s * jw;
+    p.Wt[i] = p.W[(((size_t)co * p.Ci + ci) * p.KH + kh) * p.KW + kw];
+  }
+}
+
+// Fills the phase table of a data-gradient launch for a conv with (KH,KW,stride s,pad) whose input
+// grid is IH x IW and whose output-gradient grid is OH x OW.  Returns floats needed for Wt.
+static long long setup_dgrad(GConvP& g, WTransP& wt, int Cout, int Cin, int KH, int KW, int s, int pad,
+                             int IH, int IW, float* Wt) {
+  int q = 0;
+  long long off = 0;
+  for (int ph = 0; ph < s; ++ph) {
+    for (int pw = 0; pw < s; ++pw) {
+      const int JH = ph < KH ? (KH - ph + s - 1) / s : 0;
+      const int JW = pw < KW ? (KW - pw + s - 1) / s : 0;
+      const int ih0 = ((ph - pad) % s + s) % s, iw0 = ((pw - pad) % s + s) % s;
+      const int NA = ih0 < IH ? (IH - ih0 + s - 1) / s : 0;
+      const int NC = iw0 < IW ? (IW - iw0 + s - 1) / s : 0;
+      GPhase& P = g.ph[q];
+      P.A = Wt + off;
+      P.JH = JH;
+      P.JW = JW;
+      P.K = Cout * JH * JW;
+      P.fJHJW = make_fastdiv((uint32_t)(JH * JW > 0 ? JH * JW : 1));
+      P.fJW = make_fastdiv((uint32_t)(JW > 0 ? JW : 1));
+      P.NA = NA;
+      P.NC = NC;
+      P.oy0 = ih0;
+      P.ox0 = iw0;
+      P.offy = (ih0 + pad - ph) / s;
+      P.offx = (iw0 + pad - pw) / s;
+      wt.ph[q] = ph;
+      wt.pw[q] = pw;
+      wt.JH[q] = JH;
+      wt.JW[q] = JW;
+      wt.off[q] = off;
+      off += (long long)Cin * Cout * JH * JW;
+      ++q;
+    }
+  }
+  wt.off[q] = off;
+  wt.nphase = g.nphase = q;
+  wt.Co = Cout;
+  wt.Ci = Cin;
+  wt.KH = KH;
+  wt.KW = KW;
+  wt.s = s;
+  wt.Wt = Wt;
+  g.oys = g.oxs = s;
+  g.sy = g.sx = 1;
+  g.dy = g.dx = -1;
+  g.pad_mode = HIM_PAD_ZERO;
+  return off;
+}
+
+// ---- reflection-pad backward: dx[y][x] = sum of dpad over the padded positions that mirror onto (y,x)
+__global__ void reflect_fold_kernel(const float* __restrict__ dpad, float* __restrict__ dx, int planes, int H,
+                                    int W, int p) {
+  const int PH = H + 2 * p, PW = W + 2 * p;
+  const long long total = (long long)planes * H * W;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W);
+    const long long r = i / W;
+    const int y = (int)(r % H);
+    const long long pl = r / H;
+    int ys[3], xs[3], ny = 0, nx = 0;
+    ys[ny++] = y + p;
+    if (y >= 1 && y <= p) ys[ny++] = p - y;
+    if (y >= H - 1 - p && y <= H - 2) ys[ny++] = p + 2 * (H - 1) - y;
+    xs[nx++] = x + p;
+    if (x >= 1 && x <= p) xs[nx++] = p - x;
+    if (x >= W - 1 - p && x <= W - 2) xs[nx++] = p + 2 * (W - 1) - x;
+    const float* base = dpad + pl * PH * PW;
+    float s = 0.f;
+    for (int a = 0; a < ny; ++a)
+      for (int b = 0; b < nx; ++b) s += base[ys[a] * PW + xs[b]];
+    dx[i] = s;
+  }
+}
+
+// ==============================================================================================
+// wgrad
+// ==============================================================================================
+struct WGradP {
+  const float* dy;  // [B][M][OH][OW]
+  const float* x;   // [B][C][H][W]
+  float* out;       // dW [M][Np]  or slabs [splits][M][Np]
+  int M, C, B, H, W, OH, OW, KH, KW, stride, pad, pad_mode;
+  int Np, Kdim, kchunk, splits, accumulate;
+  FastDiv fKK, fKW, fOW;
+};
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WGradP p) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 32;
+  constexpr int LD = BK + 1;
+  constexpr int RA = BM / 8, RB = BN / 8;
+  static_assert(WM * WN == 4, "4 waves");
+  __shared__ float sA[2][BM * LD];
+  __shared__ float sB[2][BN * LD];
+  __shared__ int tabOff[BN];
+  __shared__ int tabD[BN];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+  const int OHW = p.OH * p.OW, HW = p.H * p.W;
+  const int kbeg = blockIdx.z * p.kchunk;
+  const int kend = min(p.Kdim, kbeg + p.kchunk);
+
+  // per-column (ci,kh,kw) table: loop invariant
+  if (t < BN) {
+    const int np = n0 + t;
+    int off = -1, d = 0;
+    if (np < p.Np) {
+      const int ci = (int)fdiv((uint32_t)np, p.fKK);
+      const int r = np - ci * p.KH * p.KW;
+      const int kh = (int)fdiv((uint32_t)r, p.fKW);
+      const int kw = r - kh * p.KW;
+      off = ci * HW;
+      d = ((kh - p.pad + 128) << 16) | (kw - p.pad + 128);
+    }
+    tabOff[t] = off;
+    tabD[t] = d;
+  }
+  __syncthreads();
+
+  const int kkl = t & 31, rg = t >> 5;
+  // position of this thread's k index (b, sp) tracked incrementally
+  int kcur = kbeg + kkl;
+  int b = kcur / OHW;
+  int sp = kcur - b * OHW;
+
+  float ra[RA], rb[RB];
+  const bool reflect = p.pad_mode == HIM_PAD_REFLECT;
+  const int H = p.H, W = p.W, stride = p.stride;
+
+  auto loadAB = [&]() {
+    const bool kvalid = kcur < kend;
+    const int oh = (int)fdiv((uint32_t)sp, p.fOW);
+    const int ow = sp - oh * p.OW;
+    const float* __restrict__ dyb = p.dy + ((size_t)b * p.M) * OHW + sp;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const int m = m0 + rg + 8 * i;
+      ra[i] = (kvalid && m < p.M) ? dyb[(size_t)m * OHW] : 0.f;
+    }
+    const float* __restrict__ xb = p.x + (size_t)b * p.C * HW;
+    const int ihb = oh * stride, iwb = ow * stride;
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int row = rg + 8 * i;
+      const int off = tabOff[row];
+      const int d = tabD[row];
+      float v = 0.f;
+      if (kvalid && off >= 0) {
+        int ih = ihb + (d >> 16) - 128, iw = iwb + (d & 0xffff) - 128;
+        if (reflect) {
+          ih = ih < 0 ? -ih : ih;
+          ih = ih >= H ? 2 * (H - 1) - ih : ih;
+          iw = iw < 0 ? -iw : iw;
+          iw = iw >= W ? 2 * (W - 1) - iw : iw;
+          v = xb[off + ih * W + iw];
+        } else if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+          v = xb[off + ih * W + iw];
+        }
+      }
+      rb[i] = v;
+    }
+  };
+  auto advance = [&]() {
+    kcur += BK;
+    sp += BK;
+    while (sp >= OHW) {
+      sp -= OHW;
+      ++b;
+    }
+  };
+  auto storeAB = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < RA; ++i) sA[buf][(rg + 8 * i) * LD + kkl] = ra[i];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) sB[buf][(rg + 8 * i) * LD + kkl] = rb[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  if (nk > 0) {
+    loadAB();
+    storeAB(0);
+    advance();
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) loadAB();
+    const float* __restrict__ pa = &sA[buf][(wm * TM * 32 + l31) * LD + lh];
+    const float* __restrict__ pb = &sB[buf][(wn * TN * 32 + l31) * LD + lh];
+#pragma unroll
+    for (int kp = 0; kp < BK / 2; ++kp) {
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = pa[i * 32 * LD + kp * 2];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = pb[j * 32 * LD + kp * 2];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      storeAB(buf ^ 1);
+      advance();
+    }
+    __syncthreads();
+  }
+
+  float* __restrict__ out = p.out + (p.splits > 1 ? (size_t)blockIdx.z * p.M * p.Np : (size_t)0);
+  const bool accum = p.splits == 1 && p.accumulate;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int np = n0 + wn * TN * 32 + j * 32 + l31;
+    if (np >= p.Np) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < p.M) {
+          float* o = out + (size_t)m * p.Np + np;
+          *o = accum ? (*o + acc[i][j][r]) : acc[i][j][r];
+        }
+      }
+    }
+  }
+}
+
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, long long n,
+                                   int splits, int accumulate) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += slabs[(size_t)z * n + i];
+    out[i] = accumulate ? out[i] + s : s;
+  }
+}
+
+// dbias[c] (+)= sum_{b,sp} dy[b][c][sp]; one 256-thread block per channel, fixed order.
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db,
+                                                        int B, int C, int hw, int accumulate) {
+  __shared__ float sh[8];
+  const int c = blockIdx.x;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float* pl = dy + ((size_t)b * C + c) * hw;
+    for (int i = threadIdx.x; i < hw; i += 256) s += pl[i];
+  }
+  s = block_sum_256(s, sh);
+  if (threadIdx.x == 0) db[c] = accumulate ? db[c] + s : s;
+}
+
+static int wgrad_splits(int M, int Np, int Kdim, int BM, int BN) {
+  const long long tiles = (long long)cdiv(M, BM) * cdiv(Np, BN);
+  int splits = (int)((1024 + tiles - 1) / tiles);
+  const int maxs = cdiv(Kdim, 32 * 8);  // at least 8 K-steps per split
+  if (splits > maxs) splits = maxs;
+  if (splits < 1) splits = 1;
+  if (splits > 512) splits = 512;
+  return splits;
+}
+static void wgrad_tile(int M, int* BM, int* BN) {
+  *BN = 128;
+  *BM = M <= 32 ? 32 : (M <= 64 ? 64 : 128);
+}
+
+static size_t wgrad_ws_bytes(int M, int Np, int Kdim) {
+  int BM, BN;
+  wgrad_tile(M, &BM, &BN);
+  const int s = wgrad_splits(M, Np, Kdim, BM, BN);
+  return s > 1 ? (size_t)s * M * Np * sizeof(float) : 0;
+}
+
+// generic weight gradient: dW[M][C*KH*KW] from dy[B][M][OH][OW] and x[B][C][H][W]
+static int run_wgrad(const float* dy, const float* x, float* dw, int M, int C, int B, int H, int W, int OH,
+                     int OW, int KH, int KW, int stride, int pad, int pad_mode, int accumulate, void* ws,
+                     size_t ws_bytes, hipStream_t st) {
+  WGradP p;
+  p.dy = dy;
+  p.x = x;
+  p.M = M;
+  p.C = C;
+  p.B = B;
+  p.H = H;
+  p.W = W;
+  p.OH = OH;
+  p.OW = OW;
+  p.KH = KH;
+  p.KW = KW;
+  p.stride = stride;
+  p.pad = pad;
+  p.pad_mode = pad_mode;
+  p.Np = C * KH * KW;
+  p.Kdim = B * OH * OW;
+  p.fKK = make_fastdiv((uint32_t)(KH * KW));
+  p.fKW = make_fastdiv((uint32_t)KW);
+  p.fOW = make_fastdiv((uint32_t)OW);
+  int BM, BN;
+  wgrad_tile(M, &BM, &BN);
+  const int splits = wgrad_splits(M, p.Np, p.Kdim, BM, BN);
+  p.splits = splits;
+  p.accumulate = accumulate;
+  int kchunk = cdiv(p.Kdim, splits);
+  kchunk = ((kchunk + 31) / 32) * 32;
+  p.kchunk = kchunk;
+  if (splits > 1) {
+    const size_t need = (size_t)splits * M * p.Np * sizeof(float);
+    if (ws_bytes < need || !ws) return fail(HIM_E_WORKSPACE, "wgrad needs %zu ws bytes, got %zu", need, ws_bytes);
+    p.out = (float*)ws;
+  } else {
+    p.out = dw;
+  }
+  dim3 grid(cdiv(p.Np, BN), cdiv(M, BM), splits), block(256);
+  if (BM == 128)
+    hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2>), grid, block, 0, st, p);
+  else if (BM == 64)
+    hipLaunchKernelGGL((wgrad_kernel<1, 4, 2, 1>), grid, block, 0, st, p);
+  else
+    hipLaunchKernelGGL((wgrad_kernel<1, 4, 1, 1>), grid, block, 0, st, p);
+  int rc = check_launch("wgrad");
+  if (rc) return rc;
+  if (splits > 1) {
+    const long long n = (long long)M * p.Np;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(std::min<long long>(cdiv(n, 256), 4096)), dim3(256), 0, st,
+                       (const float*)ws, dw, n, splits, accumulate);
+    rc = check_launch("slab_reduce");
+  }
+  return rc;
+}
+
+static int run_bias_grad(const float* dy, float* db, int B, int C, int hw, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, st, dy, db, B, C, hw, accumulate);
+  return check_launch("bias_grad");
+}
+
+static int check_conv(const HimConv2d* d) {
+  if (!d) return fail(HIM_E_INVALID, "null descriptor");
+  if (d->B <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->H <= 0 || d->W <= 0 || d->KH <= 0 || d->KW <= 0 ||
+      d->stride <= 0 || d->pad < 0)
+    return fail(HIM_E_INVALID, "conv2d: non-positive dimension");
+  if (d->stride > 2) return fail(HIM_E_UNSUPPORTED, "conv2d: stride %d > 2", d->stride);
+  const int oh = (d->H + 2 * d->pad - d->KH) / d->stride + 1, ow = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+  if (oh != d->OH || ow != d->OW)
+    return fail(HIM_E_INVALID, "conv2d: OH/OW (%d,%d) != expected (%d,%d)", d->OH, d->OW, oh, ow);
+  if (d->pad_mode == HIM_PAD_REFLECT && (d->pad >= d->H || d->pad >= d->W))
+    return fail(HIM_E_INVALID, "conv2d: reflect pad %d >= input size", d->pad);
+  if (d->pad_mode == HIM_PAD_REFLECT && d->stride != 1)
+    return fail(HIM_E_UNSUPPORTED, "conv2d: reflect pad needs stride 1");
+  if ((long long)d->Cin * d->KH * d->KW >= (1 << 20) || (long long)d->Cout * d->KH * d->KW >= (1 << 20))
+    return fail(HIM_E_UNSUPPORTED, "conv2d: reduction length too large for fastdiv");
+  return HIM_OK;
+}
+
+static void fill_fprop(GConvP& g, const HimConv2d* d, const float* x, const float* w, const float* bias,
+                       float* y) {
+  memset(&g, 0, sizeof(g));
+  g.src = x;
+  g.dst = y;
+  g.bias = bias;
+  g.M = d->Cout;
+  g.C2 = d->Cin;
+  g.B = d->B;
+  g.SH = d->H;
+  g.SW = d->W;
+  g.DH = d->OH;
+  g.DW = d->OW;
+  g.oys = g.oxs = 1;
+  g.sy = g.sx = d->stride;
+  g.dy = g.dx = 1;
+  g.pad_mode = d->pad_mode;
+  g.act = d->act;
+  g.slope = d->slope;
+  g.nphase = 1;
+  GPhase& P = g.ph[0];
+  P.A = w;
+  P.K = d->Cin * d->KH * d->KW;
+  P.JH = d->KH;
+  P.JW = d->KW;
+  P.fJHJW = make_fastdiv((uint32_t)(d->KH * d->KW));
+  P.fJW = make_fastdiv((uint32_t)d->KW);
+  P.NA = d->OH;
+  P.NC = d->OW;
+  P.oy0 = P.ox0 = 0;
+  P.offy = P.offx = -d->pad;
+}
+
+// data gradient of the conv described by `d` (also the forward of its transposed conv):
+// out (B,Cin,H,W) = sum W * g (B,Cout,OH,OW); for reflect mode goes through the padded gradient + fold.
+static size_t dgrad_ws_bytes(const HimConv2d* d) {
+  size_t n = (size_t)d->Cin * d->Cout * d->KH * d->KW;
+  if (d->pad_mode == HIM_PAD_REFLECT)
+    n += (size_t)d->B * d->Cin * (d->H + 2 * d->pad) * (d->W + 2 * d->pad);
+  return n * sizeof(float) + 256;
+}
+static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float* out, const float* bias, int act,
+                     float slope, void* ws, size_t ws_bytes, hipStream_t st) {
+  const size_t need = dgrad_ws_bytes(d);
+  if (!ws || ws_bytes < need) return fail(HIM_E_WORKSPACE, "dgrad needs %zu ws bytes, got %zu", need, ws_bytes);
+  float* Wt = (float*)ws;
+  const bool refl = d->pad_mode == HIM_PAD_REFLECT;
+  GConvP g;
+  memset(&g, 0, sizeof(g));
+  WTransP wt;
+  memset(&wt, 0, sizeof(wt));
+  wt.W = w;
+  const int IH = refl ? d->H + 2 * d->pad : d->H, IW = refl ? d->W + 2 * d->pad : d->W;
+  const long long nw = setup_dgrad(g, wt, d->Cout, d->Cin, d->KH, d->KW, d->stride, refl ? 0 : d->pad, IH, IW, Wt);
+  float* dpad = Wt + ((nw + 63) / 64) * 64;
+  g.src = gy;
+  g.dst = refl ? dpad : out;
+  g.bias = refl ? nullptr : bias;
+  g.M = d->Cin;
+  g.C2 = d->Cout;
+  g.B = d->B;
+  g.SH = d->OH;
+  g.SW = d->OW;
+  g.DH = IH;
+  g.DW = IW;
+  g.act = refl ? HIM_ACT_NONE : act;
+  g.slope = slope;
+  hipLaunchKernelGGL(wtrans_kernel, dim3(std::min<long long>(cdiv(nw, 256), 8192)), dim3(256), 0, st, wt);
+  int rc = check_launch("wtrans");
+  if (rc) return rc;
+  rc = launch_gconv(g, st);
+  if (rc) return rc;
+  if (refl) {
+    const long long tot = (long long)d->B * d->Cin * d->H * d->W;
+    hipLaunchKernelGGL(reflect_fold_kernel, dim3(std::min<long long>(cdiv(tot, 256), 16384)), dim3(256), 0, st,
+                       (const float*)dpad, out, d->B * d->Cin, d->H, d->W, d->pad);
+    rc = check_launch("reflect_fold");
+  }
+  return rc;
+}
+
+static int adjoint_of(const HimDeconv2d* t, HimConv2d* c) {
+  if (!t) return fail(HIM_E_INVALID, "null descriptor");
+  const int oh = (t->H - 1) * t->stride - 2 * t->pad + t->KH + t->out_pad;
+  const int ow = (t->W - 1) * t->stride - 2 * t->pad + t->KW + t->out_pad;
+  if (oh != t->OH || ow != t->OW)
+    return fail(HIM_E_INVALID, "deconv2d: OH/OW (%d,%d) != expected (%d,%d)", t->OH, t->OW, oh, ow);
+  c->B = t->B;
+  c->Cin = t->Cout;  // adjoint conv maps the deconv OUTPUT space ...
+  c->H = t->OH;
+  c->W = t->OW;
+  c->Cout = t->Cin;  // ... onto the deconv INPUT space
+  c->KH = t->KH;
+  c->KW = t->KW;
+  c->stride = t->stride;
+  c->pad = t->pad;
+  c->pad_mode = HIM_PAD_ZERO;
+  c->OH = t->H;
+  c->OW = t->W;
+  c->act = HIM_ACT_NONE;
+  c->slope = 0.f;
+  if ((c->H + 2 * c->pad - c->KH) / c->stride + 1 != c->OH || (c->W + 2 * c->pad - c->KW) / c->stride + 1 != c->OW)
+    return fail(HIM_E_UNSUPPORTED, "deconv2d: output_padding %d not representable", t->out_pad);
+  return check_conv(c);
+}
+
+}  // namespace him
+
+using namespace him;
+
+extern "C" {
+
+int him_conv2d_fwd(const HimConv2d* d, const float* x, const float* w, const float* bias, float* y,
+                   void* stream) {
+  int rc = check_conv(d);
+  if (rc) return rc;
+  GConvP g;
+  fill_fprop(g, d, x, w, bias, y);
+  return launch_gconv(g, (hipStream_t)stream);
+}
+
+size_t him_conv2d_bwd_data_ws(const HimConv2d* d) { return d ? dgrad_ws_bytes(d) : 0; }
+
+int him_conv2d_bwd_data(const HimConv2d* d, const float* dy, const float* w, float* dx, void* ws,
+                        size_t ws_bytes, void* stream) {
+  int rc = check_conv(d);
+  if (rc) return rc;
+  return run_dgrad(d, dy, w, dx, nullptr, HIM_ACT_NONE, 0.f, ws, ws_bytes, (hipStream_t)stream);
+}
+
+size_t him_conv2d_bwd_weight_ws(const HimConv2d* d) {
+  return d ? wgrad_ws_bytes(d->Cout, d->Cin * d->KH * d->KW, d->B * d->OH * d->OW) : 0;
+}
+
+int him_conv2d_bwd_weight(const HimConv2d* d, const float* x, const float* dy, float* dw, float* dbias,
+                          int accumulate, void* ws, size_t ws_bytes, void* stream) {
+  int rc = check_conv(d);
+  if (rc) return rc;
+  if (dw) {
+    rc = run_wgrad(dy, x, dw, d->Cout, d->Cin, d->B, d->H, d->W, d->OH, d->OW, d->KH, d->KW, d->stride, d->pad,
+                   d->pad_mode, accumulate, ws, ws_bytes, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  if (dbias) rc = run_bias_grad(dy, dbias, d->B, d->Cout, d->OH * d->OW, accumulate, (hipStream_t)stream);
+  return rc;
+}
+
+size_t him_deconv2d_fwd_ws(const HimDeconv2d* t) {
+  HimConv2d c;
+  if (adjoint_of(t, &c)) return 0;
+  return dgrad_ws_bytes(&c);
+}
+
+int him_deconv2d_fwd(const HimDeconv2d* t, const float* x, const float* w, const float* bias, float* y,
+                     void* ws, size_t ws_bytes, void* stream) {
+  HimConv2d c;
+  int rc = adjoint_of(t, &c);
+  if (rc) return rc;
+  // ConvTranspose2d weight (Cin_t, Cout_t, KH, KW) is exactly the adjoint conv's (Cout_c, Cin_c, KH, KW).
+  return run_dgrad(&c, x, w, y, bias, t->act, t->slope, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int him_deconv2d_bwd_data(const HimDeconv2d* t, const float* dy, const float* w, float* dx, void* stream) {
+  HimConv2d c;
+  int rc = adjoint_of(t, &c);
+  if (rc) return rc;
+  GConvP g;
+  fill_fprop(g, &c, dy, w, nullptr, dx);
+  return launch_gconv(g, (hipStream_t)stream);
+}
+
+size_t him_deconv2d_bwd_weight_ws(const HimDeconv2d* t) {
+  HimConv2d c;
+  if (adjoint_of(t, &c)) return 0;
+  return wgrad_ws_bytes(c.Cout, c.Cin * c.KH * c.KW, c.B * c.OH * c.OW);
+}
+
+int him_deconv2d_bwd_weight(const HimDeconv2d* t, const float* x, const float* dy, float* dw, float* dbias,
+                            int accumulate, void* ws, size_t ws_bytes, void* stream) {
+  HimConv2d c;
+  int rc = adjoint_of(t, &c);
+  if (rc) return rc;
+  // adjoint conv: "input" = deconv output gradient dy, "output gradient" = deconv input x
+  if (dw) {
+    rc = run_wgrad(x, dy, dw, c.Cout, c.Cin, c.B, c.H, c.W, c.OH, c.OW, c.KH, c.KW, c.stride, c.pad, HIM_PAD_ZERO,
+                   accumulate, ws, ws_bytes, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  if (dbias) rc = run_bias_grad(dy, dbias, t->B, t->Cout, t->OH * t->OW, accumulate, (hipStream_t)stream);
+  return rc;
+}
+
+}  // extern "C"

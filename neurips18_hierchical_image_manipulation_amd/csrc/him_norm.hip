@@ -1,0 +1,239 @@
+// InstanceNorm2d(affine=False) forward/backward fused with the activation that follows it and the
+// ResnetBlock residual add.  HBM-bound: one (n,c) plane per wave64 (small planes, values cached in
+// registers: one read) or per 256-thread workgroup (large planes, float4 streams).  Per-plane sums use
+// wave64 butterfly shuffles (+ a 4-entry LDS exchange across the waves of a workgroup); the variance is
+// the centred second pass (matches torch's biased variance without E[x^2]-mean^2 cancellation).
+#include "him_common.h"
+
+namespace him {
+
+template <int G>
+__device__ __forceinline__ float group_sum(float v, float* sh) {
+  if constexpr (G == 64) {
+    return wave_sum(v);
+  } else {
+    return block_sum_256(v, sh);
+  }
+}
+
+__device__ __forceinline__ float act_grad_from_xhat(float xh, int act, float slope) {
+  // derivative of act at the normalised value (ReLU / LeakyReLU only follow an IN in this path)
+  if (act == HIM_ACT_RELU) return xh > 0.f ? 1.f : 0.f;
+  if (act == HIM_ACT_LRELU) return xh > 0.f ? 1.f : slope;
+  if (act == HIM_ACT_TANH) {
+    const float y = tanhf(xh);
+    return 1.f - y * y;
+  }
+  return 1.f;
+}
+
+// G = threads cooperating on one plane (64 or 256); CACHE = elements per thread kept in registers (0: stream)
+template <int G, int CACHE>
+__global__ __launch_bounds__(256) void instnorm_fwd_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ res, float* __restrict__ y,
+                                                           float* __restrict__ mean, float* __restrict__ rstd,
+                                                           int planes, int hw, float eps, int act, float slope) {
+  __shared__ float sh[8];
+  constexpr int PPB = 256 / G;
+  const int plane = blockIdx.x * PPB + (G == 64 ? (threadIdx.x >> 6) : 0);
+  if (G == 64 && plane >= planes) return;  // whole wave exits together
+  const int tid = G == 64 ? (threadIdx.x & 63) : threadIdx.x;
+  const float* __restrict__ xp = x + (size_t)plane * hw;
+  float* __restrict__ yp = y + (size_t)plane * hw;
+  const float* __restrict__ rp = res ? res + (size_t)plane * hw : nullptr;
+  const float inv_n = 1.f / (float)hw;
+
+  if constexpr (CACHE > 0) {
+    float v[CACHE];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < CACHE; ++i) {
+      const int idx = tid + i * G;
+      v[i] = idx < hw ? xp[idx] : 0.f;
+      s += v[i];
+    }
+    const float mu = group_sum<G>(s, sh) * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < CACHE; ++i) {
+      const int idx = tid + i * G;
+      const float d = idx < hw ? v[i] - mu : 0.f;
+      q += d * d;
+    }
+    const float var = group_sum<G>(q, sh) * inv_n;
+    const float rs = 1.f / sqrtf(var + eps);
+    if (tid == 0) {
+      mean[plane] = mu;
+      rstd[plane] = rs;
+    }
+#pragma unroll
+    for (int i = 0; i < CACHE; ++i) {
+      const int idx = tid + i * G;
+      if (idx < hw) {
+        float o = apply_act((v[i] - mu) * rs, act, slope);
+        if (rp) o += rp[idx];
+        yp[idx] = o;
+      }
+    }
+  } else {
+    const bool vec = (hw & 3) == 0;
+    float s = 0.f;
+    if (vec) {
+      const float4* x4 = (const float4*)xp;
+      for (int i = tid; i < hw / 4; i += G) {
+        const float4 a = x4[i];
+        s += (a.x + a.y) + (a.z + a.w);
+      }
+    } else {
+      for (int i = tid; i < hw; i += G) s += xp[i];
+    }
+    const float mu = group_sum<G>(s, sh) * inv_n;
+    float q = 0.f;
+    if (vec) {
+      const float4* x4 = (const float4*)xp;
+      for (int i = tid; i < hw / 4; i += G) {
+        const float4 a = x4[i];
+        const float d0 = a.x - mu, d1 = a.y - mu, d2 = a.z - mu, d3 = a.w - mu;
+        q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      }
+    } else {
+      for (int i = tid; i < hw; i += G) {
+        const float d = xp[i] - mu;
+        q += d * d;
+      }
+    }
+    const float var = group_sum<G>(q, sh) * inv_n;
+    const float rs = 1.f / sqrtf(var + eps);
+    if (tid == 0) {
+      mean[plane] = mu;
+      rstd[plane] = rs;
+    }
+    if (vec) {
+      const float4* x4 = (const float4*)xp;
+      const float4* r4 = (const float4*)rp;
+      float4* y4 = (float4*)yp;
+      for (int i = tid; i < hw / 4; i += G) {
+        const float4 a = x4[i];
+        float4 o;
+        o.x = apply_act((a.x - mu) * rs, act, slope);
+        o.y = apply_act((a.y - mu) * rs, act, slope);
+        o.z = apply_act((a.z - mu) * rs, act, slope);
+        o.w = apply_act((a.w - mu) * rs, act, slope);
+        if (rp) {
+          const float4 r = r4[i];
+          o.x += r.x;
+          o.y += r.y;
+          o.z += r.z;
+          o.w += r.w;
+        }
+        y4[i] = o;
+      }
+    } else {
+      for (int i = tid; i < hw; i += G) {
+        float o = apply_act((xp[i] - mu) * rs, act, slope);
+        if (rp) o += rp[i];
+        yp[i] = o;
+      }
+    }
+  }
+}
+
+template <int G, int CACHE>
+__global__ __launch_bounds__(256) void instnorm_bwd_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd,
+                                                           const float* __restrict__ dy, float* __restrict__ dx,
+                                                           int planes, int hw, int act, float slope) {
+  __shared__ float sh[8];
+  constexpr int PPB = 256 / G;
+  const int plane = blockIdx.x * PPB + (G == 64 ? (threadIdx.x >> 6) : 0);
+  if (G == 64 && plane >= planes) return;
+  const int tid = G == 64 ? (threadIdx.x & 63) : threadIdx.x;
+  const float* __restrict__ xp = x + (size_t)plane * hw;
+  const float* __restrict__ gp = dy + (size_t)plane * hw;
+  float* __restrict__ op = dx + (size_t)plane * hw;
+  const float mu = mean[plane], rs = rstd[plane];
+  const float inv_n = 1.f / (float)hw;
+
+  if constexpr (CACHE > 0) {
+    float xh[CACHE], dz[CACHE];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < CACHE; ++i) {
+      const int idx = tid + i * G;
+      if (idx < hw) {
+        xh[i] = (xp[idx] - mu) * rs;
+        dz[i] = gp[idx] * act_grad_from_xhat(xh[i], act, slope);
+      } else {
+        xh[i] = 0.f;
+        dz[i] = 0.f;
+      }
+      s1 += dz[i];
+      s2 += dz[i] * xh[i];
+    }
+    const float m1 = group_sum<G>(s1, sh) * inv_n;
+    const float m2 = group_sum<G>(s2, sh) * inv_n;
+#pragma unroll
+    for (int i = 0; i < CACHE; ++i) {
+      const int idx = tid + i * G;
+      if (idx < hw) op[idx] = rs * (dz[i] - m1 - xh[i] * m2);
+    }
+  } else {
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = tid; i < hw; i += G) {
+      const float xh = (xp[i] - mu) * rs;
+      const float dz = gp[i] * act_grad_from_xhat(xh, act, slope);
+      s1 += dz;
+      s2 += dz * xh;
+    }
+    const float m1 = group_sum<G>(s1, sh) * inv_n;
+    const float m2 = group_sum<G>(s2, sh) * inv_n;
+    for (int i = tid; i < hw; i += G) {
+      const float xh = (xp[i] - mu) * rs;
+      const float dz = gp[i] * act_grad_from_xhat(xh, act, slope);
+      op[i] = rs * (dz - m1 - xh * m2);
+    }
+  }
+}
+
+}  // namespace him
+
+using namespace him;
+
+extern "C" {
+
+int him_instnorm_fwd(const float* x, const float* residual, float* y, float* mean, float* rstd, int planes,
+                     int hw, float eps, int act, float slope, void* stream) {
+  if (planes <= 0 || hw <= 0) return fail(HIM_E_INVALID, "instnorm: planes=%d hw=%d", planes, hw);
+  hipStream_t st = (hipStream_t)stream;
+  if (hw <= 512) {
+    hipLaunchKernelGGL((instnorm_fwd_kernel<64, 8>), dim3(cdiv(planes, 4)), dim3(256), 0, st, x, residual, y,
+                       mean, rstd, planes, hw, eps, act, slope);
+  } else if (hw <= 4096) {
+    hipLaunchKernelGGL((instnorm_fwd_kernel<256, 16>), dim3(planes), dim3(256), 0, st, x, residual, y, mean,
+                       rstd, planes, hw, eps, act, slope);
+  } else {
+    hipLaunchKernelGGL((instnorm_fwd_kernel<256, 0>), dim3(planes), dim3(256), 0, st, x, residual, y, mean, rstd,
+                       planes, hw, eps, act, slope);
+  }
+  return check_launch("instnorm_fwd");
+}
+
+int him_instnorm_bwd(const float* x, const float* mean, const float* rstd, const float* dy, float* dx, int planes,
+                     int hw, int act, float slope, void* stream) {
+  if (planes <= 0 || hw <= 0) return fail(HIM_E_INVALID, "instnorm: planes=%d hw=%d", planes, hw);
+  hipStream_t st = (hipStream_t)stream;
+  if (hw <= 512) {
+    hipLaunchKernelGGL((instnorm_bwd_kernel<64, 8>), dim3(cdiv(planes, 4)), dim3(256), 0, st, x, mean, rstd, dy,
+                       dx, planes, hw, act, slope);
+  } else if (hw <= 4096) {
+    hipLaunchKernelGGL((instnorm_bwd_kernel<256, 16>), dim3(planes), dim3(256), 0, st, x, mean, rstd, dy, dx,
+                       planes, hw, act, slope);
+  } else {
+    hipLaunchKernelGGL((instnorm_bwd_kernel<256, 0>), dim3(planes), dim3(256), 0, st, x, mean, rstd, dy, dx,
+                       planes, hw, act, slope);
+  }
+  return check_launch("instnorm_bwd");
+}
+
+}  // extern "C"

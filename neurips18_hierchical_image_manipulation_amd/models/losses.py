@@ -1,0 +1,44 @@
+"""GANLoss / VGGLoss of the reference's ``models/losses.py`` on fused HIP reductions."""
+import torch.nn as nn
+
+from .. import ops
+from .layer_util import Vgg19
+
+
+class GANLoss(nn.Module):
+    """LSGAN: sum over scales of mean((logits - target)^2) on the last tensor of each scale (:40-50).
+    The constant target tensor of the reference is never materialised."""
+
+    def __init__(self, use_lsgan=True, target_real_label=1.0, target_fake_label=0.0, tensor=None):
+        super().__init__()
+        if not use_lsgan:
+            raise NotImplementedError('vanilla GAN (BCE) loss is not on the HIP path; LSGAN only')
+        self.real_label, self.fake_label = target_real_label, target_fake_label
+
+    def __call__(self, input, target_is_real):
+        t = self.real_label if target_is_real else self.fake_label
+        if isinstance(input[0], list):
+            loss = 0
+            for input_i in input:
+                loss = loss + ops.mse_const(input_i[-1], t)
+            return loss
+        return ops.mse_const(input[-1], t)
+
+
+class VGGLoss(nn.Module):
+    def __init__(self, gpu_ids=None, normalize=False):
+        super().__init__()
+        if normalize:
+            raise NotImplementedError('VGGLoss(normalize=True) is never used by the reference models')
+        self.vgg = Vgg19()
+        self.weights = [1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0]
+
+    def forward(self, x, y):
+        import torch
+        x_vgg = self.vgg(x)
+        with torch.no_grad():
+            y_vgg = self.vgg(y)
+        loss = 0
+        for i in range(len(x_vgg)):
+            loss = loss + self.weights[i] * ops.l1_mean(x_vgg[i], y_vgg[i])
+        return loss

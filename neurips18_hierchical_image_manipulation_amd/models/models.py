@@ -1,0 +1,20 @@
+"""``create_model(opt)`` -- the reference factory (``models/models.py:6-24``) for the mask2image path."""
+
+
+def create_model(opt, data_size=None):
+    from ..options import complete
+    opt = complete(opt)
+    if opt.model == 'pix2pixHD_condImg':
+        from .pix2pixHD_condImg_model import Pix2PixHDModel_condImg
+        model = Pix2PixHDModel_condImg(opt)
+    elif opt.model == 'pix2pixHD_condImgColor':
+        from .pix2pixHD_condImgColor_model import Pix2PixHDModel_condImgColor
+        model = Pix2PixHDModel_condImgColor(opt)
+    elif opt.model == 'AE_maskgen_twostream':
+        raise NotImplementedError('box2mask (AE_maskgen_twostream) is outside this build\'s hot path (SURVEY 8f.2)')
+    else:
+        raise NotImplementedError('the model is not implemented')
+    if getattr(opt, 'verbose', False):
+        print('model [%s] was created' % model.name())
+    # DataParallel wrapping of the reference is replaced by one process per GPU: ``model.module is model``.
+    return model

@@ -1,0 +1,331 @@
+"""``Pix2PixHDModel_condImg`` on the MI355X kernels: the reference trainer object
+(``models/pix2pixHD_condImg_model.py:23-327``) with the same constructor flags, attributes
+(``loss_names``, ``optimizer_G/D``, ``netG/netD``), ``forward`` signature and return value.
+
+Added by this build (named by the task, absent from the reference): ``backward_G`` / ``backward_D`` /
+``optimize_parameters`` -- thin wrappers around exactly the lines ``train_mask2image.py:68-86`` runs inline.
+"""
+import os
+import random
+from collections import OrderedDict
+
+import torch
+
+from .. import ops, synth
+from ..nn import frozen_params
+from ..optim import FusedAdam
+from .base_model import BaseModel
+
+NULLVAL = 0.0
+
+
+class ImagePool(object):
+    """History buffer of generated images (reference ``util/image_pool.py``); identity when pool_size == 0,
+    which is what every shipped recipe uses."""
+
+    def __init__(self, pool_size):
+        self.pool_size, self.images = pool_size, []
+
+    def query(self, images):
+        if self.pool_size == 0:
+            return images
+        out = []
+        for image in images.detach():
+            image = image.unsqueeze(0)
+            if len(self.images) < self.pool_size:
+                self.images.append(image)
+                out.append(image)
+            elif random.uniform(0, 1) > 0.5:
+                i = random.randint(0, self.pool_size - 1)
+                out.append(self.images[i].clone())
+                self.images[i] = image
+            else:
+                out.append(image)
+        return torch.cat(out, 0)
+
+
+def pick_device(opt):
+    if not torch.cuda.is_available():
+        raise RuntimeError('the mask2image HIP path needs an MI355X (no CUDA/HIP device visible); '
+                           'there is no CPU fallback')
+    if 'LOCAL_RANK' in os.environ:
+        return torch.device('cuda', int(os.environ['LOCAL_RANK']))
+    return torch.device('cuda', opt.gpu_ids[0] if len(opt.gpu_ids) else 0)
+
+
+class Pix2PixHDModel_condImg(BaseModel):
+    color = False
+
+    def __init__(self, opt):
+        super().__init__(opt)
+        self.isTrain = opt.isTrain
+        self.netG_type = opt.netG
+        if opt.instance_feat or opt.label_feat:
+            raise NotImplementedError('instance/label feature encoder (netE) is broken in the reference '
+                                      '(Pix2Pix_NET.py:255) and outside the hot path')
+        self.device = pick_device(opt)
+        input_nc = opt.label_nc if opt.label_nc != 0 else 3
+        netG_input_nc = input_nc + (0 if opt.no_instance else 1)
+        self.n_label = netG_input_nc
+
+        from .Pix2Pix_NET import GlobalGenerator, GlobalTwoStreamGenerator, LocalEnhancer
+        if opt.netG == 'global':
+            self.netG = GlobalGenerator(netG_input_nc + 3, opt.output_nc, opt.ngf, opt.n_downsample_global,
+                                        opt.n_blocks_global, opt.norm, 'reflect', opt.use_output_gate)
+        elif opt.netG == 'global_twostream':
+            self.netG = GlobalTwoStreamGenerator(netG_input_nc, opt.output_nc, opt.ngf, opt.n_downsample_global,
+                                                 opt.n_blocks_global, opt.norm, 'reflect', opt.use_skip,
+                                                 opt.which_encoder, opt.use_output_gate, opt.feat_fusion,
+                                                 extra_embed=self.color)
+        elif opt.netG == 'local':      # reachable here, dead in the reference
+            self.netG = LocalEnhancer(netG_input_nc + 3, opt.output_nc, opt.ngf, opt.n_downsample_global,
+                                      opt.n_blocks_global, opt.n_local_enhancers, opt.n_blocks_local, opt.norm)
+        else:
+            raise NameError('global generator name is not defined properly: %s' % opt.netG)
+        self.netG.to(self.device)
+
+        if self.isTrain:
+            self.no_imgCond = opt.no_imgCond
+            self.mask_gan_input = opt.mask_gan_input
+            self.use_soft_mask = opt.use_soft_mask
+            netD_input_nc = input_nc + opt.output_nc + (0 if self.no_imgCond else 3)
+            if not opt.no_instance:
+                netD_input_nc += 1
+            if opt.netG == 'global_twostream' and opt.which_encoder == 'ctx':
+                netD_input_nc = 3
+            from .Discriminator_NET import MultiscaleDiscriminator
+            self.netD = MultiscaleDiscriminator(netD_input_nc, opt.ndf, opt.n_layers_D, opt.norm, opt.no_lsgan,
+                                                opt.num_D, not opt.no_ganFeat_loss or True)
+            self.netD.to(self.device)
+
+        if not self.isTrain or opt.continue_train or opt.load_pretrain:
+            pretrained_path = '' if not self.isTrain else opt.load_pretrain
+            self.load_network(self.netG, 'G', opt.which_epoch, pretrained_path)
+            if self.isTrain:
+                self.load_network(self.netD, 'D', opt.which_epoch, pretrained_path)
+
+        if self.isTrain:
+            if opt.pool_size > 0 and int(os.environ.get('WORLD_SIZE', '1')) > 1:
+                raise NotImplementedError('Fake Pool Not Implemented for MultiGPU')
+            self.fake_pool = ImagePool(opt.pool_size)
+            self.old_lr = opt.lr
+            from .losses import GANLoss, VGGLoss
+            self.criterionGAN = GANLoss(use_lsgan=not opt.no_lsgan)
+            self.criterionFeat = ops.l1_mean
+            if not opt.no_vgg_loss:
+                self.criterionVGG = VGGLoss(self.gpu_ids)
+                if opt.vgg_weights:
+                    self.criterionVGG.vgg.load_torchvision_state_dict(torch.load(opt.vgg_weights, map_location='cpu'))
+                else:   # no network, no torchvision: seeded synthetic weights (He-normal), see DESIGN.md
+                    self.criterionVGG.vgg.load_state_dict(
+                        synth.init_state_dict(self.criterionVGG.vgg.state_dict(), 3, 'vgg'))
+                self.criterionVGG.to(self.device)
+            self.loss_names = ['G_GAN', 'G_GAN_Feat', 'G_VGG', 'D_real', 'D_fake']
+            if opt.niter_fix_global > 0:
+                raise NotImplementedError('niter_fix_global > 0 (per-parameter lr groups) is not supported by the '
+                                          'flat-arena Adam')
+            self.optimizer_G = FusedAdam(self.netG.parameters(), lr=opt.lr, betas=(opt.beta1, 0.999))
+            self.optimizer_D = FusedAdam(self.netD.parameters(), lr=opt.lr, betas=(opt.beta1, 0.999))
+            self.reducer_G = self.reducer_D = None
+        self.loss_G = self.loss_D = None
+
+    def name(self):
+        return 'Pix2PixHDModel_condImg'
+
+    # ------------------------------------------------------------------------------------------
+    def _dev(self, t):
+        if t is None:
+            return None
+        t = t.detach()
+        if t.device != self.device or t.dtype != torch.float32:
+            t = t.to(self.device, torch.float32, non_blocking=True)
+        return t.contiguous()
+
+    def _color_embedding(self, obj_mask, real_image, color_embed, infer):
+        return None
+
+    def encode_input(self, label_map, inst_map=None, real_image=None, feat_map=None, mask_in=None, infer=False,
+                     obj_mask=None, color_embed=None):
+        """-> (input_label, inst_map, real_image, feat_map, cond_image), as the reference (:144-174); the
+        concatenated [label | cond] buffer the generator/discriminator read is kept in ``self._enc``."""
+        assert real_image is not None
+        assert mask_in is not None
+        label_map, inst_map = self._dev(label_map), self._dev(inst_map)
+        real_image, mask_in = self._dev(real_image), self._dev(mask_in)
+        emb = self._color_embedding(self._dev(obj_mask), real_image, color_embed, infer)
+        buf, n_label, n_cond = ops.encode_channels(label_map, inst_map, real_image, mask_in, self.opt.label_nc,
+                                                   not self.opt.no_instance, color_emb=emb)
+        self._enc = (buf, n_label, n_cond, mask_in)
+        input_label = ops.slice_channels(buf, 0, n_label)
+        cond_image = ops.slice_channels(buf, n_label, n_cond)
+        return input_label, inst_map, real_image, feat_map, cond_image
+
+    def _d_input(self, cond, image, mask):
+        if self.opt.netG == 'global_twostream' and self.opt.which_encoder == 'ctx':
+            return ops.mul_mask(image, mask) if self.mask_gan_input else image
+        return ops.cat_channels([cond, image], mask if self.mask_gan_input else None, 1)
+
+    def discriminate(self, input_label, test_image, mask, use_pool=False):
+        x = self._d_input(input_label, test_image.detach(), mask)
+        if use_pool:
+            x = self.fake_pool.query(x)
+        return self.netD.forward(x)
+
+    def _generate(self, buf, input_mask, cond_image, mask_in):
+        if self.netG_type == 'global':
+            return self.netG.forward(buf, mask_in)
+        if self.netG_type == 'local':
+            return self.netG.forward(buf)
+        return self.netG.forward(cond_image, input_mask, mask_in)
+
+    def forward(self, label, inst, image, feat, mask_in, mask_out, infer=False, obj_mask=None):
+        opt = self.opt
+        input_mask, inst_map, real_image, _, cond_image = self.encode_input(label, inst, image, feat, mask_in=mask_in,
+                                                                           obj_mask=obj_mask)
+        buf, n_label, n_cond, mask_in = self._enc
+        fake_image = self._generate(buf, input_mask, cond_image, mask_in)
+
+        netD_cond = input_mask if self.no_imgCond else buf
+        mask_cond = mask_in if not self.use_soft_mask else self._dev(mask_out)
+
+        # Fake detection and loss / real detection and loss (:218-223)
+        pred_fake_pool = self.discriminate(netD_cond, fake_image, mask_cond, True)
+        loss_D_fake = self.criterionGAN(pred_fake_pool, False)
+        pred_real = self.discriminate(netD_cond, real_image, mask_cond, False)
+        loss_D_real = self.criterionGAN(pred_real, True)
+
+        # GAN loss (fake passability): gradients reach G only; D's weight gradients of this pass are the ones
+        # the reference computes and zeroes (train_mask2image.py:84), so they are never computed here.
+        with frozen_params():
+            pred_fake = self.netD.forward(self._d_input(netD_cond, fake_image, mask_cond))
+        loss_G_GAN = self.criterionGAN(pred_fake, True)
+
+        loss_G_GAN_Feat = torch.zeros(1, device=self.device)
+        if not opt.no_ganFeat_loss:
+            feat_weights = 4.0 / (opt.n_layers_D + 1)
+            D_weights = 1.0 / opt.num_D
+            for i in range(opt.num_D):
+                for j in range(len(pred_fake[i]) - 1):
+                    loss_G_GAN_Feat = loss_G_GAN_Feat + D_weights * feat_weights * \
+                        self.criterionFeat(pred_fake[i][j], pred_real[i][j]) * opt.lambda_feat
+
+        loss_G_VGG = torch.zeros(1, device=self.device)
+        if not opt.no_vgg_loss:
+            loss_G_VGG = self.criterionVGG(fake_image, real_image) * opt.lambda_feat
+        if opt.lambda_rec > 0:
+            loss_G_GAN_Feat = loss_G_GAN_Feat + self.criterionFeat(fake_image, real_image) * opt.lambda_rec
+
+        # kept on the device (the reference does four blocking .cpu() copies here every step, :253-256)
+        self._visuals = (fake_image.detach(), real_image, input_mask, cond_image)
+        return [[loss_G_GAN, loss_G_GAN_Feat, loss_G_VGG, loss_D_real, loss_D_fake],
+                None if not infer else fake_image]
+
+    def inference(self, label, inst, image, mask_in, mask_out, obj_mask=None, color_embed=None):
+        with torch.no_grad():
+            input_mask, _, real_image, _, cond_image = self.encode_input(label, inst, image, mask_in=mask_in,
+                                                                        infer=True, obj_mask=obj_mask,
+                                                                        color_embed=color_embed)
+            buf, _, _, mask_dev = self._enc
+            fake_image = self._generate(buf, input_mask, cond_image, mask_dev)
+        self._visuals = (fake_image, real_image, input_mask, cond_image)
+        return fake_image
+
+    def get_edges(self, t):
+        t = self._dev(t)
+        B, _, H, W = t.shape
+        out = torch.empty_like(t)
+        from .._cabi import lib
+        lib.him_edges(t.data_ptr(), out.data_ptr(), B, H, W, 1, 0, torch.cuda.current_stream().cuda_stream)
+        return out
+
+    def get_current_visuals(self):
+        fake, real, label, cond = self._visuals
+        return OrderedDict([('input_label', label[0].cpu()), ('input_image', cond[0].cpu()),
+                            ('real_image', real[0].cpu()), ('synthesized_image', fake[0].cpu())])
+
+    # ------------------------------------------------------------------------------------------
+    # the optimisation step: train_mask2image.py:68-86
+    # ------------------------------------------------------------------------------------------
+    def combine_losses(self, losses):
+        losses = [torch.mean(x) if not isinstance(x, int) else x for x in losses]
+        loss_dict = dict(zip(self.loss_names, losses))
+        self.loss_D = (loss_dict['D_fake'] + loss_dict['D_real']) * 0.5
+        self.loss_G = loss_dict['G_GAN'] + loss_dict['G_GAN_Feat'] + loss_dict['G_VGG']
+        return loss_dict
+
+    def backward_G(self):
+        """optimizer_G.zero_grad(); loss_G.backward(); optimizer_G.step()   (:78-80)."""
+        self.optimizer_G.zero_grad()
+        if self.reducer_G is not None:
+            self.reducer_G.begin()
+        self.loss_G.backward()
+        if self.reducer_G is not None:
+            self.reducer_G.finish()
+        self.optimizer_G.step()
+
+    def backward_D(self):
+        """optimizer_D.zero_grad(); loss_D.backward(); optimizer_D.step()   (:84-86)."""
+        self.optimizer_D.zero_grad()
+        if self.reducer_D is not None:
+            self.reducer_D.begin(contributions=2)
+        self.loss_D.backward()
+        if self.reducer_D is not None:
+            self.reducer_D.finish()
+        self.optimizer_D.step()
+
+    def optimize_parameters(self, data=None, infer=False):
+        """One full training step on a batch dict (keys of SegmentationDataset: label, inst, image, mask_in,
+        mask_out[, obj_mask]).  Same arithmetic as backward_G(); backward_D() but the generator's all-reduce and
+        Adam step are deferred behind loss_D.backward() (legal: loss_D's graph holds no G parameter, the fake is
+        detached) so the 730 MB exchange overlaps D's backward."""
+        data = data if data is not None else self.input
+        kw = dict(label=data['label'], inst=data['inst'], image=data['image'], feat=None, mask_in=data['mask_in'],
+                  mask_out=data['mask_out'], infer=infer)
+        if 'obj_mask' in data:
+            kw['obj_mask'] = data['obj_mask']
+        losses, generated = self.forward(**kw)
+        loss_dict = self.combine_losses(losses)
+        if self.reducer_G is None:
+            self.backward_G()
+            if not self.opt.no_gan:
+                self.backward_D()
+        else:
+            self.optimizer_G.zero_grad()
+            self.reducer_G.begin()
+            self.loss_G.backward()
+            if not self.opt.no_gan:
+                self.optimizer_D.zero_grad()
+                self.reducer_D.begin(contributions=2)
+                self.loss_D.backward()
+            self.reducer_G.finish()
+            self.optimizer_G.step()
+            if not self.opt.no_gan:
+                self.reducer_D.finish()
+                self.optimizer_D.step()
+        self.generated = generated
+        return loss_dict
+
+    # ------------------------------------------------------------------------------------------
+    def save(self, which_epoch):
+        self.save_network(self.netG, 'G', which_epoch, self.gpu_ids)
+        self.save_network(self.netD, 'D', which_epoch, self.gpu_ids)
+
+    def delete_model(self, which_epoch):
+        self.delete_network('G', which_epoch, self.gpu_ids)
+        self.delete_network('D', which_epoch, self.gpu_ids)
+
+    def update_fixed_params(self):
+        self.optimizer_G = FusedAdam(self.netG.parameters(), lr=self.opt.lr, betas=(self.opt.beta1, 0.999),
+                                     arena=self.optimizer_G.arena)
+        print('------------ Now also finetuning global generator -----------')
+
+    def update_learning_rate(self):
+        lrd = self.opt.lr / self.opt.niter_decay
+        lr = self.old_lr - lrd
+        for param_group in self.optimizer_D.param_groups:
+            param_group['lr'] = lr
+        for param_group in self.optimizer_G.param_groups:
+            param_group['lr'] = lr
+        if getattr(self.opt, 'verbose', False):
+            print('update learning rate: %f -> %f' % (self.old_lr, lr))
+        self.old_lr = lr

@@ -1,0 +1,180 @@
+"""Parameter-holding layer modules and the fusing executor.
+
+The layer classes are *markers* that carry parameters under exactly the reference's state_dict keys
+(``model.1.weight`` ...).  They are never run one by one: ``run_layers`` walks a layer list and fuses
+    [ReflectionPad2d] Conv2d|ConvTranspose2d [InstanceNorm2d] [ReLU|LeakyReLU|Tanh]
+into one conv kernel (reflect indexing in the tile loader, bias + activation in the epilogue when no norm
+sits in between) plus, when a norm is present, one fused InstanceNorm+activation(+residual) kernel.
+"""
+import contextlib
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class _Frozen(object):
+    on = False
+
+
+@contextlib.contextmanager
+def frozen_params():
+    """Run modules with detached weights: gradients flow to the input only (the D pass inside loss_G --
+    the reference computes those weight gradients and throws them away at train_mask2image.py:84)."""
+    prev, _Frozen.on = _Frozen.on, True
+    try:
+        yield
+    finally:
+        _Frozen.on = prev
+
+
+def _pw(p):
+    return p.detach() if (_Frozen.on and p is not None) else p
+
+
+class Conv2d(nn.Module):
+    transposed = False
+
+    def __init__(self, cin, cout, k, stride=1, padding=0, bias=True):
+        super().__init__()
+        self.k, self.stride, self.padding = k, stride, padding
+        self.weight = nn.Parameter(torch.randn(cout, cin, k, k) * 0.02)
+        bound = 1.0 / math.sqrt(cin * k * k)
+        self.bias = nn.Parameter((torch.rand(cout) * 2 - 1) * bound) if bias else None
+
+    def effective_weight(self):
+        return _pw(self.weight)
+
+    def extra_repr(self):
+        return '%d->%d k%d s%d p%d' % (self.weight.shape[1], self.weight.shape[0], self.k, self.stride, self.padding)
+
+
+class ConvTranspose2d(nn.Module):
+    transposed = True
+
+    def __init__(self, cin, cout, k, stride=2, padding=1, output_padding=1, bias=True):
+        super().__init__()
+        self.k, self.stride, self.padding, self.output_padding = k, stride, padding, output_padding
+        self.weight = nn.Parameter(torch.randn(cin, cout, k, k) * 0.02)
+        bound = 1.0 / math.sqrt(cout * k * k)
+        self.bias = nn.Parameter((torch.rand(cout) * 2 - 1) * bound) if bias else None
+
+    def effective_weight(self):
+        return _pw(self.weight)
+
+
+class ReflectionPad2d(nn.Module):
+    def __init__(self, p):
+        super().__init__()
+        self.p = p
+
+
+class InstanceNorm2d(nn.Module):
+    def __init__(self, ch, eps=1e-5):
+        super().__init__()
+        self.ch, self.eps = ch, eps
+
+
+class ReLU(nn.Module):
+    act, slope = 'relu', 0.0
+
+
+class LeakyReLU(nn.Module):
+    act = 'lrelu'
+
+    def __init__(self, slope=0.2):
+        super().__init__()
+        self.slope = slope
+
+
+class Tanh(nn.Module):
+    act, slope = 'tanh', 0.0
+
+
+_ACTS = (ReLU, LeakyReLU, Tanh)
+
+
+def run_layers(layers, x, final_residual=None):
+    """Execute a list of marker layers / sub-modules on x with the fusion described in the module docstring.
+    ``final_residual`` is added by the LAST InstanceNorm of the list (ResnetBlock tail)."""
+    layers = list(layers)
+    n, i = len(layers), 0
+    last_norm = max([j for j, l in enumerate(layers) if isinstance(l, InstanceNorm2d)], default=-1)
+    while i < n:
+        l = layers[i]
+        pad_mode, rpad = 'zero', 0
+        if isinstance(l, ReflectionPad2d):
+            if i + 1 >= n or not isinstance(layers[i + 1], Conv2d):
+                raise ValueError('ReflectionPad2d must be followed by Conv2d')
+            pad_mode, rpad = 'reflect', l.p
+            i += 1
+            l = layers[i]
+        if isinstance(l, (Conv2d, ConvTranspose2d)):
+            norm = act = None
+            norm_idx = -2
+            j = i + 1
+            if j < n and isinstance(layers[j], InstanceNorm2d):
+                norm, norm_idx = layers[j], j
+                j += 1
+            if j < n and isinstance(layers[j], _ACTS):
+                act = layers[j]
+                j += 1
+            aname = act.act if act is not None else 'none'
+            slope = getattr(act, 'slope', 0.0) if act is not None else 0.0
+            epi = 'none' if norm is not None else aname
+            w, b = l.effective_weight(), _pw(l.bias)
+            if l.transposed:
+                x = ops.conv_transpose2d(x, w, b, l.stride, l.padding, l.output_padding, epi, slope)
+            else:
+                if pad_mode == 'reflect' and l.padding != 0:
+                    raise ValueError('reflect pad + conv padding')
+                x = ops.conv2d(x, w, b, l.stride, rpad if pad_mode == 'reflect' else l.padding, pad_mode, epi, slope)
+            if norm is not None:
+                res = final_residual if (final_residual is not None and norm_idx == last_norm) else None
+                if res is not None and act is not None:
+                    raise ValueError('residual after an activated norm is not a ResnetBlock tail')
+                x = ops.instance_norm(x, res, aname, slope, norm.eps)
+            i = j
+        elif isinstance(l, InstanceNorm2d):
+            x = ops.instance_norm(x, None, 'none', 0.0, l.eps)
+            i += 1
+        elif isinstance(l, _ACTS):
+            raise ValueError('stand-alone activation is not on the hot path')
+        else:
+            x = l(x)
+            i += 1
+    return x
+
+
+class FusedSequential(nn.Sequential):
+    def forward(self, x):
+        return run_layers(list(self), x)
+
+
+class ResnetBlock(nn.Module):
+    """x + IN(conv3(refpad(ReLU(IN(conv3(refpad(x)))))))  (reference models/layer_util.py:333-378);
+    parameters at ``conv_block.1`` and ``conv_block.5``."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.conv_block = nn.Sequential(ReflectionPad2d(1), Conv2d(dim, dim, 3), InstanceNorm2d(dim), ReLU(),
+                                        ReflectionPad2d(1), Conv2d(dim, dim, 3), InstanceNorm2d(dim))
+
+    def forward(self, x):
+        return run_layers(list(self.conv_block), x, final_residual=x)
+
+
+class AvgPool3s2(nn.Module):
+    def forward(self, x):
+        return ops.avgpool3s2(x)
+
+
+class MaxPool(nn.Module):
+    def __init__(self, k):
+        super().__init__()
+        self.k = k
+
+    def forward(self, x):
+        return ops.maxpool(x, self.k)

@@ -1,0 +1,547 @@
+"""torch.autograd bindings of the HIP kernels (the only place the C ABI is called from).
+
+PyTorch supplies device memory, the current HIP stream and the autograd tape; every arithmetic op of
+the hot path below is a hand-written gfx950 kernel in libhim_hip.so.  Nothing here runs on the CPU and
+nothing falls back: a non-CUDA tensor raises.
+
+Weight gradients: parameters that live in a flat gradient arena (``optim.FlatArena``) carry
+``_him_direct_grad = True``; their wgrad kernels accumulate straight into ``param.grad`` (which is a view
+of the arena, zeroed by ``zero_grad``) and autograd receives ``None`` -- no per-parameter add pass and no
+bucket copies for the RCCL all-reduce.
+"""
+import ctypes
+
+import torch
+
+from ._cabi import (lib, HimConv2d, HimDeconv2d, ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, PAD_ZERO,
+                    PAD_REFLECT, HimError)
+
+ACTS = {'none': ACT_NONE, 'relu': ACT_RELU, 'lrelu': ACT_LRELU, 'tanh': ACT_TANH}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise HimError('HIP op called with a non-GPU tensor: the product path has no CPU fallback')
+        if t.dtype != torch.float32:
+            raise HimError('HIP ops are fp32 only, got %s' % t.dtype)
+        if not t.is_contiguous():
+            raise HimError('HIP ops need contiguous NCHW tensors')
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _ws(nbytes, like):
+    n = max((int(nbytes) + 3) // 4, 1)
+    return torch.empty(n, dtype=torch.float32, device=like.device)
+
+
+def _direct(p):
+    return getattr(p, '_him_direct_grad', False) and p.grad is not None
+
+
+def _notify(p):
+    """Tell the data-parallel reducer (if any) that this parameter's gradient for the step is final."""
+    r = getattr(p, '_him_reducer', None)
+    if r is not None:
+        r.on_param(p)
+
+
+# ------------------------------------------------------------------------------------------------
+# convolution
+# ------------------------------------------------------------------------------------------------
+def _conv_desc(x, w, stride, pad, pad_mode, act, slope):
+    B, Cin, H, W = x.shape
+    Cout, Cin2, KH, KW = w.shape
+    if Cin2 != Cin:
+        raise HimError('conv2d: weight expects %d input channels, got %d' % (Cin2, Cin))
+    OH = (H + 2 * pad - KH) // stride + 1
+    OW = (W + 2 * pad - KW) // stride + 1
+    return HimConv2d(B, Cin, H, W, Cout, KH, KW, stride, pad, pad_mode, OH, OW, act, slope)
+
+
+class _Conv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, pad_mode, act, slope):
+        x = x.contiguous()
+        _chk(x, w, b)
+        d = _conv_desc(x, w, stride, pad, pad_mode, act, slope)
+        y = torch.empty((d.B, d.Cout, d.OH, d.OW), dtype=torch.float32, device=x.device)
+        lib.him_conv2d_fwd(ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), _stream())
+        ctx.d = d
+        ctx.x, ctx.w, ctx.b = x, w, b
+        ctx.y = y if act != ACT_NONE else None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        d, x, w, b = ctx.d, ctx.x, ctx.w, ctx.b
+        dy = dy.contiguous()
+        st = _stream()
+        if d.act != ACT_NONE:
+            dz = torch.empty_like(dy)
+            lib.him_act_bwd(_p(ctx.y), _p(dy), _p(dz), dy.numel(), d.act, d.slope, st)
+        else:
+            dz = dy
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            nb = lib.him_conv2d_bwd_data_ws(ctypes.byref(d))
+            ws = _ws(nb, x)
+            lib.him_conv2d_bwd_data(ctypes.byref(d), _p(dz), _p(w), _p(dx), _p(ws), nb, st)
+        need_w = ctx.needs_input_grad[1]
+        need_b = b is not None and ctx.needs_input_grad[2]
+        if need_w or need_b:
+            nb = lib.him_conv2d_bwd_weight_ws(ctypes.byref(d))
+            ws = _ws(nb, x)
+            if need_w and _direct(w) and (not need_b or _direct(b)):
+                lib.him_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dz), _p(w.grad), _p(b.grad) if need_b else 0,
+                                          1, _p(ws), nb, st)
+                _notify(w)
+                if need_b:
+                    _notify(b)
+            else:
+                dw = torch.empty_like(w) if need_w else None
+                db = torch.empty_like(b) if need_b else None
+                lib.him_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dz), _p(dw), _p(db), 0, _p(ws), nb, st)
+        ctx.x = ctx.y = None
+        return dx, dw, db, None, None, None, None, None
+
+
+def conv2d(x, w, b=None, stride=1, pad=0, pad_mode='zero', act='none', slope=0.2):
+    """act(conv2d(pad(x), w) + b); pad_mode 'reflect' == nn.ReflectionPad2d(pad) + Conv2d(padding=0)."""
+    return _Conv2d.apply(x, w, b, stride, pad, PAD_REFLECT if pad_mode == 'reflect' else PAD_ZERO, ACTS[act],
+                         float(slope))
+
+
+class _Deconv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, out_pad, act, slope):
+        x = x.contiguous()
+        _chk(x, w, b)
+        B, Cin, H, W = x.shape
+        Cin2, Cout, KH, KW = w.shape
+        if Cin2 != Cin:
+            raise HimError('deconv2d: weight expects %d input channels, got %d' % (Cin2, Cin))
+        OH = (H - 1) * stride - 2 * pad + KH + out_pad
+        OW = (W - 1) * stride - 2 * pad + KW + out_pad
+        d = HimDeconv2d(B, Cin, H, W, Cout, KH, KW, stride, pad, out_pad, OH, OW, act, slope)
+        y = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
+        nb = lib.him_deconv2d_fwd_ws(ctypes.byref(d))
+        ws = _ws(nb, x)
+        lib.him_deconv2d_fwd(ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), _p(ws), nb, _stream())
+        ctx.d = d
+        ctx.x, ctx.w, ctx.b = x, w, b
+        ctx.y = y if act != ACT_NONE else None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        d, x, w, b = ctx.d, ctx.x, ctx.w, ctx.b
+        dy = dy.contiguous()
+        st = _stream()
+        if d.act != ACT_NONE:
+            dz = torch.empty_like(dy)
+            lib.him_act_bwd(_p(ctx.y), _p(dy), _p(dz), dy.numel(), d.act, d.slope, st)
+        else:
+            dz = dy
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            lib.him_deconv2d_bwd_data(ctypes.byref(d), _p(dz), _p(w), _p(dx), st)
+        need_w = ctx.needs_input_grad[1]
+        need_b = b is not None and ctx.needs_input_grad[2]
+        if need_w or need_b:
+            nb = lib.him_deconv2d_bwd_weight_ws(ctypes.byref(d))
+            ws = _ws(nb, x)
+            if need_w and _direct(w) and (not need_b or _direct(b)):
+                lib.him_deconv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dz), _p(w.grad), _p(b.grad) if need_b else 0,
+                                            1, _p(ws), nb, st)
+                _notify(w)
+                if need_b:
+                    _notify(b)
+            else:
+                dw = torch.empty_like(w) if need_w else None
+                db = torch.empty_like(b) if need_b else None
+                lib.him_deconv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dz), _p(dw), _p(db), 0, _p(ws), nb, st)
+        ctx.x = ctx.y = None
+        return dx, dw, db, None, None, None, None, None
+
+
+def conv_transpose2d(x, w, b=None, stride=2, pad=1, out_pad=1, act='none', slope=0.2):
+    return _Deconv2d.apply(x, w, b, stride, pad, out_pad, ACTS[act], float(slope))
+
+
+# ------------------------------------------------------------------------------------------------
+# instance norm (+activation, +residual)
+# ------------------------------------------------------------------------------------------------
+class _InstNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, act, slope, eps):
+        x = x.contiguous()
+        if residual is not None:
+            residual = residual.contiguous()
+        _chk(x, residual)
+        B, Cn, H, W = x.shape
+        planes, hw = B * Cn, H * W
+        y = torch.empty_like(x)
+        mean = torch.empty(planes, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        lib.him_instnorm_fwd(_p(x), _p(residual), _p(y), _p(mean), _p(rstd), planes, hw, eps, act, slope, _stream())
+        ctx.x, ctx.mean, ctx.rstd = x, mean, rstd
+        ctx.cfg = (planes, hw, act, slope)
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        planes, hw, act, slope = ctx.cfg
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(ctx.x)
+            lib.him_instnorm_bwd(_p(ctx.x), _p(ctx.mean), _p(ctx.rstd), _p(dy), _p(dx), planes, hw, act, slope,
+                                 _stream())
+        dres = dy if (ctx.has_res and ctx.needs_input_grad[1]) else None
+        ctx.x = None
+        return dx, dres, None, None, None
+
+
+def instance_norm(x, residual=None, act='none', slope=0.2, eps=1e-5):
+    """act(InstanceNorm2d(affine=False)(x)) [+ residual]."""
+    return _InstNorm.apply(x, residual, ACTS[act], float(slope), float(eps))
+
+
+# ------------------------------------------------------------------------------------------------
+# pooling
+# ------------------------------------------------------------------------------------------------
+class _AvgPool3s2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        _chk(x)
+        B, Cn, H, W = x.shape
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty((B, Cn, OH, OW), dtype=torch.float32, device=x.device)
+        lib.him_avgpool3s2_fwd(_p(x), _p(y), B * Cn, H, W, OH, OW, _stream())
+        ctx.shape = (B, Cn, H, W, OH, OW)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, Cn, H, W, OH, OW = ctx.shape
+        dy = dy.contiguous()
+        dx = torch.empty((B, Cn, H, W), dtype=torch.float32, device=dy.device)
+        lib.him_avgpool3s2_bwd(_p(dy), _p(dx), B * Cn, H, W, OH, OW, _stream())
+        return dx
+
+
+def avgpool3s2(x):
+    """nn.AvgPool2d(3, stride=2, padding=1, count_include_pad=False)."""
+    return _AvgPool3s2.apply(x)
+
+
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k):
+        x = x.contiguous()
+        _chk(x)
+        B, Cn, H, W = x.shape
+        y = torch.empty((B, Cn, H // k, W // k), dtype=torch.float32, device=x.device)
+        lib.him_maxpool_fwd(_p(x), _p(y), B * Cn, H, W, k, _stream())
+        ctx.x, ctx.k = x, k
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, k = ctx.x, ctx.k
+        B, Cn, H, W = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        lib.him_maxpool_bwd(_p(x), _p(dy), _p(dx), B * Cn, H, W, k, _stream())
+        ctx.x = None
+        return dx, None
+
+
+def maxpool(x, k):
+    return _MaxPool.apply(x, int(k))
+
+
+# ------------------------------------------------------------------------------------------------
+# channel plumbing: cat / slice / mask-multiply / blend
+# ------------------------------------------------------------------------------------------------
+class _CatMask(torch.autograd.Function):
+    """out = f(mask) * cat(tensors, dim=1); mask (B,1,H,W) or None; mode 0 none, 1 mask, 2 (1-mask)."""
+
+    @staticmethod
+    def forward(ctx, mask, mode, *ts):
+        ts = [t.contiguous() for t in ts]
+        _chk(mask, *ts)
+        B, _, H, W = ts[0].shape
+        Ctot = sum(t.shape[1] for t in ts)
+        out = torch.empty((B, Ctot, H, W), dtype=torch.float32, device=ts[0].device)
+        st, c0 = _stream(), 0
+        for t in ts:
+            lib.him_copy_channels(_p(t), t.shape[1], 0, _p(out), Ctot, c0, t.shape[1], B, H * W, _p(mask), mode, 0, st)
+            c0 += t.shape[1]
+        ctx.mask, ctx.mode = mask, mode
+        ctx.chs = [t.shape[1] for t in ts]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        B, Ctot, H, W = dout.shape
+        st, c0, grads = _stream(), 0, []
+        for i, ch in enumerate(ctx.chs):
+            if ctx.needs_input_grad[2 + i]:
+                g = torch.empty((B, ch, H, W), dtype=torch.float32, device=dout.device)
+                lib.him_copy_channels(_p(dout), Ctot, c0, _p(g), ch, 0, ch, B, H * W, _p(ctx.mask), ctx.mode, 0, st)
+                grads.append(g)
+            else:
+                grads.append(None)
+            c0 += ch
+        return (None, None) + tuple(grads)
+
+
+def cat_channels(tensors, mask=None, mask_mode=0):
+    return _CatMask.apply(mask, int(mask_mode if mask is not None else 0), *tensors)
+
+
+def mul_mask(x, mask):
+    """x * mask.repeat(1, C, 1, 1)."""
+    return _CatMask.apply(mask, 1, x)
+
+
+class _Blend(torch.autograd.Function):
+    """out = (1-m) * a[:, a0:a0+C] + m * b    (m: (B,1,H,W))."""
+
+    @staticmethod
+    def forward(ctx, a, a0, b, m):
+        a, b, m = a.contiguous(), b.contiguous(), m.contiguous()
+        _chk(a, b, m)
+        B, Cn, H, W = b.shape
+        out = torch.empty_like(b)
+        lib.him_blend(_p(a), a.shape[1], a0, _p(b), Cn, 0, _p(m), _p(out), B, Cn, H * W, _stream())
+        ctx.m, ctx.a0, ctx.Ca = m, a0, a.shape[1]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        B, Cn, H, W = dout.shape
+        st = _stream()
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            if ctx.Ca == Cn:
+                da = torch.empty_like(dout)
+            else:
+                da = torch.zeros((B, ctx.Ca, H, W), dtype=torch.float32, device=dout.device)
+            lib.him_copy_channels(_p(dout), Cn, 0, _p(da), ctx.Ca, ctx.a0, Cn, B, H * W, _p(ctx.m), 2, 0, st)
+        if ctx.needs_input_grad[2]:
+            db = torch.empty_like(dout)
+            lib.him_copy_channels(_p(dout), Cn, 0, _p(db), Cn, 0, Cn, B, H * W, _p(ctx.m), 1, 0, st)
+        return da, None, db, None
+
+
+def blend(a, b, m, a0=0):
+    return _Blend.apply(a, int(a0), b, m)
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        _chk(a, b)
+        out = torch.empty_like(a)
+        lib.him_add(_p(a), _p(b), _p(out), a.numel(), _stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+# ------------------------------------------------------------------------------------------------
+# input encoding (no gradients)
+# ------------------------------------------------------------------------------------------------
+def encode_channels(label, inst, image, mask_in, label_nc, use_edges, extra_after=0, color_emb=None):
+    """Builds, in ONE (B, Ctot, H, W) buffer and without any torch.cat,
+         [ one-hot(label) | edges(inst)? | (1-mask)*image | emb*mask ? ]
+    (reference encode_input + the torch.cat at pix2pixHD_condImg_model.py:204).  Returns (buf, n_label, n_cond)."""
+    _chk(label, inst, image, mask_in, color_emb)
+    B, _, H, W = image.shape
+    hw = H * W
+    n_label = (label_nc if label_nc else label.shape[1]) + (1 if use_edges else 0)
+    n_cond = 3 + (3 if color_emb is not None else 0)
+    Ctot = n_label + n_cond
+    buf = torch.empty((B, Ctot, H, W), dtype=torch.float32, device=image.device)
+    st = _stream()
+    if label_nc:
+        lib.him_onehot(_p(label), _p(buf), B, label_nc, Ctot, 0, hw, st)
+        c = label_nc
+    else:
+        c = label.shape[1]
+        lib.him_copy_channels(_p(label), c, 0, _p(buf), Ctot, 0, c, B, hw, 0, 0, 0, st)
+    if use_edges:
+        lib.him_edges(_p(inst), _p(buf), B, H, W, Ctot, c, st)
+        c += 1
+    lib.him_copy_channels(_p(image), 3, 0, _p(buf), Ctot, c, 3, B, hw, _p(mask_in), 2, 0, st)
+    c += 3
+    if color_emb is not None:
+        lib.him_tile_embed(_p(color_emb), _p(mask_in), _p(buf), B, Ctot, c, hw, st)
+    return buf, n_label, n_cond
+
+
+def slice_channels(x, c0, n):
+    """contiguous copy of x[:, c0:c0+n] (no gradient)."""
+    _chk(x)
+    B, Cn, H, W = x.shape
+    out = torch.empty((B, n, H, W), dtype=torch.float32, device=x.device)
+    lib.him_copy_channels(_p(x), Cn, c0, _p(out), n, 0, n, B, H * W, 0, 0, 0, _stream())
+    return out
+
+
+def masked_mean_color(image, obj_mask, noise=None):
+    _chk(image, obj_mask, noise)
+    B, _, H, W = image.shape
+    emb = torch.empty((B, 3), dtype=torch.float32, device=image.device)
+    lib.him_masked_mean(_p(image), _p(obj_mask), _p(noise), _p(emb), B, H * W, _stream())
+    return emb
+
+
+# ------------------------------------------------------------------------------------------------
+# losses
+# ------------------------------------------------------------------------------------------------
+class _L1Mean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        _chk(a, b)
+        if a.shape != b.shape:
+            raise HimError('l1: shape mismatch %s vs %s' % (tuple(a.shape), tuple(b.shape)))
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        nb = lib.him_reduce_ws(a.numel())
+        ws = _ws(nb, a)
+        lib.him_l1_mean_fwd(_p(a), _p(b), a.numel(), _p(out), _p(ws), nb, _stream())
+        ctx.a, ctx.b = a, b
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.a, ctx.b
+        g = g.contiguous()
+        da = torch.empty_like(a)
+        lib.him_l1_mean_bwd(_p(a), _p(b), a.numel(), _p(g), _p(da), 0, _stream())
+        ctx.a = ctx.b = None
+        return da, None
+
+
+def l1_mean(a, b):
+    """nn.L1Loss()(a, b.detach())."""
+    return _L1Mean.apply(a, b.detach())
+
+
+class _MSEConst(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, target):
+        x = x.contiguous()
+        _chk(x)
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        nb = lib.him_reduce_ws(x.numel())
+        ws = _ws(nb, x)
+        lib.him_mse_const_fwd(_p(x), x.numel(), target, _p(out), _p(ws), nb, _stream())
+        ctx.x, ctx.t = x, target
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x = ctx.x
+        g = g.contiguous()
+        dx = torch.empty_like(x)
+        lib.him_mse_const_bwd(_p(x), x.numel(), ctx.t, _p(g), _p(dx), 0, _stream())
+        ctx.x = None
+        return dx, None
+
+
+def mse_const(x, target):
+    """nn.MSELoss()(x, full_like(x, target))."""
+    return _MSEConst.apply(x, float(target))
+
+
+# ------------------------------------------------------------------------------------------------
+# spectral norm
+# ------------------------------------------------------------------------------------------------
+class _SNSigma(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, W, u):
+        W2 = W.contiguous().view(W.shape[0], -1)
+        u = u.contiguous()
+        _chk(W2, u)
+        rows, cols = W2.shape
+        v = torch.empty(cols, dtype=torch.float32, device=W.device)
+        u_new = torch.empty((1, rows), dtype=torch.float32, device=W.device)
+        sigma = torch.empty((1, 1), dtype=torch.float32, device=W.device)
+        nb = lib.him_sn_ws(rows, cols)
+        ws = _ws(nb, W)
+        lib.him_sn_power_iter_fwd(_p(W2), _p(u), rows, cols, _p(v), _p(u_new), _p(sigma), _p(ws), nb, _stream())
+        ctx.W, ctx.u, ctx.v, ctx.u_new, ctx.sigma = W2, u, v, u_new, sigma
+        ctx.shape = W.shape
+        ctx.mark_non_differentiable(u_new)
+        return sigma, u_new
+
+    @staticmethod
+    def backward(ctx, g, _gu):
+        W2 = ctx.W
+        rows, cols = W2.shape
+        g = g.contiguous()
+        dW = torch.empty_like(W2)
+        nb = lib.him_sn_ws(rows, cols)
+        ws = _ws(nb, W2)
+        lib.him_sn_power_iter_bwd(_p(W2), _p(ctx.u), _p(ctx.v), _p(ctx.u_new), _p(ctx.sigma), _p(g), rows, cols,
+                                  _p(dW), 0, _p(ws), nb, _stream())
+        return dW.view(ctx.shape), None
+
+
+def sn_max_singular_value(W, u):
+    """(sigma (1,1), u' (1,rows)) of models/sn_utils.py:11-25 with Ip = 1; sigma is differentiable in W through
+    BOTH normalisations (nothing detached, as in the reference)."""
+    return _SNSigma.apply(W, u)
+
+
+class _DivScalar(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, W, sigma):
+        W = W.contiguous()
+        sigma = sigma.contiguous()
+        _chk(W, sigma)
+        out = torch.empty_like(W)
+        lib.him_div_scalar_fwd(_p(W), _p(sigma), _p(out), W.numel(), _stream())
+        ctx.W, ctx.sigma = W, sigma
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        W, sigma = ctx.W, ctx.sigma
+        dout = dout.contiguous()
+        dW = torch.empty_like(W)
+        dsig = torch.empty_like(sigma)
+        ws = _ws(4096, W)
+        lib.him_div_scalar_bwd(_p(W), _p(sigma), _p(dout), _p(dW), _p(dsig), W.numel(), 0, _p(ws), 4096, _stream())
+        return dW, dsig
+
+
+def div_scalar(W, sigma):
+    return _DivScalar.apply(W, sigma)

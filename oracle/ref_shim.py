@@ -1,0 +1,122 @@
+"""Import harness for the *real* reference (``/root/reference``)  --  TEST INFRASTRUCTURE.
+
+Works only in the build container (the reference does not travel to the GPU box).  Used by
+``tests/golden/make_golden.py`` to (1) validate ``oracle/ref_cpu.py`` against the reference's own
+classes and (2) emit the golden vectors committed under ``tests/golden/``.  Nothing in
+``/root/reference`` is modified: the shim emulates Python-2 implicit relative imports through
+``sys.path``, stubs the absent ``torchvision``/``cStringIO`` modules and makes ``.cuda()`` an identity.
+"""
+import importlib
+import io
+import os
+import sys
+import types
+
+import torch
+import torch.nn as nn
+
+REF = os.environ.get('HIM_REFERENCE', '/root/reference')
+
+
+def available():
+    return os.path.isdir(os.path.join(REF, 'models'))
+
+
+_installed = False
+
+
+def install():
+    global _installed
+    if _installed:
+        return
+    assert available(), 'reference checkout not present'
+    sys.path[:0] = [REF, os.path.join(REF, 'models'), os.path.join(REF, 'options')]
+    cs = types.ModuleType('cStringIO')
+    cs.StringIO = io.BytesIO
+    sys.modules['cStringIO'] = cs
+    tv = types.ModuleType('torchvision')
+    tvm = types.ModuleType('torchvision.models')
+    tvt = types.ModuleType('torchvision.transforms')
+
+    def vgg19(pretrained=False):
+        cfg = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M',
+               512, 512, 512, 512, 'M']
+        layers, c = [], 3
+        for v in cfg:
+            if v == 'M':
+                layers.append(nn.MaxPool2d(2, 2))
+            else:
+                layers += [nn.Conv2d(c, v, 3, padding=1), nn.ReLU(True)]
+                c = v
+        m = nn.Module()
+        m.features = nn.Sequential(*layers)
+        return m
+
+    tvm.vgg19 = vgg19
+    tv.models, tv.transforms = tvm, tvt
+    sys.modules.update({'torchvision': tv, 'torchvision.models': tvm, 'torchvision.transforms': tvt})
+    torch.Tensor.cuda = lambda s, *a, **k: s
+    nn.Module.cuda = lambda s, *a, **k: s
+    torch.cuda.FloatTensor = torch.FloatTensor
+    torch.cuda.ByteTensor = torch.ByteTensor
+    torch.cuda.set_device = lambda *a, **k: None
+    _installed = True
+
+
+def nets():
+    """(Pix2Pix_NET, Discriminator_NET, losses, sn_utils, layer_util) reference modules."""
+    install()
+    return tuple(importlib.import_module(m) for m in
+                 ('Pix2Pix_NET', 'Discriminator_NET', 'losses', 'sn_utils', 'layer_util'))
+
+
+def make_opt(argv):
+    install()
+    from options.mask2image_train_options import MaskToImageTrainOptions
+    stdout = sys.stdout
+    sys.stdout = io.StringIO()
+    try:
+        opt = MaskToImageTrainOptions().parse(save=False, default_args=argv)
+    finally:
+        sys.stdout = stdout
+    return opt
+
+
+def make_model(argv, color=False):
+    """Construct the reference's Pix2PixHDModel_condImg[Color] on CPU."""
+    install()
+    opt = make_opt(argv)
+    name = 'models.pix2pixHD_condImgColor_model' if color else 'models.pix2pixHD_condImg_model'
+    M = importlib.import_module(name)
+    cls = M.Pix2PixHDModel_condImgColor if color else M.Pix2PixHDModel_condImg
+    real = torch.cuda.is_available
+    torch.cuda.is_available = lambda: True
+    stdout = sys.stdout
+    sys.stdout = io.StringIO()
+    try:
+        model = cls(opt)
+    finally:
+        sys.stdout = stdout
+        torch.cuda.is_available = lambda: False
+    model._restore_cuda_available = real
+    return model, opt
+
+
+def ref_step(model, batch, color=False):
+    """train_mask2image.py:58-86 executed on the reference model object; returns the 5 losses."""
+    kw = dict(label=batch['label'], inst=batch['inst'], image=batch['image'], feat=None,
+              mask_in=batch['mask_in'], mask_out=batch['mask_out'], infer=False)
+    if color:
+        kw['obj_mask'] = batch['obj_mask']
+    losses, _ = model(**kw)
+    losses = [torch.mean(x) if not isinstance(x, int) else x for x in losses]
+    ld = dict(zip(model.loss_names, losses))
+    loss_D = (ld['D_fake'] + ld['D_real']) * 0.5
+    loss_G = ld['G_GAN'] + ld['G_GAN_Feat'] + ld['G_VGG']
+    model.optimizer_G.zero_grad()
+    loss_G.backward()
+    model.optimizer_G.step()
+    model.optimizer_D.zero_grad()
+    loss_D.backward()
+    model.optimizer_D.step()
+    return {k: float(v.detach()) for k, v in ld.items()}

@@ -1,0 +1,179 @@
+"""Generate the golden vectors under tests/golden/ by running the REAL reference (imported from
+/root/reference through oracle/ref_shim.py) and, in the same breath, assert that oracle/ref_cpu.py
+reproduces it.  Runs only in the build container.  Usage:
+
+    python tests/golden/make_golden.py [tiny] [c1] [c2]
+
+Fixtures hold arrays + the flag dict only (no reference source).  Weights/batches are NOT stored: they
+are regenerated from neurips18_hierchical_image_manipulation_amd.synth seeds (G=1, D=2, VGG=3; batch
+seed = 1000+step*64+rank).
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.abspath(os.path.join(HERE, '..', '..')))
+from oracle import ref_shim, ref_cpu                                     # noqa: E402
+from neurips18_hierchical_image_manipulation_amd import synth            # noqa: E402
+
+SEED_G, SEED_D, SEED_V = 1, 2, 3
+NAMES = ref_cpu.Mask2ImageModel.loss_names
+
+
+def flags_to_argv(fl):
+    argv = ['--name', 'g', '--checkpoints_dir', '/tmp/him_golden_ck', '--gpu_ids', '0']
+    for k, v in fl.items():
+        if isinstance(v, bool):
+            if v:
+                argv.append('--' + k)
+        else:
+            argv += ['--' + k, str(v)]
+    return argv
+
+
+def load_same(rm, om):
+    sdG = synth.init_state_dict(om.netG.state_dict(), SEED_G)
+    sdD = synth.init_state_dict(om.netD.state_dict(), SEED_D)
+    assert list(rm.netG.state_dict().keys()) == list(sdG.keys())
+    assert list(rm.netD.state_dict().keys()) == list(sdD.keys())
+    for m in (rm, om):
+        m.netG.load_state_dict(sdG)
+        m.netD.load_state_dict(sdD)
+    if om.vgg is not None:
+        sdV = synth.init_state_dict(om.vgg.state_dict(), SEED_V, 'vgg')
+        rm.criterionVGG.vgg.load_state_dict(sdV)
+        om.vgg.load_state_dict(sdV)
+
+
+def trajectory(tag, fl, B, H, W, steps, color=False, save_outputs=False):
+    t0 = time.time()
+    rm, _ = ref_shim.make_model(flags_to_argv(dict(fl, batchSize=B)), color=color)
+    om = ref_cpu.Mask2ImageModel(ref_cpu.Opt(**fl))
+    load_same(rm, om)
+    extra = {}
+    if save_outputs:
+        b0 = synth.make_batch(0, 0, B, H, W, fl.get('label_nc', 35), color)
+        with torch.no_grad():
+            onehot, cond = om.encode_input(b0['label'], b0['inst'], b0['image'], b0['mask_in'],
+                                           b0.get('obj_mask'))
+            if color:
+                r_in = rm.encode_input(b0['label'], b0['inst'], b0['image'], None, mask_in=b0['mask_in'],
+                                       obj_mask=b0['obj_mask'])
+            else:
+                r_in = rm.encode_input(b0['label'], b0['inst'], b0['image'], None, mask_in=b0['mask_in'])
+            assert torch.equal(r_in[0], onehot) and torch.allclose(r_in[4], cond, atol=1e-7)
+            fake_o = om.generate(onehot, cond, b0['mask_in'])
+            if fl['netG'] == 'global':
+                fake_r = rm.netG.forward(torch.cat((r_in[0], r_in[4]), 1), b0['mask_in'])
+            else:
+                fake_r = rm.netG.forward(r_in[4], r_in[0], b0['mask_in'])
+            assert torch.allclose(fake_r, fake_o, atol=1e-6), (fake_r - fake_o).abs().max()
+            d_in = torch.randn(B, om.d_in, H, W, generator=torch.Generator().manual_seed(5))
+            dr, do = rm.netD(d_in), om.netD(d_in)
+            for a, b in zip(dr, do):
+                for x, y in zip(a, b):
+                    assert torch.allclose(x, y, atol=1e-6)
+            extra['fake0'] = fake_r.numpy()
+            extra['cond0'] = r_in[4].numpy()
+            extra['d_in'] = d_in.numpy()
+            for i, sc in enumerate(dr):
+                extra['d_logits%d' % i] = sc[-1].numpy()
+                extra['d_feat%d_0' % i] = sc[0].numpy()
+    ref_l, ora_l = [], []
+    uni = torch.Tensor.uniform_
+    if color:  # colour noise U(0.97,1.03) -> exactly 1.0 in parity mode
+        torch.Tensor.uniform_ = lambda self, *a, **k: self.fill_(0.5)
+    try:
+        for s in range(steps):
+            b = synth.make_batch(s, 0, B, H, W, fl.get('label_nc', 35), color)
+            r = ref_shim.ref_step(rm, b, color)
+            o = om.optimize_parameters(b)
+            ref_l.append([r[k] for k in NAMES])
+            ora_l.append([o[k] for k in NAMES])
+    finally:
+        torch.Tensor.uniform_ = uni
+    ref_l, ora_l = np.array(ref_l, np.float64), np.array(ora_l, np.float64)
+    rel = np.abs(ref_l - ora_l) / np.maximum(np.abs(ref_l), 1e-12)
+    print('%s: %d steps, max rel(oracle vs reference) = %.3e, %.1fs' % (tag, steps, rel.max(), time.time() - t0))
+    assert rel.max() < 1e-5, rel
+    np.savez_compressed(os.path.join(HERE, tag + '.npz'), flags=json.dumps(fl), B=B, H=H, W=W,
+                        color=int(color), losses=ref_l.astype(np.float32), loss_names=np.array(NAMES), **extra)
+
+
+def golden_nets():
+    """Forward of classes the reference models cannot reach (LocalEnhancer) + SN + edges."""
+    P, D, L, S, U = ref_shim.nets()
+    out = {}
+    # LocalEnhancer (models/Pix2Pix_NET.py:8-61)
+    r = P.LocalEnhancer(9, 3, ngf=4, n_downsample_global=2, n_blocks_global=2, n_local_enhancers=1, n_blocks_local=2)
+    o = ref_cpu.LocalEnhancer(9, 3, ngf=4, n_downsample_global=2, n_blocks_global=2, n_local_enhancers=1, n_blocks_local=2)
+    sd = synth.init_state_dict(o.state_dict(), 11)
+    assert list(r.state_dict().keys()) == list(sd.keys())
+    r.load_state_dict(sd)
+    o.load_state_dict(sd)
+    x = torch.randn(2, 9, 32, 64, generator=torch.Generator().manual_seed(7))
+    with torch.no_grad():
+        yr, yo = r(x), o(x)
+    assert torch.allclose(yr, yo, atol=1e-6)
+    out.update(local_x=x.numpy(), local_y=yr.numpy())
+    # spectral norm (models/sn_utils.py:8-25): sigma, u', W/sigma, d sigma / dW
+    for tag, shape in (('sn_small', (16, 8, 3, 3)), ('sn_big', (512, 256, 4, 4))):
+        g = torch.Generator().manual_seed(13)
+        W = (torch.randn(*shape, generator=g) * 0.05).requires_grad_(True)
+        u = torch.randn(1, shape[0], generator=g)
+        sig_r, u_r = S.max_singular_value(W, u, 1)
+        (gW_r,) = torch.autograd.grad(sig_r.sum(), W)
+        W2 = W.detach().clone().requires_grad_(True)
+        sig_o, u_o = ref_cpu.max_singular_value(W2, u, 1)
+        (gW_o,) = torch.autograd.grad(sig_o.sum(), W2)
+        assert torch.allclose(sig_r, sig_o) and torch.allclose(gW_r, gW_o, atol=1e-7)
+        out[tag + '_sigma'] = sig_r.detach().numpy()
+        out[tag + '_u'] = u_r.detach().numpy()
+        if tag == 'sn_small':
+            out[tag + '_W'] = W.detach().numpy()
+            out[tag + '_u0'] = u.numpy()
+            out[tag + '_gW'] = gW_r.numpy()
+        else:
+            out[tag + '_gW_sum'] = np.array([gW_r.double().sum().item(), gW_r.double().abs().sum().item()])
+    # instance edges (models/pix2pixHD_condImg_model.py:285-291)
+    rm, _ = ref_shim.make_model(flags_to_argv(dict(model='pix2pixHD_condImg', netG='global', ngf=4, ndf=4,
+                                                   n_blocks_global=1, num_D=1, label_nc=35, no_vgg_loss=True)))
+    inst = torch.from_numpy(np.random.Generator(np.random.Philox(5)).integers(0, 3, (2, 1, 16, 32)).astype(np.float32))
+    er = rm.get_edges(inst)
+    assert torch.equal(er, ref_cpu.get_edges(inst))
+    out.update(edge_inst=inst.numpy(), edge_map=er.numpy())
+    np.savez_compressed(os.path.join(HERE, 'nets_misc.npz'), **out)
+    print('nets_misc: LocalEnhancer / SN / edges pinned')
+
+
+TINY = dict(model='pix2pixHD_condImg', netG='global', ngf=8, ndf=8, n_downsample_global=4, n_blocks_global=2,
+            num_D=2, n_layers_D=3, label_nc=35, no_instance=True)
+TINY_GATE = dict(TINY, use_output_gate=True, num_D=3)
+TINY_INST = dict(TINY, no_instance=False, n_downsample_global=3)
+TINY_TWO = dict(model='pix2pixHD_condImg', netG='global_twostream', ngf=8, ndf=8, n_downsample_global=4,
+                n_blocks_global=2, num_D=2, n_layers_D=3, label_nc=35, no_instance=True, no_imgCond=True,
+                which_encoder='ctx_label', use_skip=True, use_output_gate=True, mask_gan_input=True)
+TINY_COLOR = dict(TINY_TWO, model='pix2pixHD_condImgColor', label_nc=49)
+C1 = dict(model='pix2pixHD_condImg', netG='global', ngf=64, ndf=64, n_downsample_global=4, n_blocks_global=9,
+          num_D=1, n_layers_D=3, label_nc=35, no_instance=True)
+C2 = dict(C1, num_D=3)
+
+if __name__ == '__main__':
+    what = sys.argv[1:] or ['tiny']
+    torch.manual_seed(0)
+    if 'tiny' in what:
+        golden_nets()
+        trajectory('tiny_global', TINY, 2, 32, 64, 20, save_outputs=True)
+        trajectory('tiny_gate3', TINY_GATE, 2, 32, 64, 5)
+        trajectory('tiny_inst', TINY_INST, 2, 32, 64, 5, save_outputs=True)
+        trajectory('tiny_twostream', TINY_TWO, 2, 64, 64, 20, save_outputs=True)
+        trajectory('tiny_color', TINY_COLOR, 2, 64, 64, 5, color=True)
+    if 'c1' in what:
+        trajectory('c1_traj', C1, 1, 128, 256, 20)
+    if 'c2' in what:
+        trajectory('c2_traj', C2, 8, 256, 512, 20)

@@ -1,0 +1,166 @@
+"""not gpu: C-ABI surface, host logic (flags, fusion plan, key compatibility), synthetic data determinism,
+and the world_size-2 gloo run of the bucketed gradient reducer."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+
+
+def test_library_exports_every_declared_symbol():
+    from neurips18_hierchical_image_manipulation_amd import _cabi
+    hdr = open(os.path.join(ROOT, 'include', 'him.h')).read()
+    declared = sorted(set(re.findall(r'\b(him_[a-z0-9_]+)\s*\(', hdr)))
+    assert declared, 'no declarations parsed'
+    assert os.path.isfile(_cabi.LIB_PATH), 'libhim_hip.so not built'
+    dll = ctypes.CDLL(_cabi.LIB_PATH)
+    for name in declared:
+        assert hasattr(dll, name), 'missing export %s' % name
+    assert sorted(_cabi.EXPORTS) == declared, 'ctypes table and header disagree: %s' % (
+        set(_cabi.EXPORTS) ^ set(declared))
+    assert _cabi.lib.him_arch() == b'gfx950'
+
+
+def test_descriptor_validation_without_gpu():
+    """Argument checking happens before any launch, so it is testable on the CPU box."""
+    from neurips18_hierchical_image_manipulation_amd import _cabi
+    d = _cabi.HimConv2d(1, 3, 8, 8, 4, 3, 3, 1, 1, 0, 9, 8, 0, 0.0)       # wrong OH
+    with pytest.raises(_cabi.HimError, match='OH/OW'):
+        _cabi.lib.him_conv2d_fwd(ctypes.byref(d), 0, 0, 0, 0, 0)
+    d = _cabi.HimConv2d(1, 3, 8, 8, 4, 3, 3, 3, 1, 0, 3, 3, 0, 0.0)       # stride 3
+    with pytest.raises(_cabi.HimError, match='stride'):
+        _cabi.lib.him_conv2d_fwd(ctypes.byref(d), 0, 0, 0, 0, 0)
+    ok = _cabi.HimConv2d(8, 1024, 16, 32, 1024, 3, 3, 1, 1, 1, 16, 32, 0, 0.0)
+    assert _cabi.lib.him_conv2d_bwd_data_ws(ctypes.byref(ok)) >= 4 * (1024 * 1024 * 9 + 8 * 1024 * 18 * 34)
+    with pytest.raises(_cabi.HimError, match='ws'):
+        _cabi.lib.him_l1_mean_fwd(0, 0, 16, 0, 0, 0, 0)
+
+
+def test_state_dict_keys_match_oracle_for_every_generator():
+    from oracle import ref_cpu
+    from neurips18_hierchical_image_manipulation_amd.models import Pix2Pix_NET as P
+    from neurips18_hierchical_image_manipulation_amd.models.Discriminator_NET import MultiscaleDiscriminator
+    from neurips18_hierchical_image_manipulation_amd.models.layer_util import Vgg19
+    pairs = [
+        (P.GlobalGenerator(38, 3, 8, 4, 2), ref_cpu.GlobalGenerator(38, 3, 8, 4, 2)),
+        (P.LocalEnhancer(38, 3, 4, 3, 2, 1, 2), ref_cpu.LocalEnhancer(38, 3, 4, 3, 2, 1, 2)),
+        (P.GlobalTwoStreamGenerator(35, 3, 8, 4, 2, use_skip=True, which_stream='ctx_label', use_output_gate=True),
+         ref_cpu.GlobalTwoStreamGenerator(35, 3, 8, 4, 2, True, 'ctx_label', True)),
+        (MultiscaleDiscriminator(41, 8, 3, num_D=3), ref_cpu.MultiscaleDiscriminator(41, 8, 3, 3)),
+        (Vgg19(), ref_cpu.Vgg19()),
+    ]
+    for a, b in pairs:
+        sa, sb = a.state_dict(), b.state_dict()
+        assert list(sa.keys()) == list(sb.keys())
+        assert [tuple(v.shape) for v in sa.values()] == [tuple(v.shape) for v in sb.values()]
+
+
+def test_fusion_plan_groups_pad_conv_norm_act(monkeypatch):
+    from neurips18_hierchical_image_manipulation_amd import nn as hn, ops
+    calls = []
+    monkeypatch.setattr(ops, 'conv2d', lambda x, w, b, s, p, pm, act, sl: calls.append(('conv', p, pm, act)) or x)
+    monkeypatch.setattr(ops, 'conv_transpose2d', lambda x, w, b, s, p, op, act, sl: calls.append(('deconv', act)) or x)
+    monkeypatch.setattr(ops, 'instance_norm', lambda x, r, act, sl, eps: calls.append(('in', act, r is not None)) or x)
+    layers = [hn.ReflectionPad2d(3), hn.Conv2d(4, 4, 7), hn.InstanceNorm2d(4), hn.ReLU(),
+              hn.Conv2d(4, 4, 4, 2, 2), hn.LeakyReLU(0.2),
+              hn.ConvTranspose2d(4, 4, 3), hn.InstanceNorm2d(4), hn.ReLU(),
+              hn.ReflectionPad2d(3), hn.Conv2d(4, 3, 7), hn.Tanh()]
+    hn.run_layers(layers, torch.zeros(1))
+    assert calls == [('conv', 3, 'reflect', 'none'), ('in', 'relu', False), ('conv', 2, 'zero', 'lrelu'),
+                     ('deconv', 'none'), ('in', 'relu', False), ('conv', 3, 'reflect', 'tanh')]
+    calls.clear()
+    hn.ResnetBlock(4)(torch.zeros(1))
+    assert calls == [('conv', 1, 'reflect', 'none'), ('in', 'relu', False), ('conv', 1, 'reflect', 'none'),
+                     ('in', 'none', True)]
+
+
+def test_options_defaults_are_the_reference_defaults():
+    from neurips18_hierchical_image_manipulation_amd.options import MaskToImageTrainOptions, complete
+    opt = MaskToImageTrainOptions().parse(save=False, default_args=['--no_instance', '--netG', 'global_twostream',
+                                                                    '--gpu_ids', '0,1'])
+    assert (opt.ngf, opt.n_downsample_global, opt.n_blocks_global, opt.num_D, opt.n_layers_D, opt.ndf) == (64, 4, 9, 2, 3, 64)
+    assert (opt.lambda_feat, opt.lr, opt.beta1, opt.pool_size, opt.label_nc) == (10.0, 2e-4, 0.5, 0, 35)
+    assert opt.gpu_ids == [0, 1] and opt.isTrain and opt.no_instance
+    c = complete(dict(netG='global'))
+    assert c.n_blocks_global == 9 and c.isTrain
+
+
+def test_create_model_without_gpu_fails_loudly():
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from neurips18_hierchical_image_manipulation_amd.models import create_model
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        create_model(dict(model='pix2pixHD_condImg', gpu_ids=[0], ngf=4, ndf=4, n_blocks_global=1,
+                          checkpoints_dir='/tmp/x', name='y'))
+    with pytest.raises(NotImplementedError):
+        create_model(dict(model='nope', gpu_ids=[0], checkpoints_dir='/tmp/x', name='y'))
+
+
+def test_synthetic_batches_and_weights_are_deterministic():
+    from neurips18_hierchical_image_manipulation_amd import synth
+    a, b = synth.make_batch(3, 1, 2, 32, 64), synth.make_batch(3, 1, 2, 32, 64)
+    for k in a:
+        assert torch.equal(a[k], b[k])
+    assert set(a.keys()) == {'label', 'inst', 'image', 'mask_in', 'mask_out'}
+    assert a['label'].shape == (2, 1, 32, 64) and a['label'].max() < 35 and a['label'].min() >= 0
+    assert float(a['image'].min()) >= -1 and float(a['image'].max()) < 1
+    assert a['mask_in'][0, 0, 8:24, 16:48].min() == 1 and a['mask_in'].sum() == 2 * 16 * 32
+    assert (a['mask_out'] >= a['mask_in']).all()
+    assert not torch.equal(a['image'], synth.make_batch(4, 1, 2, 32, 64)['image'])
+    shapes = {'m.weight': (4, 3, 3, 3), 'm.bias': (4,)}
+    s1, s2 = synth.init_state_dict(shapes, 5), synth.init_state_dict(shapes, 5)
+    assert torch.equal(s1['m.weight'], s2['m.weight']) and abs(float(s1['m.weight'].std()) - 0.02) < 0.01
+    assert float(s1['m.bias'].abs().max()) <= 1 / np.sqrt(27)
+
+
+WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from neurips18_hierchical_image_manipulation_amd.dist import GradReducer, init_process_group_from_env
+rank, local, world = init_process_group_from_env('gloo')
+assert world == 2
+class P(object): pass
+sizes = [5, 70, 3, 130, 64, 9]
+ranges, off = [], 0
+for n in sizes:
+    ranges.append((off, off + n)); off += (n + 63) // 64 * 64
+flat = torch.zeros(off)
+params = []
+for r in ranges:
+    p = P(); p._him_arena_range = r; params.append(p)
+red = GradReducer(flat, ranges, bucket_bytes=4 * 128)
+red.attach(params)
+assert len(red.buckets) >= 3 and red.buckets[0][1] == ranges[-1][1]
+for step in range(3):
+    flat.zero_()
+    red.begin(contributions=2)
+    for rep in range(2):
+        for p in reversed(params):                       # backward order, two contributions each
+            s, e = p._him_arena_range
+            flat[s:e] += (rank + 1) * (step + 1) * torch.arange(e - s, dtype=torch.float32)
+            red.on_param(p)
+    red.finish()
+    for (s, e) in ranges:                                # avg over ranks of 2*(rank+1)*(step+1)*i
+        exp = 2 * 1.5 * (step + 1) * torch.arange(e - s, dtype=torch.float32)
+        assert torch.allclose(flat[s:e], exp), (rank, step, s, e)
+assert all(red.launched)
+print('RANK%%d OK' %% rank)
+'''
+
+
+def test_gloo_world2_bucketed_reducer(tmp_path):
+    script = tmp_path / 'w.py'
+    script.write_text(WORKER % ROOT)
+    port = 29500 + os.getpid() % 1000
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr',
+           '127.0.0.1', '--master-port', str(port), str(script)]
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert 'RANK0 OK' in r.stdout and 'RANK1 OK' in r.stdout

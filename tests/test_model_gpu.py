@@ -1,0 +1,168 @@
+"""-m gpu: the whole mask2image trainer on the HIP path against (1) the committed golden vectors generated
+from the REAL reference (tests/golden/*.npz) and (2) the CPU oracle run side by side on the same seeded
+weights and batches.  Tolerances (fp32 both sides, different summation orders): forward tensors 1e-4 of
+max|ref|; step-0 losses 1e-4 relative; 20-step loss trajectories 1e-3 relative on the full-size configs."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from util import assert_close, load_golden
+
+pytestmark = pytest.mark.gpu
+NAMES = ['G_GAN', 'G_GAN_Feat', 'G_VGG', 'D_real', 'D_fake']
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'gpurun_out')
+
+
+def build(flags, tmp='/tmp/him_test_ck'):
+    from neurips18_hierchical_image_manipulation_amd.models import create_model
+    from neurips18_hierchical_image_manipulation_amd import synth
+    model = create_model(dict(flags, gpu_ids=[0], isTrain=True, checkpoints_dir=tmp, name='t'))
+    model.netG.load_state_dict(synth.init_state_dict(model.netG.state_dict(), 1))
+    model.netD.load_state_dict(synth.init_state_dict(model.netD.state_dict(), 2))
+    return model
+
+
+def run_traj(tag, steps=None):
+    from neurips18_hierchical_image_manipulation_amd import synth
+    g = load_golden(tag)
+    flags = json.loads(str(g['flags']))
+    B, H, W, color = int(g['B']), int(g['H']), int(g['W']), bool(int(g['color']))
+    ref = g['losses'].astype(np.float64)
+    steps = steps or ref.shape[0]
+    model = build(flags)
+    got = []
+    for s in range(steps):
+        b = synth.make_batch(s, 0, B, H, W, flags.get('label_nc', 35), color)
+        ld = model.optimize_parameters(b)
+        got.append([float(ld[k]) for k in NAMES])
+    got = np.array(got, np.float64)
+    rel = np.abs(got - ref[:steps]) / np.maximum(np.abs(ref[:steps]), 1e-12)
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, 'traj_%s.json' % tag), 'w') as f:
+        json.dump(dict(tag=tag, rel=rel.tolist(), got=got.tolist(), ref=ref[:steps].tolist()), f)
+    return rel, model, g, flags
+
+
+def test_tiny_global_forward_tensors_match_reference():
+    from neurips18_hierchical_image_manipulation_amd import synth
+    g = load_golden('tiny_global')
+    flags = json.loads(str(g['flags']))
+    model = build(flags)
+    b = synth.make_batch(0, 0, int(g['B']), int(g['H']), int(g['W']))
+    with torch.no_grad():
+        fake = model.inference(b['label'], b['inst'], b['image'], b['mask_in'], b['mask_out'])
+        assert_close('cond image', model._visuals[3], torch.from_numpy(g['cond0']), rtol=1e-6)
+        assert_close('generator output', fake, torch.from_numpy(g['fake0']), rtol=1e-4)
+        pred = model.netD(torch.from_numpy(g['d_in']).cuda())
+        for i, sc in enumerate(pred):
+            assert_close('D scale %d first feature' % i, sc[0], torch.from_numpy(g['d_feat%d_0' % i]), rtol=1e-4)
+            assert_close('D scale %d logits' % i, sc[-1], torch.from_numpy(g['d_logits%d' % i]), rtol=2e-4)
+
+
+@pytest.mark.parametrize('tag', ['tiny_global', 'tiny_gate3', 'tiny_inst', 'tiny_twostream', 'tiny_color'])
+def test_tiny_trajectories_match_reference(tag):
+    rel, _, _, _ = run_traj(tag)
+    assert rel[0].max() < 1e-4, 'step-0 losses: %s' % rel[0]
+    # the 32x64 toy nets normalise 2x3-pixel maps, which amplifies rounding; the 1e-3 bar is for the real sizes
+    assert rel[:5].max() < 5e-3, 'first steps: %s' % rel[:5].max(axis=1)
+    assert np.isfinite(rel).all()
+
+
+def test_tiny_twostream_forward_matches_reference():
+    from neurips18_hierchical_image_manipulation_amd import synth
+    g = load_golden('tiny_twostream')
+    flags = json.loads(str(g['flags']))
+    model = build(flags)
+    b = synth.make_batch(0, 0, int(g['B']), int(g['H']), int(g['W']))
+    fake = model.inference(b['label'], b['inst'], b['image'], b['mask_in'], b['mask_out'])
+    assert_close('two-stream generator output', fake, torch.from_numpy(g['fake0']), rtol=1e-4)
+
+
+def test_c1_full_size_20_step_losses_match_reference():
+    """BASELINE config 1: 256x128, bs 1, GlobalGenerator ngf 64 / 9 blocks, 1-scale D, VGG on (183 M params)."""
+    rel, _, _, _ = run_traj('c1_traj')
+    assert rel[0].max() < 1e-4, rel[0]
+    assert rel.max() < 1e-3, 'per-step max rel err: %s' % rel.max(axis=1)
+
+
+def test_c2_full_size_losses_match_reference():
+    """BASELINE config 2 (the benchmark workload): 512x256, bs 8, 3-scale D."""
+    if not os.path.isfile(os.path.join(os.path.dirname(__file__), 'golden', 'c2_traj.npz')):
+        pytest.skip('c2 golden trajectory not generated')
+    rel, _, _, _ = run_traj('c2_traj')
+    assert rel[0].max() < 1e-4, rel[0]
+    assert rel.max() < 1e-3, 'per-step max rel err: %s' % rel.max(axis=1)
+
+
+def test_local_enhancer_matches_reference():
+    from neurips18_hierchical_image_manipulation_amd.models.Pix2Pix_NET import LocalEnhancer
+    from neurips18_hierchical_image_manipulation_amd import synth
+    g = load_golden('nets_misc')
+    net = LocalEnhancer(9, 3, ngf=4, n_downsample_global=2, n_blocks_global=2, n_local_enhancers=1, n_blocks_local=2)
+    net.load_state_dict(synth.init_state_dict(net.state_dict(), 11))
+    net.cuda()
+    with torch.no_grad():
+        y = net(torch.from_numpy(g['local_x']).cuda())
+    assert_close('LocalEnhancer', y, torch.from_numpy(g['local_y']), rtol=1e-4)
+
+
+def test_spectral_norm_matches_reference_golden():
+    from neurips18_hierchical_image_manipulation_amd import ops
+    g = load_golden('nets_misc')
+    W = torch.from_numpy(g['sn_small_W']).cuda().requires_grad_(True)
+    sig, u = ops.sn_max_singular_value(W, torch.from_numpy(g['sn_small_u0']).cuda())
+    assert_close('sigma', sig, torch.from_numpy(g['sn_small_sigma']), rtol=2e-6)
+    assert_close('u', u, torch.from_numpy(g['sn_small_u']), rtol=1e-5)
+    (gW,) = torch.autograd.grad(sig.sum(), W)
+    assert_close('d sigma / dW', gW, torch.from_numpy(g['sn_small_gW']), rtol=2e-5)
+
+
+def test_edges_match_reference_golden():
+    g = load_golden('nets_misc')
+    model = build(dict(model='pix2pixHD_condImg', netG='global', ngf=4, ndf=4, n_blocks_global=1, num_D=1,
+                       no_vgg_loss=True))
+    e = model.get_edges(torch.from_numpy(g['edge_inst']))
+    assert torch.equal(e.cpu(), torch.from_numpy(g['edge_map']))
+
+
+def test_checkpoint_roundtrip_and_reference_keys(tmp_path):
+    from oracle import ref_cpu
+    flags = dict(model='pix2pixHD_condImg', netG='global', ngf=8, ndf=8, n_blocks_global=2, num_D=2, no_instance=True)
+    m = build(flags, str(tmp_path))
+    o = ref_cpu.Mask2ImageModel(ref_cpu.Opt(**flags))
+    assert list(m.netG.state_dict().keys()) == list(o.netG.state_dict().keys())
+    assert list(m.netD.state_dict().keys()) == list(o.netD.state_dict().keys())
+    m.save('latest')
+    o.netG.load_state_dict(torch.load(os.path.join(str(tmp_path), 't', 'latest_net_G.pth')))   # loads into torch.nn
+    m2 = build(dict(flags), str(tmp_path))
+    m2.load_network(m2.netG, 'G', 'latest')
+    for a, b in zip(m.netG.state_dict().values(), m2.netG.state_dict().values()):
+        assert torch.equal(a, b)
+
+
+def test_backward_G_backward_D_equal_optimize_parameters():
+    from neurips18_hierchical_image_manipulation_amd import synth
+    flags = dict(model='pix2pixHD_condImg', netG='global', ngf=8, ndf=8, n_blocks_global=2, num_D=2, no_instance=True)
+    a, b = build(flags), build(flags)
+    batch = synth.make_batch(0, 0, 2, 32, 64)
+    la = a.optimize_parameters(batch)
+    losses, _ = b(batch['label'], batch['inst'], batch['image'], None, batch['mask_in'], batch['mask_out'])
+    lb = b.combine_losses(losses)
+    b.backward_G()
+    b.backward_D()
+    for k in NAMES:
+        assert float(la[k]) == float(lb[k])
+    for p, q in zip(a.netG.parameters(), b.netG.parameters()):
+        assert torch.equal(p, q)
+    for p, q in zip(a.netD.parameters(), b.netD.parameters()):
+        assert torch.equal(p, q)
+
+
+def test_cpu_tensor_into_hip_op_fails_loudly():
+    from neurips18_hierchical_image_manipulation_amd import ops
+    from neurips18_hierchical_image_manipulation_amd._cabi import HimError
+    with pytest.raises(HimError):
+        ops.conv2d(torch.zeros(1, 3, 8, 8), torch.zeros(4, 3, 3, 3))

@@ -1,0 +1,289 @@
+"""-m gpu: every HIP op (through the C ABI) against the fp32 CPU oracle building blocks (torch.nn.functional
+on the CPU -- the exact ops the reference executes), forward and backward, on the layer shapes of the path:
+odd PatchGAN sizes, Cin 38/41, Cout 3/1, reflect pads, stride-2 phases, split-K wgrad."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+
+
+def _ops():
+    from neurips18_hierchical_image_manipulation_amd import ops
+    return ops
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _ref_conv(x, w, b, stride, pad, pad_mode, act):
+    if pad_mode == 'reflect':
+        x = F.pad(x, (pad, pad, pad, pad), mode='reflect')
+        pad = 0
+    y = F.conv2d(x, w, b, stride, pad)
+    if act == 'relu':
+        y = F.relu(y)
+    elif act == 'lrelu':
+        y = F.leaky_relu(y, 0.2)
+    elif act == 'tanh':
+        y = torch.tanh(y)
+    return y
+
+
+CONV_CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad, pad_mode, act
+    (2, 38, 20, 36, 64, 7, 1, 3, 'reflect', 'none'),     # G stem
+    (2, 16, 16, 32, 16, 3, 1, 1, 'reflect', 'none'),     # ResnetBlock conv
+    (1, 160, 9, 13, 136, 3, 1, 1, 'reflect', 'none'),    # M,N,K tails in every tile dim
+    (2, 64, 16, 32, 128, 3, 2, 1, 'zero', 'none'),       # downsample
+    (2, 41, 32, 64, 64, 4, 2, 2, 'zero', 'lrelu'),       # D first block (odd output 17x33)
+    (2, 64, 17, 33, 128, 4, 2, 2, 'zero', 'none'),       # D block on odd input
+    (2, 96, 9, 17, 160, 4, 1, 2, 'zero', 'none'),        # D stride-1 block
+    (2, 160, 10, 18, 1, 4, 1, 2, 'zero', 'none'),        # D head -> 1 channel
+    (2, 64, 20, 36, 3, 7, 1, 3, 'reflect', 'tanh'),      # G head -> 3 channels + tanh
+    (2, 3, 16, 32, 64, 3, 1, 1, 'zero', 'relu'),         # VGG conv1_1 + bias + ReLU
+    (1, 256, 8, 16, 256, 3, 1, 1, 'zero', 'relu'),       # VGG mid
+    (3, 8, 5, 7, 8, 3, 1, 1, 'reflect', 'none'),         # tiny everything
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_conv2d_fwd_bwd(case):
+    ops = _ops()
+    B, Cin, H, W, Cout, k, s, p, pm, act = case
+    x = _rand(B, Cin, H, W, seed=1).requires_grad_(True)
+    w = _rand(Cout, Cin, k, k, seed=2, scale=(Cin * k * k) ** -0.5).requires_grad_(True)
+    b = _rand(Cout, seed=3, scale=0.1).requires_grad_(True)
+    y_ref = _ref_conv(x, w, b, s, p, pm, act)
+    gy = _rand(*y_ref.shape, seed=4)
+    gx_ref, gw_ref, gb_ref = torch.autograd.grad(y_ref, (x, w, b), gy)
+
+    xd, wd, bd = (t.detach().to(DEV).requires_grad_(True) for t in (x, w, b))
+    y = ops.conv2d(xd, wd, bd, s, p, pm, act, 0.2)
+    assert_close('conv fwd', y, y_ref)
+    gx, gw, gb = torch.autograd.grad(y, (xd, wd, bd), gy.to(DEV))
+    assert_close('conv dgrad', gx, gx_ref)
+    assert_close('conv wgrad', gw, gw_ref)
+    assert_close('conv bgrad', gb, gb_ref)
+
+
+def test_conv2d_wgrad_splitk_large_spatial():
+    """K = B*OH*OW = 131072 -> many split-K slabs, fixed-order reduction; also accumulate mode."""
+    ops = _ops()
+    B, Cin, H, W, Cout = 2, 8, 256, 256, 16
+    x = _rand(B, Cin, H, W, seed=1)
+    w = _rand(Cout, Cin, 3, 3, seed=2, scale=0.1).requires_grad_(True)
+    y_ref = F.conv2d(x, w, None, 1, 1)
+    gy = _rand(*y_ref.shape, seed=4, scale=0.1)
+    (gw_ref,) = torch.autograd.grad(y_ref, (w,), gy)
+    wd = w.detach().to(DEV).requires_grad_(True)
+    y = ops.conv2d(x.to(DEV), wd, None, 1, 1, 'zero', 'none')
+    (gw,) = torch.autograd.grad(y, (wd,), gy.to(DEV))
+    assert_close('wgrad split-K', gw, gw_ref, rtol=1e-4)
+    (gw2,) = torch.autograd.grad(ops.conv2d(x.to(DEV), wd, None, 1, 1, 'zero', 'none'), (wd,), gy.to(DEV))
+    assert torch.equal(gw, gw2), 'wgrad must be run-to-run deterministic'
+
+
+DECONV_CASES = [(2, 64, 8, 16, 32), (2, 128, 5, 9, 64), (1, 16, 16, 32, 8), (2, 136, 4, 6, 72)]
+
+
+@pytest.mark.parametrize('case', DECONV_CASES, ids=lambda c: 'x'.join(map(str, c)))
+@pytest.mark.parametrize('act', ['none', 'relu'])
+def test_conv_transpose2d_fwd_bwd(case, act):
+    ops = _ops()
+    B, Cin, H, W, Cout = case
+    x = _rand(B, Cin, H, W, seed=1).requires_grad_(True)
+    w = _rand(Cin, Cout, 3, 3, seed=2, scale=(Cin * 9) ** -0.5).requires_grad_(True)
+    b = _rand(Cout, seed=3, scale=0.1).requires_grad_(True)
+    y_ref = F.conv_transpose2d(x, w, b, stride=2, padding=1, output_padding=1)
+    if act == 'relu':
+        y_ref = F.relu(y_ref)
+    gy = _rand(*y_ref.shape, seed=4)
+    gx_ref, gw_ref, gb_ref = torch.autograd.grad(y_ref, (x, w, b), gy)
+    xd, wd, bd = (t.detach().to(DEV).requires_grad_(True) for t in (x, w, b))
+    y = ops.conv_transpose2d(xd, wd, bd, 2, 1, 1, act)
+    assert_close('deconv fwd', y, y_ref)
+    gx, gw, gb = torch.autograd.grad(y, (xd, wd, bd), gy.to(DEV))
+    assert_close('deconv dgrad', gx, gx_ref)
+    assert_close('deconv wgrad', gw, gw_ref)
+    assert_close('deconv bgrad', gb, gb_ref)
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 16, 32), (2, 8, 2, 3), (1, 4, 33, 65), (2, 3, 64, 128), (1, 2, 300, 301)],
+                         ids=str)
+@pytest.mark.parametrize('act', ['none', 'relu', 'lrelu'])
+@pytest.mark.parametrize('with_res', [False, True])
+def test_instance_norm(shape, act, with_res):
+    if with_res and act != 'none':
+        pytest.skip('residual only follows an un-activated norm')
+    ops = _ops()
+    x = (_rand(*shape, seed=1) * 2 + 0.5).requires_grad_(True)
+    r = _rand(*shape, seed=2).requires_grad_(True) if with_res else None
+    y_ref = F.instance_norm(x, eps=1e-5)
+    if act == 'relu':
+        y_ref = F.relu(y_ref)
+    elif act == 'lrelu':
+        y_ref = F.leaky_relu(y_ref, 0.2)
+    if with_res:
+        y_ref = r + y_ref
+    gy = _rand(*shape, seed=3)
+    ins = (x, r) if with_res else (x,)
+    g_ref = torch.autograd.grad(y_ref, ins, gy)
+    xd = x.detach().to(DEV).requires_grad_(True)
+    rd = r.detach().to(DEV).requires_grad_(True) if with_res else None
+    y = ops.instance_norm(xd, rd, act, 0.2)
+    assert_close('IN fwd', y, y_ref, rtol=2e-5)
+    g = torch.autograd.grad(y, (xd, rd) if with_res else (xd,), gy.to(DEV))
+    assert_close('IN bwd x', g[0], g_ref[0], rtol=1e-4)
+    if with_res:
+        assert_close('IN bwd res', g[1], g_ref[1])
+
+
+@pytest.mark.parametrize('hw', [(16, 32), (17, 33), (9, 17), (256, 512), (5, 4)], ids=str)
+def test_avgpool3s2(hw):
+    ops = _ops()
+    x = _rand(2, 5, *hw, seed=1).requires_grad_(True)
+    y_ref = F.avg_pool2d(x, 3, 2, 1, count_include_pad=False)
+    gy = _rand(*y_ref.shape, seed=2)
+    (gx_ref,) = torch.autograd.grad(y_ref, x, gy)
+    xd = x.detach().to(DEV).requires_grad_(True)
+    y = ops.avgpool3s2(xd)
+    assert_close('avgpool fwd', y, y_ref, rtol=1e-6)
+    (gx,) = torch.autograd.grad(y, xd, gy.to(DEV))
+    assert_close('avgpool bwd', gx, gx_ref, rtol=1e-6)
+
+
+@pytest.mark.parametrize('k,hw', [(2, (16, 32)), (2, (8, 8)), (16, (64, 64)), (8, (32, 64))], ids=str)
+def test_maxpool(k, hw):
+    ops = _ops()
+    x = F.relu(_rand(2, 4, *hw, seed=1)).requires_grad_(True)    # ReLU'd input -> ties at 0
+    y_ref = F.max_pool2d(x, k, k)
+    gy = _rand(*y_ref.shape, seed=2)
+    (gx_ref,) = torch.autograd.grad(y_ref, x, gy)
+    xd = x.detach().to(DEV).requires_grad_(True)
+    y = ops.maxpool(xd, k)
+    assert torch.equal(y.cpu(), y_ref)
+    (gx,) = torch.autograd.grad(y, xd, gy.to(DEV))
+    assert torch.equal(gx.cpu(), gx_ref), 'max-pool gradient routing (first max in window order)'
+
+
+@pytest.mark.parametrize('n', [7, 4096, 8 * 64 * 129 * 257 // 16, 1 << 20], ids=str)
+def test_losses(n):
+    ops = _ops()
+    a = _rand(n, seed=1).requires_grad_(True)
+    b = _rand(n, seed=2)
+    b[: n // 3] = a.detach()[: n // 3]                        # exact zeros of a-b -> sign(0) = 0
+    l_ref = F.l1_loss(a, b)
+    (ga_ref,) = torch.autograd.grad(l_ref * 3.0, a)
+    ad = a.detach().to(DEV).requires_grad_(True)
+    l = ops.l1_mean(ad, b.to(DEV))
+    assert_close('l1', l, l_ref, rtol=2e-6)
+    (ga,) = torch.autograd.grad(l * 3.0, ad)
+    assert_close('l1 grad', ga, ga_ref, rtol=1e-6)
+    for t in (0.0, 1.0):
+        m_ref = F.mse_loss(a, torch.full_like(a, t))
+        (gm_ref,) = torch.autograd.grad(m_ref, a)
+        m = ops.mse_const(ad, t)
+        assert_close('mse', m, m_ref, rtol=2e-6)
+        (gm,) = torch.autograd.grad(m, ad)
+        assert_close('mse grad', gm, gm_ref, rtol=1e-6)
+
+
+def test_adam_matches_torch_over_steps():
+    from neurips18_hierchical_image_manipulation_amd.optim import FusedAdam
+    ps = [torch.nn.Parameter(_rand(33, 7, seed=1)), torch.nn.Parameter(_rand(130, seed=2))]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    o_ref = torch.optim.Adam(ref, lr=2e-4, betas=(0.5, 0.999))
+    dps = [torch.nn.Parameter(p.detach().clone().to(DEV)) for p in ps]
+    o = FusedAdam(dps, lr=2e-4, betas=(0.5, 0.999))
+    for step in range(25):
+        o.zero_grad()
+        o_ref.zero_grad()
+        for i, (p, q) in enumerate(zip(ref, dps)):
+            g = _rand(*p.shape, seed=100 + 7 * step + i) * (10.0 ** (i - 2))
+            p.grad = g.clone()
+            q.grad.copy_(g)
+        o_ref.step()
+        o.step()
+    for p, q in zip(ref, dps):
+        assert_close('adam param', q, p, rtol=1e-6)
+
+
+def test_cat_blend_encode():
+    ops = _ops()
+    B, H, W = 2, 16, 32
+    a = _rand(B, 5, H, W, seed=1).requires_grad_(True)
+    b = _rand(B, 3, H, W, seed=2).requires_grad_(True)
+    m = (torch.rand(B, 1, H, W, generator=torch.Generator().manual_seed(3)) > 0.5).float()
+    ref = torch.cat((a, b), 1) * m
+    gy = _rand(*ref.shape, seed=4)
+    ga_ref, gb_ref = torch.autograd.grad(ref, (a, b), gy)
+    ad, bd = a.detach().to(DEV).requires_grad_(True), b.detach().to(DEV).requires_grad_(True)
+    out = ops.cat_channels([ad, bd], m.to(DEV), 1)
+    assert torch.equal(out.cpu(), ref.detach())
+    ga, gb = torch.autograd.grad(out, (ad, bd), gy.to(DEV))
+    assert torch.equal(ga.cpu(), ga_ref) and torch.equal(gb.cpu(), gb_ref)
+    # blend with a channel-sliced first operand (output gate) and full (two-stream fusion)
+    img = _rand(B, 9, H, W, seed=5).requires_grad_(True)
+    gen = _rand(B, 3, H, W, seed=6).requires_grad_(True)
+    ref = (1 - m) * img[:, 6:] + m * gen
+    gi_ref, gg_ref = torch.autograd.grad(ref, (img, gen), gy[:, :3])
+    imd, gd = img.detach().to(DEV).requires_grad_(True), gen.detach().to(DEV).requires_grad_(True)
+    out = ops.blend(imd, gd, m.to(DEV), a0=6)
+    assert torch.equal(out.cpu(), ref.detach())
+    gi, gg = torch.autograd.grad(out, (imd, gd), gy[:, :3].to(DEV))
+    assert torch.equal(gi.cpu(), gi_ref) and torch.equal(gg.cpu(), gg_ref)
+    # encode: one-hot | edges | (1-mask)*image
+    label = torch.randint(0, 35, (B, 1, H, W), generator=torch.Generator().manual_seed(7)).float()
+    inst = torch.randint(0, 3, (B, 1, H, W), generator=torch.Generator().manual_seed(8)).float()
+    image = _rand(B, 3, H, W, seed=9)
+    buf, nl, nc = ops.encode_channels(label.to(DEV), inst.to(DEV), image.to(DEV), m.to(DEV), 35, True)
+    onehot = torch.zeros(B, 35, H, W).scatter_(1, label.long(), 1.0)
+    from oracle.ref_cpu import get_edges
+    ref = torch.cat((onehot, get_edges(inst), (1 - m) * image), 1)
+    assert (nl, nc) == (36, 3)
+    assert torch.equal(buf.cpu(), ref)
+    s = ops.add(ad, ad)
+    assert torch.equal(s.cpu(), (a + a).detach())
+
+
+def test_masked_mean_color():
+    ops = _ops()
+    from oracle.ref_cpu import color_embedding
+    B, H, W = 3, 16, 16
+    image = _rand(B, 3, H, W, seed=1)
+    m = torch.zeros(B, 1, H, W)
+    m[0, :, 4:12, 4:12] = 1
+    m[1, :, :, :] = 1                                          # image 2 keeps an empty mask -> zeros
+    noise = torch.rand(B, 3, generator=torch.Generator().manual_seed(2)) * 0.06 + 0.97
+    for nz in (None, noise):
+        ref = color_embedding(m, image, nz)
+        got = ops.masked_mean_color(image.to(DEV), m.to(DEV), None if nz is None else nz.to(DEV))
+        assert_close('colour embedding', got, ref, rtol=2e-6)
+
+
+@pytest.mark.parametrize('shape', [(16, 8, 3, 3), (512, 256, 4, 4), (64, 41, 4, 4)], ids=str)
+def test_spectral_norm_sigma_and_full_gradient(shape):
+    ops = _ops()
+    from oracle.ref_cpu import max_singular_value
+    g = torch.Generator().manual_seed(13)
+    W = (torch.randn(*shape, generator=g) * 0.05).requires_grad_(True)
+    u = torch.randn(1, shape[0], generator=g)
+    sig_ref, u_ref = max_singular_value(W, u, 1)
+    Wbar_ref = W / sig_ref
+    gy = _rand(*shape, seed=5)
+    (gW_ref,) = torch.autograd.grad(Wbar_ref, W, gy)
+    Wd = W.detach().to(DEV).requires_grad_(True)
+    sig, u_new = ops.sn_max_singular_value(Wd, u.to(DEV))
+    assert_close('sigma', sig, sig_ref, rtol=2e-6)
+    assert_close('u', u_new, u_ref, rtol=1e-5)
+    Wbar = ops.div_scalar(Wd, sig)
+    assert_close('W/sigma', Wbar, Wbar_ref, rtol=1e-5)
+    (gW,) = torch.autograd.grad(Wbar, Wd, gy.to(DEV))
+    assert_close('d(W/sigma)/dW through both normalisations', gW, gW_ref, rtol=2e-5)
