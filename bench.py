@@ -1,0 +1,172 @@
+#!/usr/bin/env python
+"""Benchmark of the mask2image training hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One "step" = one full training step (G forward, 3x multi-scale D forward, LSGAN + feature-matching + VGG losses,
+G backward + Adam, D backward + Adam) on one synthetic Cityscapes-shaped batch that is already resident in HBM.
+Workload = BASELINE.json configs[1]: 512x256 (NCHW (8,.,256,512)), bs 8 per GPU, GlobalGenerator ngf 64 /
+4 downsamples / 9 ResnetBlocks (182.6 M params), 3-scale PatchGAN, VGG19 perceptual loss, fp32 throughout.
+Rank 0 prints ONE JSON line (metric = BASELINE.json's images/s; weak scaling: bs 8 per GPU).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+C2 = dict(model='pix2pixHD_condImg', netG='global', ngf=64, ndf=64, n_downsample_global=4, n_blocks_global=9,
+          num_D=3, n_layers_D=3, label_nc=35, no_instance=True)
+H, W, BS = 256, 512, 8
+PEAK_F32_MFMA = 157.3  # TFLOP/s, v_mfma_f32_32x32x2_f32 (MI355X_MICROARCH.md)
+G_FWD_GFLOP_PER_IMG = 246.3  # conv + transposed-conv FLOPs of GlobalGenerator at 256x512
+
+
+def _event_ms(fn, iters):
+    """HIP-event timing on the stream the kernels are launched on (torch's current stream)."""
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(iters):
+        fn()
+    end.record()
+    end.synchronize()
+    return start.elapsed_time(end) / iters
+
+
+def dominant_kernel_roofline(device):
+    """ResnetBlock conv: refpad(1) + conv3x3 1024->1024 on (8,1024,16,32): GEMM M=1024, N=4096, K=9216 =
+    77.31 GFLOP per launch; 18 of them = 70.6 % of the generator's forward FLOPs.  MFMA-bound (AI >> ridge)."""
+    from neurips18_hierchical_image_manipulation_amd import ops
+    x = torch.randn(BS, 1024, 16, 32, device=device)
+    w = torch.randn(1024, 1024, 3, 3, device=device) * 0.02
+    b = torch.zeros(1024, device=device)
+    with torch.no_grad():
+        fn = lambda: ops.conv2d(x, w, b, 1, 1, 'reflect', 'none')  # noqa: E731
+        for _ in range(3):
+            fn()
+        ms = _event_ms(fn, 20)
+    flops = 2.0 * 1024 * (BS * 16 * 32) * (1024 * 9)
+    ach = flops / (ms * 1e-3) / 1e12
+    return dict(bound='mfma', kernel='gconv_kernel<2,2,2,1> (ResnetBlock conv3x3 1024->1024 @16x32, bs 8)',
+                achieved=round(ach, 2), peak=PEAK_F32_MFMA, unit='TFLOP/s', frac=round(ach / PEAK_F32_MFMA, 4),
+                traffic=None, flop_per_launch=flops, avg_launch_ms=round(ms, 4))
+
+
+def g_forward_roofline(model, batch):
+    """The 'fused G-conv forward' the north star prices: whole GlobalGenerator forward at C2 = 1.970 TFLOP."""
+    with torch.no_grad():
+        model.encode_input(batch['label'], batch['inst'], batch['image'], None, mask_in=batch['mask_in'])
+        buf, _, _, mask = model._enc
+        fn = lambda: model.netG(buf, mask)  # noqa: E731
+        for _ in range(2):
+            fn()
+        ms = _event_ms(fn, 5)
+    tf = G_FWD_GFLOP_PER_IMG * BS / 1e3 / (ms * 1e-3)
+    return dict(ms=round(ms, 3), tflops=round(tf, 2), frac_of_f32_mfma_peak=round(tf / PEAK_F32_MFMA, 4))
+
+
+def cpu_baseline():
+    """The CPU oracle (validated bit-exact against the imported reference) timed on this box's host cores on a
+    bounded sample of the same workload: ONE full training step at 512x256 with batch 2 (not 8)."""
+    from oracle import ref_cpu
+    from neurips18_hierchical_image_manipulation_amd import synth
+    cores = torch.get_num_threads()
+    bs = 2
+    om = ref_cpu.Mask2ImageModel(ref_cpu.Opt(**C2))
+    b = synth.make_batch(0, 0, bs, H, W)
+    t0 = time.time()
+    om.optimize_parameters(b)
+    dt = time.time() - t0
+    return dict(value=round(bs / dt, 4), unit='images/s', cores=cores, kind='port',
+                sample='1 full training step (no warm-up), 512x256, batch %d of the bs-8 workload, torch CPU fp32, '
+                       '%d threads: %.1f s' % (bs, cores, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    from neurips18_hierchical_image_manipulation_amd import synth
+    from neurips18_hierchical_image_manipulation_amd.dist import init_process_group_from_env, attach_data_parallel
+    from neurips18_hierchical_image_manipulation_amd.models import create_model
+
+    rank, local, world = init_process_group_from_env()
+    if world != max(args.gpus, 1) and world > 1:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+
+    model = create_model(dict(C2, gpu_ids=[local], isTrain=True, checkpoints_dir='/tmp/him_bench', name='bench',
+                              batchSize=BS))
+    model.netG.load_state_dict(synth.init_state_dict(model.netG.state_dict(), 1))
+    model.netD.load_state_dict(synth.init_state_dict(model.netD.state_dict(), 2))
+    attach_data_parallel(model)
+
+    # synthetic batches, resident in HBM before the timed region (4 distinct batches per rank, cycled)
+    batches = []
+    for s in range(4):
+        b = synth.make_batch(s, rank, BS, H, W)
+        batches.append({k: v.to(device) for k, v in b.items()})
+
+    def step(i):
+        return model.optimize_parameters(batches[i % len(batches)])
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        losses = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        out = {
+            'metric': 'mask2image train images/sec at 512x256 bs=8',
+            'value': round(BS * world * args.steps / dt, 3), 'unit': 'images/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'C2: mask2image Cityscapes-shaped 512x256, GlobalGenerator ngf64/4down/9blocks '
+                                   '(182.6M params) + 3-scale PatchGAN + VGG19 loss (synthetic weights), full '
+                                   'train step G+D Adam, fp32', 'global_batch': BS * world, 'per_gpu_batch': BS,
+                       'parallelism': 'dp%d' % world},
+            'last_losses': {k: round(float(v), 5) for k, v in losses.items()},
+        }
+        if not args.no_roofline:
+            out['roofline'] = dominant_kernel_roofline(device)
+            out['g_forward'] = g_forward_roofline(model, batches[0])
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
