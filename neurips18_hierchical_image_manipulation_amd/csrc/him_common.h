@@ -40,7 +40,8 @@ inline FastDiv make_fastdiv(uint32_t d) {
   f.m = d <= 1 ? 0u : (uint32_t)((1ull << 32) / d + 1ull);
   return f;
 }
-__device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv f) { return f.m == 0 ? n : __umulhi(n, f.m); }
+// branch-free: m == 0 encodes d == 1
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv f) { return __umulhi(n, f.m) + n * (uint32_t)(f.m == 0); }
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   switch (act) {

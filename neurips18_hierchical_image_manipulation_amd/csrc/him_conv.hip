@@ -49,7 +49,7 @@ struct GConvP {
   GPhase ph[4];
 };
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool REFLECT>
 __global__ __launch_bounds__(256) void gconv_kernel(const GConvP p) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 16;
   constexpr int LDA = BK + 1;
@@ -70,68 +70,68 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvP p) {
   const int wm = wave / WN, wn = wave % WN;
   const int K = ph.K;
   const float* __restrict__ A = ph.A;
+  const float* __restrict__ src = p.src;
 
-  // ---- gather coordinates of this thread's column ----
+  // ---- gather coordinates of this thread's column.  Out-of-range columns/rows are CLAMPED, not predicated:
+  // they compute garbage that the epilogue never stores, and the loop body stays branch-free. ----
   const int nl = t % BN;
   const int kg = __builtin_amdgcn_readfirstlane(t / BN);
-  const int n = n0 + nl;
-  const bool nvalid = n < Ntot;
-  int b = 0, a = 0, c = 0;
-  if (nvalid) {
-    b = n / plane;
-    const int r = n - b * plane;
-    a = r / ph.NC;
-    c = r - a * ph.NC;
-  }
+  const int n = min(n0 + nl, Ntot - 1);
+  const int b = n / plane;
+  const int rr = n - b * plane;
+  const int a = rr / ph.NC;
+  const int c = rr - a * ph.NC;
   const int by = a * p.sy + ph.offy, bx = c * p.sx + ph.offx;
   const int SH = p.SH, SW = p.SW;
-  const float* __restrict__ srcb = p.src + (size_t)b * p.C2 * SH * SW;
-  const int JHJW = ph.JH * ph.JW, JW = ph.JW;
+  const uint32_t SHSW = (uint32_t)SH * SW;
+  const uint32_t boff = (uint32_t)b * p.C2 * SHSW;
+  const uint32_t JHJW = ph.JH * ph.JW, JW = ph.JW;
   const FastDiv fJHJW = ph.fJHJW, fJW = ph.fJW;
   const int ddy = p.dy, ddx = p.dx;
-  const bool reflect = p.pad_mode == HIM_PAD_REFLECT;
+
+  const int kkA = t % BK;
+  uint32_t rowoff[A_PER_T];
+#pragma unroll
+  for (int i = 0; i < A_PER_T; ++i) rowoff[i] = (uint32_t)min(m0 + t / BK + i * (256 / BK), p.M - 1) * (uint32_t)K;
 
   float ra[A_PER_T], rb[KPT];
 
   auto loadA = [&](int k0) {
+    const uint32_t kc = (uint32_t)min(k0 + kkA, K - 1);
 #pragma unroll
-    for (int i = 0; i < A_PER_T; ++i) {
-      const int e = t + i * 256;
-      const int row = e / BK, kk = e % BK;
-      const int m = m0 + row, k = k0 + kk;
-      ra[i] = (m < p.M && k < K) ? A[(size_t)m * K + k] : 0.f;
-    }
+    for (int i = 0; i < A_PER_T; ++i) ra[i] = A[rowoff[i] + kc];
   };
   auto loadB = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
-      const int k = k0 + kg * KPT + i;  // wave-uniform
-      float v = 0.f;
-      if (k < K && nvalid) {
-        const int c2 = (int)fdiv((uint32_t)k, fJHJW);
-        const int r = k - c2 * JHJW;
-        const int jh = (int)fdiv((uint32_t)r, fJW);
-        const int jw = r - jh * JW;
-        int iy = by + jh * ddy, ix = bx + jw * ddx;
-        if (reflect) {
-          iy = iy < 0 ? -iy : iy;
-          iy = iy >= SH ? 2 * (SH - 1) - iy : iy;
-          ix = ix < 0 ? -ix : ix;
-          ix = ix >= SW ? 2 * (SW - 1) - ix : ix;
-          v = srcb[((size_t)c2 * SH + iy) * SW + ix];
-        } else if ((unsigned)iy < (unsigned)SH && (unsigned)ix < (unsigned)SW) {
-          v = srcb[((size_t)c2 * SH + iy) * SW + ix];
-        }
+      const int kk = k0 + kg * KPT + i;  // wave-uniform -> scalar unit
+      const bool kval = kk < K;          // zero B rows beyond K kill the (finite) clamped A columns
+      const uint32_t kc = (uint32_t)min(kk, K - 1);
+      const uint32_t c2 = fdiv(kc, fJHJW);
+      const uint32_t r = kc - c2 * JHJW;
+      const uint32_t jh = fdiv(r, fJW);
+      const uint32_t jw = r - jh * JW;
+      int iy = by + (int)jh * ddy, ix = bx + (int)jw * ddx;
+      bool ok = kval;
+      if (REFLECT) {
+        iy = iy < 0 ? -iy : iy;
+        iy = iy >= SH ? 2 * (SH - 1) - iy : iy;
+        ix = ix < 0 ? -ix : ix;
+        ix = ix >= SW ? 2 * (SW - 1) - ix : ix;
+      } else {
+        const int cy = min(max(iy, 0), SH - 1), cx = min(max(ix, 0), SW - 1);
+        ok = ok && (cy == iy) && (cx == ix);
+        iy = cy;
+        ix = cx;
       }
-      rb[i] = v;
+      const uint32_t off = boff + c2 * SHSW + (uint32_t)iy * (uint32_t)SW + (uint32_t)ix;
+      const float v = src[off];
+      rb[i] = ok ? v : 0.f;
     }
   };
   auto storeAB = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < A_PER_T; ++i) {
-      const int e = t + i * 256;
-      sA[buf][(e / BK) * LDA + (e % BK)] = ra[i];
-    }
+    for (int i = 0; i < A_PER_T; ++i) sA[buf][(t / BK + i * (256 / BK)) * LDA + kkA] = ra[i];
 #pragma unroll
     for (int i = 0; i < KPT; ++i) sB[buf][(kg * KPT + i) * BN + nl] = rb[i];
   };
@@ -152,10 +152,10 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvP p) {
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) {
-      loadA((kt + 1) * BK);
-      loadB((kt + 1) * BK);
-    }
+    // the last iteration re-loads a clamped tile it never stores: keeps the body free of branches
+    const int knext = min(kt + 1, nk - 1) * BK;
+    loadA(knext);
+    loadB(knext);
     const float* __restrict__ pa = &sA[buf][(wm * TM * 32 + l31) * LDA + lh];
     const float* __restrict__ pb = &sB[buf][lh * BN + wn * TN * 32 + l31];
 #pragma unroll
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvP p) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) storeAB(buf ^ 1);
+    storeAB(buf ^ 1);
     __syncthreads();
   }
 
@@ -203,6 +203,14 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvP p) {
   }
 }
 
+template <int WM, int WN, int TM, int TN>
+static void launch_gconv_cfg(const GConvP& p, dim3 grid, hipStream_t st) {
+  if (p.pad_mode == HIM_PAD_REFLECT)
+    hipLaunchKernelGGL((gconv_kernel<WM, WN, TM, TN, true>), grid, dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((gconv_kernel<WM, WN, TM, TN, false>), grid, dim3(256), 0, st, p);
+}
+
 static int launch_gconv(const GConvP& p, hipStream_t st) {
   long long maxN = 0;
   for (int i = 0; i < p.nphase; ++i) {
@@ -210,21 +218,20 @@ static int launch_gconv(const GConvP& p, hipStream_t st) {
     if (n > maxN) maxN = n;
   }
   if (maxN == 0 || p.M <= 0) return HIM_OK;
-  dim3 block(256);
   if (p.M <= 32) {
     dim3 grid(cdiv(maxN, 256), cdiv(p.M, 32), p.nphase);
-    hipLaunchKernelGGL((gconv_kernel<1, 4, 1, 2>), grid, block, 0, st, p);
+    launch_gconv_cfg<1, 4, 1, 2>(p, grid, st);
   } else if (p.M <= 64) {
     dim3 grid(cdiv(maxN, 128), cdiv(p.M, 64), p.nphase);
-    hipLaunchKernelGGL((gconv_kernel<1, 4, 2, 1>), grid, block, 0, st, p);
+    launch_gconv_cfg<1, 4, 2, 1>(p, grid, st);
   } else {
     const long long tiles128 = (long long)cdiv(maxN, 128) * cdiv(p.M, 128) * p.nphase;
     if (tiles128 >= 768) {
       dim3 grid(cdiv(maxN, 128), cdiv(p.M, 128), p.nphase);
-      hipLaunchKernelGGL((gconv_kernel<2, 2, 2, 2>), grid, block, 0, st, p);
+      launch_gconv_cfg<2, 2, 2, 2>(p, grid, st);
     } else {
       dim3 grid(cdiv(maxN, 64), cdiv(p.M, 128), p.nphase);
-      hipLaunchKernelGGL((gconv_kernel<2, 2, 2, 1>), grid, block, 0, st, p);
+      launch_gconv_cfg<2, 2, 2, 1>(p, grid, st);
     }
   }
   return check_launch("gconv");
@@ -347,7 +354,7 @@ struct WGradP {
   FastDiv fKK, fKW, fOW;
 };
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool REFLECT>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WGradP p) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 32;
   constexpr int LD = BK + 1;
@@ -368,7 +375,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradP p) {
   // per-column (ci,kh,kw) table: loop invariant
   if (t < BN) {
     const int np = n0 + t;
-    int off = -1, d = 0;
+    int off = 0, d = (128 << 16) | 128;
     if (np < p.Np) {
       const int ci = (int)fdiv((uint32_t)np, p.fKK);
       const int r = np - ci * p.KH * p.KW;
@@ -389,40 +396,49 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradP p) {
   int sp = kcur - b * OHW;
 
   float ra[RA], rb[RB];
-  const bool reflect = p.pad_mode == HIM_PAD_REFLECT;
   const int H = p.H, W = p.W, stride = p.stride;
+  const float* __restrict__ dy = p.dy;
+  const float* __restrict__ x = p.x;
+  uint32_t mrow[RA];
+#pragma unroll
+  for (int i = 0; i < RA; ++i) mrow[i] = (uint32_t)min(m0 + rg + 8 * i, p.M - 1) * (uint32_t)OHW;
 
+  // branch-free: out-of-range k positions are redirected to element (0,0) and their dY operand zeroed;
+  // out-of-range rows/columns are clamped and never stored.
   auto loadAB = [&]() {
     const bool kvalid = kcur < kend;
-    const int oh = (int)fdiv((uint32_t)sp, p.fOW);
-    const int ow = sp - oh * p.OW;
-    const float* __restrict__ dyb = p.dy + ((size_t)b * p.M) * OHW + sp;
+    const int bb = kvalid ? b : 0;
+    const int spp = kvalid ? sp : 0;
+    const int oh = (int)fdiv((uint32_t)spp, p.fOW);
+    const int ow = spp - oh * p.OW;
+    const uint32_t dyb = (uint32_t)bb * (uint32_t)p.M * (uint32_t)OHW + (uint32_t)spp;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-      const int m = m0 + rg + 8 * i;
-      ra[i] = (kvalid && m < p.M) ? dyb[(size_t)m * OHW] : 0.f;
+      const float v = dy[dyb + mrow[i]];
+      ra[i] = kvalid ? v : 0.f;
     }
-    const float* __restrict__ xb = p.x + (size_t)b * p.C * HW;
+    const uint32_t xb = (uint32_t)bb * (uint32_t)p.C * (uint32_t)HW;
     const int ihb = oh * stride, iwb = ow * stride;
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
       const int row = rg + 8 * i;
       const int off = tabOff[row];
       const int d = tabD[row];
-      float v = 0.f;
-      if (kvalid && off >= 0) {
-        int ih = ihb + (d >> 16) - 128, iw = iwb + (d & 0xffff) - 128;
-        if (reflect) {
-          ih = ih < 0 ? -ih : ih;
-          ih = ih >= H ? 2 * (H - 1) - ih : ih;
-          iw = iw < 0 ? -iw : iw;
-          iw = iw >= W ? 2 * (W - 1) - iw : iw;
-          v = xb[off + ih * W + iw];
-        } else if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
-          v = xb[off + ih * W + iw];
-        }
+      int ih = ihb + (d >> 16) - 128, iw = iwb + (d & 0xffff) - 128;
+      bool ok = true;
+      if (REFLECT) {
+        ih = ih < 0 ? -ih : ih;
+        ih = ih >= H ? 2 * (H - 1) - ih : ih;
+        iw = iw < 0 ? -iw : iw;
+        iw = iw >= W ? 2 * (W - 1) - iw : iw;
+      } else {
+        const int ch = min(max(ih, 0), H - 1), cw = min(max(iw, 0), W - 1);
+        ok = (ch == ih) && (cw == iw);
+        ih = ch;
+        iw = cw;
       }
-      rb[i] = v;
+      const float v = x[xb + (uint32_t)off + (uint32_t)ih * (uint32_t)W + (uint32_t)iw];
+      rb[i] = ok ? v : 0.f;
     }
   };
   auto advance = [&]() {
@@ -458,7 +474,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradP p) {
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) loadAB();
+    loadAB();  // past the end: kvalid is false, loads hit element (0,0)
     const float* __restrict__ pa = &sA[buf][(wm * TM * 32 + l31) * LD + lh];
     const float* __restrict__ pb = &sB[buf][(wn * TN * 32 + l31) * LD + lh];
 #pragma unroll
@@ -474,10 +490,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradP p) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) {
-      storeAB(buf ^ 1);
-      advance();
-    }
+    storeAB(buf ^ 1);
+    advance();
     __syncthreads();
   }
 
@@ -586,12 +600,17 @@ static int run_wgrad(const float* dy, const float* x, float* dw, int M, int C, i
     p.out = dw;
   }
   dim3 grid(cdiv(p.Np, BN), cdiv(M, BM), splits), block(256);
-  if (BM == 128)
-    hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2>), grid, block, 0, st, p);
-  else if (BM == 64)
-    hipLaunchKernelGGL((wgrad_kernel<1, 4, 2, 1>), grid, block, 0, st, p);
-  else
-    hipLaunchKernelGGL((wgrad_kernel<1, 4, 1, 1>), grid, block, 0, st, p);
+  const bool refl = pad_mode == HIM_PAD_REFLECT;
+  if (BM == 128) {
+    if (refl) hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2, false>), grid, block, 0, st, p);
+  } else if (BM == 64) {
+    if (refl) hipLaunchKernelGGL((wgrad_kernel<1, 4, 2, 1, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((wgrad_kernel<1, 4, 2, 1, false>), grid, block, 0, st, p);
+  } else {
+    if (refl) hipLaunchKernelGGL((wgrad_kernel<1, 4, 1, 1, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((wgrad_kernel<1, 4, 1, 1, false>), grid, block, 0, st, p);
+  }
   int rc = check_launch("wgrad");
   if (rc) return rc;
   if (splits > 1) {
@@ -621,6 +640,8 @@ static int check_conv(const HimConv2d* d) {
     return fail(HIM_E_INVALID, "conv2d: reflect pad %d >= input size", d->pad);
   if (d->pad_mode == HIM_PAD_REFLECT && d->stride != 1)
     return fail(HIM_E_UNSUPPORTED, "conv2d: reflect pad needs stride 1");
+  if ((long long)d->B * d->Cin * d->H * d->W >= (1ll << 31) || (long long)d->B * d->Cout * d->OH * d->OW >= (1ll << 31))
+    return fail(HIM_E_UNSUPPORTED, "conv2d: tensor larger than 2^31 elements (32-bit offsets)");
   if ((long long)d->Cin * d->KH * d->KW >= (1 << 20) || (long long)d->Cout * d->KH * d->KW >= (1 << 20))
     return fail(HIM_E_UNSUPPORTED, "conv2d: reduction length too large for fastdiv");
   return HIM_OK;
