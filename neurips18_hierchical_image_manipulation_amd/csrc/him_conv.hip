@@ -17,6 +17,7 @@
 // D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31]  -> putting the spatial index on j makes every accumulator
 // register a 128-byte coalesced NCHW row segment.
 #include <algorithm>
+#include <type_traits>
 
 #include "him_common.h"
 
@@ -94,14 +95,15 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvP p) {
 #pragma unroll
   for (int i = 0; i < A_PER_T; ++i) rowoff[i] = (uint32_t)min(m0 + t / BK + i * (256 / BK), p.M - 1) * (uint32_t)K;
 
-  float ra[A_PER_T], rb[KPT];
+  // two register sets: tile kt+2 is in flight while tile kt+1 waits to be written to LDS (2-deep prefetch)
+  float ra2[2][A_PER_T], rb2[2][KPT];
 
-  auto loadA = [&](int k0) {
+  auto loadA = [&](float (&ra)[A_PER_T], int k0) {
     const uint32_t kc = (uint32_t)min(k0 + kkA, K - 1);
 #pragma unroll
     for (int i = 0; i < A_PER_T; ++i) ra[i] = A[rowoff[i] + kc];
   };
-  auto loadB = [&](int k0) {
+  auto loadB = [&](float (&rb)[KPT], int k0) {
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
       const int kk = k0 + kg * KPT + i;  // wave-uniform -> scalar unit
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvP p) {
       rb[i] = ok ? v : 0.f;
     }
   };
-  auto storeAB = [&](int buf) {
+  auto storeAB = [&](const float (&ra)[A_PER_T], const float (&rb)[KPT], int buf) {
 #pragma unroll
     for (int i = 0; i < A_PER_T; ++i) sA[buf][(t / BK + i * (256 / BK)) * LDA + kkA] = ra[i];
 #pragma unroll
@@ -146,18 +148,22 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvP p) {
 
   const int l31 = lane & 31, lh = lane >> 5;
   const int nk = (K + BK - 1) / BK;
-  loadA(0);
-  loadB(0);
-  storeAB(0);
+  loadA(ra2[0], 0);
+  loadB(rb2[0], 0);
+  storeAB(ra2[0], rb2[0], 0);
+  loadA(ra2[1], min(1, nk - 1) * BK);
+  loadB(rb2[1], min(1, nk - 1) * BK);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    // the last iteration re-loads a clamped tile it never stores: keeps the body free of branches
-    const int knext = min(kt + 1, nk - 1) * BK;
-    loadA(knext);
-    loadB(knext);
-    const float* __restrict__ pa = &sA[buf][(wm * TM * 32 + l31) * LDA + lh];
-    const float* __restrict__ pb = &sB[buf][lh * BN + wn * TN * 32 + l31];
+  // iteration kt (parity P = kt & 1): issue tile kt+2 into set P (freed last iteration), run the MFMAs on LDS
+  // buffer P, then write set P^1 (tile kt+1, issued a whole iteration ago) into LDS buffer P^1.  Tile indices
+  // past the end are clamped: those loads/stores are redundant but keep the body branch-free.
+  auto step = [&](auto PAR, int kt) {
+    constexpr int P = decltype(PAR)::value;
+    const int k2 = min(kt + 2, nk - 1) * BK;
+    loadA(ra2[P], k2);
+    loadB(rb2[P], k2);
+    const float* __restrict__ pa = &sA[P][(wm * TM * 32 + l31) * LDA + lh];
+    const float* __restrict__ pb = &sB[P][lh * BN + wn * TN * 32 + l31];
 #pragma unroll
     for (int kp = 0; kp < BK / 2; ++kp) {
       float af[TM], bf[TN];
@@ -171,9 +177,15 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvP p) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
-    storeAB(buf ^ 1);
+    storeAB(ra2[P ^ 1], rb2[P ^ 1], P ^ 1);
     __syncthreads();
+  };
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    step(std::integral_constant<int, 0>{}, kt);
+    step(std::integral_constant<int, 1>{}, kt + 1);
   }
+  if (kt < nk) step(std::integral_constant<int, 0>{}, kt);
 
   // ---- epilogue: bias + activation, coalesced NCHW stores ----
   const int act = p.act;
@@ -203,6 +215,122 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvP p) {
   }
 }
 
+// ---- tiny-M variant (Cout <= 4 forward heads: G tanh head, PatchGAN logit heads; Cin <= 4 data gradients) ----
+// M rows would waste >= 87 % of a 32-wide MFMA tile, so this path is a direct VALU convolution: one thread
+// per output position, MM accumulators, wave-uniform weights (scalar loads), coalesced gathers along x.
+// TJ = compile-time tap count per axis (0: run-time JH/JW).
+template <int MM, int TJ, bool REFLECT>
+__global__ __launch_bounds__(256) void gconv_small_kernel(const GConvP p) {
+  const GPhase& ph = p.ph[blockIdx.z];
+  const int plane = ph.NA * ph.NC;
+  const int Ntot = p.B * plane;
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x * 256 >= Ntot) return;
+  const int nc = min(n, Ntot - 1);
+  const int b = nc / plane;
+  const int rr = nc - b * plane;
+  const int a = rr / ph.NC;
+  const int c = rr - a * ph.NC;
+  const int by = a * p.sy + ph.offy, bx = c * p.sx + ph.offx;
+  const int SH = p.SH, SW = p.SW;
+  const int JH = TJ ? TJ : ph.JH, JW = TJ ? TJ : ph.JW;
+  const int K = ph.K, C2 = p.C2;
+  const float* __restrict__ A = ph.A;
+  const float* __restrict__ src = p.src + (size_t)b * C2 * SH * SW;
+  float acc[MM];
+#pragma unroll
+  for (int m = 0; m < MM; ++m) acc[m] = 0.f;
+
+  constexpr int MAXJ = TJ ? TJ : 8;
+  int ixs[MAXJ];
+  bool okx[MAXJ];
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    int ix = bx + j * p.dx;
+    bool ok = j < JW;
+    if (REFLECT) {
+      ix = ix < 0 ? -ix : ix;
+      ix = ix >= SW ? 2 * (SW - 1) - ix : ix;
+      ix = min(max(ix, 0), SW - 1);
+    } else {
+      const int cx = min(max(ix, 0), SW - 1);
+      ok = ok && cx == ix;
+      ix = cx;
+    }
+    ixs[j] = ix;
+    okx[j] = ok;
+  }
+  for (int jh = 0; jh < JH; ++jh) {
+    int iy = by + jh * p.dy;
+    bool oky = true;
+    if (REFLECT) {
+      iy = iy < 0 ? -iy : iy;
+      iy = iy >= SH ? 2 * (SH - 1) - iy : iy;
+    } else {
+      const int cy = min(max(iy, 0), SH - 1);
+      oky = cy == iy;
+      iy = cy;
+    }
+    const float* __restrict__ row = src + (size_t)iy * SW;
+    for (int c2 = 0; c2 < C2; ++c2) {
+      const float* __restrict__ r = row + (size_t)c2 * SH * SW;
+      const int kb = (c2 * JH + jh) * JW;
+#pragma unroll
+      for (int j = 0; j < MAXJ; ++j) {
+        if (TJ == 0 && j >= JW) break;
+        float v = r[ixs[j]];
+        v = (oky && okx[j]) ? v : 0.f;
+#pragma unroll
+        for (int m = 0; m < MM; ++m) acc[m] = fmaf(A[(size_t)m * K + kb + j], v, acc[m]);
+      }
+    }
+  }
+  if (n < Ntot) {
+    const int oy = ph.oy0 + p.oys * a, ox = ph.ox0 + p.oxs * c;
+    float* __restrict__ out = p.dst + ((size_t)b * p.M * p.DH + oy) * p.DW + ox;
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+      float v = acc[m];
+      if (p.bias) v += p.bias[m];
+      out[(size_t)m * p.DH * p.DW] = apply_act(v, p.act, p.slope);
+    }
+  }
+}
+
+template <int MM, int TJ>
+static void launch_small_cfg(const GConvP& p, dim3 grid, hipStream_t st) {
+  if (p.pad_mode == HIM_PAD_REFLECT)
+    hipLaunchKernelGGL((gconv_small_kernel<MM, TJ, true>), grid, dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((gconv_small_kernel<MM, TJ, false>), grid, dim3(256), 0, st, p);
+}
+
+// returns true when the tiny-M path took the launch
+static bool launch_gconv_small(const GConvP& p, long long maxN, hipStream_t st) {
+  if (p.M > 4) return false;
+  bool same = true;
+  for (int i = 0; i < p.nphase; ++i) same = same && p.ph[i].JH == p.ph[0].JH && p.ph[i].JW == p.ph[0].JW;
+  for (int i = 0; i < p.nphase; ++i)
+    if (p.ph[i].JH > 8 || p.ph[i].JW > 8) return false;
+  const int tj = (same && p.ph[0].JH == p.ph[0].JW) ? p.ph[0].JH : 0;
+  dim3 grid(cdiv(maxN, 256), 1, p.nphase);
+#define HIM_SMALL(MMv)                                      \
+  case MMv:                                                 \
+    if (tj == 7) launch_small_cfg<MMv, 7>(p, grid, st);      \
+    else if (tj == 4) launch_small_cfg<MMv, 4>(p, grid, st); \
+    else if (tj == 3) launch_small_cfg<MMv, 3>(p, grid, st); \
+    else launch_small_cfg<MMv, 0>(p, grid, st);              \
+    break;
+  switch (p.M) {
+    HIM_SMALL(1)
+    HIM_SMALL(2)
+    HIM_SMALL(3)
+    HIM_SMALL(4)
+  }
+#undef HIM_SMALL
+  return true;
+}
+
 template <int WM, int WN, int TM, int TN>
 static void launch_gconv_cfg(const GConvP& p, dim3 grid, hipStream_t st) {
   if (p.pad_mode == HIM_PAD_REFLECT)
@@ -218,6 +346,7 @@ static int launch_gconv(const GConvP& p, hipStream_t st) {
     if (n > maxN) maxN = n;
   }
   if (maxN == 0 || p.M <= 0) return HIM_OK;
+  if (launch_gconv_small(p, maxN, st)) return check_launch("gconv_small");
   if (p.M <= 32) {
     dim3 grid(cdiv(maxN, 256), cdiv(p.M, 32), p.nphase);
     launch_gconv_cfg<1, 4, 1, 2>(p, grid, st);
@@ -515,6 +644,91 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradP p) {
   }
 }
 
+// ---- tiny-M weight gradient (M = Cout <= 4: the G tanh head).  Direct VALU reduction: one workgroup per
+// (input channel, slice of the B*OH*OW positions); every thread keeps the MM x TJ x TJ partial filter in
+// registers, then a wave64-shuffle + LDS reduction writes one slab per slice (summed in fixed order later).
+template <int MM, int TJ, bool REFLECT>
+__global__ __launch_bounds__(256) void wgrad_small_kernel(const WGradP p) {
+  __shared__ float red[4][MM * TJ * TJ];
+  const int c = blockIdx.x;
+  const int t = threadIdx.x;
+  const int OHW = p.OH * p.OW, HW = p.H * p.W;
+  const int kbeg = blockIdx.y * p.kchunk;
+  const int kend = min(p.Kdim, kbeg + p.kchunk);
+  float acc[MM][TJ][TJ];
+#pragma unroll
+  for (int m = 0; m < MM; ++m)
+#pragma unroll
+    for (int a = 0; a < TJ; ++a)
+#pragma unroll
+      for (int b2 = 0; b2 < TJ; ++b2) acc[m][a][b2] = 0.f;
+  const int H = p.H, W = p.W;
+  for (int k = kbeg + t; k < kend; k += 256) {
+    const int b = k / OHW;
+    const int sp = k - b * OHW;
+    const int oh = (int)fdiv((uint32_t)sp, p.fOW);
+    const int ow = sp - oh * p.OW;
+    float g[MM];
+#pragma unroll
+    for (int m = 0; m < MM; ++m) g[m] = p.dy[((size_t)b * p.M + m) * OHW + sp];
+    const float* __restrict__ xb = p.x + ((size_t)b * p.C + c) * HW;
+    int ixs[TJ];
+    bool okx[TJ];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      int ix = ow * p.stride - p.pad + j;
+      bool ok = true;
+      if (REFLECT) {
+        ix = ix < 0 ? -ix : ix;
+        ix = ix >= W ? 2 * (W - 1) - ix : ix;
+      } else {
+        const int cx = min(max(ix, 0), W - 1);
+        ok = cx == ix;
+        ix = cx;
+      }
+      ixs[j] = ix;
+      okx[j] = ok;
+    }
+#pragma unroll
+    for (int a = 0; a < TJ; ++a) {
+      int iy = oh * p.stride - p.pad + a;
+      bool oky = true;
+      if (REFLECT) {
+        iy = iy < 0 ? -iy : iy;
+        iy = iy >= H ? 2 * (H - 1) - iy : iy;
+      } else {
+        const int cy = min(max(iy, 0), H - 1);
+        oky = cy == iy;
+        iy = cy;
+      }
+      const float* __restrict__ row = xb + (size_t)iy * W;
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        float v = row[ixs[j]];
+        v = (oky && okx[j]) ? v : 0.f;
+#pragma unroll
+        for (int m = 0; m < MM; ++m) acc[m][a][j] = fmaf(g[m], v, acc[m][a][j]);
+      }
+    }
+  }
+  const int wave = t >> 6, lane = t & 63;
+#pragma unroll
+  for (int m = 0; m < MM; ++m)
+#pragma unroll
+    for (int a = 0; a < TJ; ++a)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const float v = wave_sum(acc[m][a][j]);
+        if (lane == 0) red[wave][(m * TJ + a) * TJ + j] = v;
+      }
+  __syncthreads();
+  float* __restrict__ out = p.out + (size_t)blockIdx.y * p.M * p.Np;
+  for (int i = t; i < MM * TJ * TJ; i += 256) {
+    const int m = i / (TJ * TJ), r = i - m * TJ * TJ;
+    out[(size_t)m * p.Np + c * TJ * TJ + r] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+  }
+}
+
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, long long n,
                                    int splits, int accumulate) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -525,19 +739,30 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __res
   }
 }
 
-// dbias[c] (+)= sum_{b,sp} dy[b][c][sp]; one 256-thread block per channel, fixed order.
-__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db,
-                                                        int B, int C, int hw, int accumulate) {
+// dbias[c] (+)= sum_{b,sp} dy[b][c][sp]: stage 1 = (channel, slice) partial sums, stage 2 = fixed-order finish.
+constexpr int BIAS_SLICES = 32;
+__global__ __launch_bounds__(256) void bias_grad1_kernel(const float* __restrict__ dy, float* __restrict__ part,
+                                                         int B, int C, int hw) {
   __shared__ float sh[8];
-  const int c = blockIdx.x;
+  const int c = blockIdx.x, sl = blockIdx.y;
+  const int chunk = (hw + BIAS_SLICES - 1) / BIAS_SLICES;
+  const int beg = sl * chunk, end = min(hw, beg + chunk);
   float s = 0.f;
   for (int b = 0; b < B; ++b) {
     const float* pl = dy + ((size_t)b * C + c) * hw;
-    for (int i = threadIdx.x; i < hw; i += 256) s += pl[i];
+    for (int i = beg + threadIdx.x; i < end; i += 256) s += pl[i];
   }
   s = block_sum_256(s, sh);
-  if (threadIdx.x == 0) db[c] = accumulate ? db[c] + s : s;
+  if (threadIdx.x == 0) part[c * BIAS_SLICES + sl] = s;
 }
+__global__ void bias_grad2_kernel(const float* __restrict__ part, float* __restrict__ db, int C, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int i = 0; i < BIAS_SLICES; ++i) s += part[c * BIAS_SLICES + i];
+  db[c] = accumulate ? db[c] + s : s;
+}
+static size_t bias_ws_bytes(int C) { return (size_t)C * BIAS_SLICES * sizeof(float) + 256; }
 
 static int wgrad_splits(int M, int Np, int Kdim, int BM, int BN) {
   const long long tiles = (long long)cdiv(M, BM) * cdiv(Np, BN);
@@ -553,11 +778,28 @@ static void wgrad_tile(int M, int* BM, int* BN) {
   *BM = M <= 32 ? 32 : (M <= 64 ? 64 : 128);
 }
 
-static size_t wgrad_ws_bytes(int M, int Np, int Kdim) {
-  int BM, BN;
-  wgrad_tile(M, &BM, &BN);
-  const int s = wgrad_splits(M, Np, Kdim, BM, BN);
-  return s > 1 ? (size_t)s * M * Np * sizeof(float) : 0;
+static int small_wgrad_slices(int C, int Kdim) {
+  int s = (2048 + C - 1) / C;
+  const int maxs = cdiv(Kdim, 256 * 8);
+  if (s > maxs) s = maxs;
+  return s < 1 ? 1 : s;
+}
+static bool small_wgrad_ok(int M, int KH, int KW) { return M <= 4 && KH == KW && (KH == 7 || KH == 4 || KH == 3); }
+static size_t wgrad_slab_bytes(int M, int C, int KH, int KW, int Kdim) {
+  const int Np = C * KH * KW;
+  size_t slabs;
+  if (small_wgrad_ok(M, KH, KW)) {
+    slabs = (size_t)small_wgrad_slices(C, Kdim) * M * Np * sizeof(float);
+  } else {
+    int BM, BN;
+    wgrad_tile(M, &BM, &BN);
+    const int s = wgrad_splits(M, Np, Kdim, BM, BN);
+    slabs = s > 1 ? (size_t)s * M * Np * sizeof(float) : 0;
+  }
+  return ((slabs + 255) / 256) * 256;
+}
+static size_t wgrad_ws_bytes(int M, int C, int KH, int KW, int Kdim, int biasC) {
+  return wgrad_slab_bytes(M, C, KH, KW, Kdim) + bias_ws_bytes(biasC);
 }
 
 // generic weight gradient: dW[M][C*KH*KW] from dy[B][M][OH][OW] and x[B][C][H][W]
@@ -584,6 +826,32 @@ static int run_wgrad(const float* dy, const float* x, float* dw, int M, int C, i
   p.fKK = make_fastdiv((uint32_t)(KH * KW));
   p.fKW = make_fastdiv((uint32_t)KW);
   p.fOW = make_fastdiv((uint32_t)OW);
+  if (small_wgrad_ok(M, KH, KW)) {
+    const int slices = small_wgrad_slices(C, p.Kdim);
+    const size_t need = (size_t)slices * M * p.Np * sizeof(float);
+    if (ws_bytes < need || !ws) return fail(HIM_E_WORKSPACE, "wgrad needs %zu ws bytes, got %zu", need, ws_bytes);
+    p.splits = slices;
+    p.accumulate = 0;
+    p.kchunk = cdiv(p.Kdim, slices);
+    p.out = (float*)ws;
+    dim3 grid(C, slices), block(256);
+    const bool refl = pad_mode == HIM_PAD_REFLECT;
+#define HIM_WS(MMv, TJv)                                                                             \
+  if (M == MMv && KH == TJv) {                                                                       \
+    if (refl) hipLaunchKernelGGL((wgrad_small_kernel<MMv, TJv, true>), grid, block, 0, st, p);        \
+    else hipLaunchKernelGGL((wgrad_small_kernel<MMv, TJv, false>), grid, block, 0, st, p);            \
+  }
+    HIM_WS(1, 7) HIM_WS(2, 7) HIM_WS(3, 7) HIM_WS(4, 7)
+    HIM_WS(1, 4) HIM_WS(2, 4) HIM_WS(3, 4) HIM_WS(4, 4)
+    HIM_WS(1, 3) HIM_WS(2, 3) HIM_WS(3, 3) HIM_WS(4, 3)
+#undef HIM_WS
+    int rc0 = check_launch("wgrad_small");
+    if (rc0) return rc0;
+    const long long n = (long long)M * p.Np;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(std::min<long long>(cdiv(n, 256), 4096)), dim3(256), 0, st,
+                       (const float*)ws, dw, n, slices, accumulate);
+    return check_launch("slab_reduce");
+  }
   int BM, BN;
   wgrad_tile(M, &BM, &BN);
   const int splits = wgrad_splits(M, p.Np, p.Kdim, BM, BN);
@@ -622,8 +890,11 @@ static int run_wgrad(const float* dy, const float* x, float* dw, int M, int C, i
   return rc;
 }
 
-static int run_bias_grad(const float* dy, float* db, int B, int C, int hw, int accumulate, hipStream_t st) {
-  hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, st, dy, db, B, C, hw, accumulate);
+static int run_bias_grad(const float* dy, float* db, int B, int C, int hw, int accumulate, void* ws, size_t ws_bytes,
+                         hipStream_t st) {
+  if (!ws || ws_bytes < bias_ws_bytes(C)) return fail(HIM_E_WORKSPACE, "bias grad ws too small");
+  hipLaunchKernelGGL(bias_grad1_kernel, dim3(C, BIAS_SLICES), dim3(256), 0, st, dy, (float*)ws, B, C, hw);
+  hipLaunchKernelGGL(bias_grad2_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, (const float*)ws, db, C, accumulate);
   return check_launch("bias_grad");
 }
 
@@ -778,7 +1049,7 @@ int him_conv2d_bwd_data(const HimConv2d* d, const float* dy, const float* w, flo
 }
 
 size_t him_conv2d_bwd_weight_ws(const HimConv2d* d) {
-  return d ? wgrad_ws_bytes(d->Cout, d->Cin * d->KH * d->KW, d->B * d->OH * d->OW) : 0;
+  return d ? wgrad_ws_bytes(d->Cout, d->Cin, d->KH, d->KW, d->B * d->OH * d->OW, d->Cout) : 0;
 }
 
 int him_conv2d_bwd_weight(const HimConv2d* d, const float* x, const float* dy, float* dw, float* dbias,
@@ -790,7 +1061,12 @@ int him_conv2d_bwd_weight(const HimConv2d* d, const float* x, const float* dy, f
                    d->pad_mode, accumulate, ws, ws_bytes, (hipStream_t)stream);
     if (rc) return rc;
   }
-  if (dbias) rc = run_bias_grad(dy, dbias, d->B, d->Cout, d->OH * d->OW, accumulate, (hipStream_t)stream);
+  if (dbias) {
+    const size_t off = wgrad_slab_bytes(d->Cout, d->Cin, d->KH, d->KW, d->B * d->OH * d->OW);
+    if (ws_bytes < off) return fail(HIM_E_WORKSPACE, "bwd_weight ws too small");
+    rc = run_bias_grad(dy, dbias, d->B, d->Cout, d->OH * d->OW, accumulate, (char*)ws + off, ws_bytes - off,
+                       (hipStream_t)stream);
+  }
   return rc;
 }
 
@@ -821,7 +1097,7 @@ int him_deconv2d_bwd_data(const HimDeconv2d* t, const float* dy, const float* w,
 size_t him_deconv2d_bwd_weight_ws(const HimDeconv2d* t) {
   HimConv2d c;
   if (adjoint_of(t, &c)) return 0;
-  return wgrad_ws_bytes(c.Cout, c.Cin * c.KH * c.KW, c.B * c.OH * c.OW);
+  return wgrad_ws_bytes(c.Cout, c.Cin, c.KH, c.KW, c.B * c.OH * c.OW, t->Cout);
 }
 
 int him_deconv2d_bwd_weight(const HimDeconv2d* t, const float* x, const float* dy, float* dw, float* dbias,
@@ -835,7 +1111,12 @@ int him_deconv2d_bwd_weight(const HimDeconv2d* t, const float* x, const float* d
                    accumulate, ws, ws_bytes, (hipStream_t)stream);
     if (rc) return rc;
   }
-  if (dbias) rc = run_bias_grad(dy, dbias, t->B, t->Cout, t->OH * t->OW, accumulate, (hipStream_t)stream);
+  if (dbias) {
+    const size_t off = wgrad_slab_bytes(c.Cout, c.Cin, c.KH, c.KW, c.B * c.OH * c.OW);
+    if (ws_bytes < off) return fail(HIM_E_WORKSPACE, "bwd_weight ws too small");
+    rc = run_bias_grad(dy, dbias, t->B, t->Cout, t->OH * t->OW, accumulate, (char*)ws + off, ws_bytes - off,
+                       (hipStream_t)stream);
+  }
   return rc;
 }
 

@@ -112,7 +112,6 @@ class _Conv2d(torch.autograd.Function):
                 dw = torch.empty_like(w) if need_w else None
                 db = torch.empty_like(b) if need_b else None
                 lib.him_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dz), _p(dw), _p(db), 0, _p(ws), nb, st)
-        ctx.x = ctx.y = None
         return dx, dw, db, None, None, None, None, None
 
 
@@ -172,7 +171,6 @@ class _Deconv2d(torch.autograd.Function):
                 dw = torch.empty_like(w) if need_w else None
                 db = torch.empty_like(b) if need_b else None
                 lib.him_deconv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dz), _p(dw), _p(db), 0, _p(ws), nb, st)
-        ctx.x = ctx.y = None
         return dx, dw, db, None, None, None, None, None
 
 
@@ -211,7 +209,6 @@ class _InstNorm(torch.autograd.Function):
             lib.him_instnorm_bwd(_p(ctx.x), _p(ctx.mean), _p(ctx.rstd), _p(dy), _p(dx), planes, hw, act, slope,
                                  _stream())
         dres = dy if (ctx.has_res and ctx.needs_input_grad[1]) else None
-        ctx.x = None
         return dx, dres, None, None, None
 
 
@@ -267,7 +264,6 @@ class _MaxPool(torch.autograd.Function):
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         lib.him_maxpool_bwd(_p(x), _p(dy), _p(dx), B * Cn, H, W, k, _stream())
-        ctx.x = None
         return dx, None
 
 
@@ -445,7 +441,6 @@ class _L1Mean(torch.autograd.Function):
         g = g.contiguous()
         da = torch.empty_like(a)
         lib.him_l1_mean_bwd(_p(a), _p(b), a.numel(), _p(g), _p(da), 0, _stream())
-        ctx.a = ctx.b = None
         return da, None
 
 
@@ -472,7 +467,6 @@ class _MSEConst(torch.autograd.Function):
         g = g.contiguous()
         dx = torch.empty_like(x)
         lib.him_mse_const_bwd(_p(x), x.numel(), ctx.t, _p(g), _p(dx), 0, _stream())
-        ctx.x = None
         return dx, None
 
 
