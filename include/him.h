@@ -60,9 +60,10 @@ typedef struct HimConv2d {
   float slope;        /* LeakyReLU negative slope */
 } HimConv2d;
 
-/* y = act(conv(x, w) + bias); bias may be NULL. */
-int him_conv2d_fwd(const HimConv2d* d, const float* x, const float* w, const float* bias, float* y,
-                   void* stream);
+/* y = act(conv(x, w) + bias); bias may be NULL.  ws holds the tap-major regrouped weight tile stream. */
+size_t him_conv2d_fwd_ws(const HimConv2d* d);
+int him_conv2d_fwd(const HimConv2d* d, const float* x, const float* w, const float* bias, float* y, void* ws,
+                   size_t ws_bytes, void* stream);
 /* dx = conv^T(dy, w); dy is the gradient w.r.t. the PRE-activation output (see him_act_bwd). */
 size_t him_conv2d_bwd_data_ws(const HimConv2d* d);
 int him_conv2d_bwd_data(const HimConv2d* d, const float* dy, const float* w, float* dx, void* ws,
@@ -86,7 +87,9 @@ typedef struct HimDeconv2d {
 size_t him_deconv2d_fwd_ws(const HimDeconv2d* d);
 int him_deconv2d_fwd(const HimDeconv2d* d, const float* x, const float* w, const float* bias, float* y,
                      void* ws, size_t ws_bytes, void* stream);
-int him_deconv2d_bwd_data(const HimDeconv2d* d, const float* dy, const float* w, float* dx, void* stream);
+size_t him_deconv2d_bwd_data_ws(const HimDeconv2d* d);
+int him_deconv2d_bwd_data(const HimDeconv2d* d, const float* dy, const float* w, float* dx, void* ws,
+                          size_t ws_bytes, void* stream);
 size_t him_deconv2d_bwd_weight_ws(const HimDeconv2d* d);
 int him_deconv2d_bwd_weight(const HimDeconv2d* d, const float* x, const float* dy, float* dw, float* dbias,
                             int accumulate, void* ws, size_t ws_bytes, void* stream);

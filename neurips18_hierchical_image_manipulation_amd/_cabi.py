@@ -34,14 +34,16 @@ _SIGS = {
     'him_version': (C.c_char_p, []),
     'him_arch': (C.c_char_p, []),
     'him_last_error': (C.c_char_p, []),
-    'him_conv2d_fwd': (c_int, [_CONV, P, P, P, P, P]),
+    'him_conv2d_fwd_ws': (c_size_t, [_CONV]),
+    'him_conv2d_fwd': (c_int, [_CONV, P, P, P, P, P, c_size_t, P]),
     'him_conv2d_bwd_data_ws': (c_size_t, [_CONV]),
     'him_conv2d_bwd_data': (c_int, [_CONV, P, P, P, P, c_size_t, P]),
     'him_conv2d_bwd_weight_ws': (c_size_t, [_CONV]),
     'him_conv2d_bwd_weight': (c_int, [_CONV, P, P, P, P, c_int, P, c_size_t, P]),
     'him_deconv2d_fwd_ws': (c_size_t, [_DECONV]),
     'him_deconv2d_fwd': (c_int, [_DECONV, P, P, P, P, P, c_size_t, P]),
-    'him_deconv2d_bwd_data': (c_int, [_DECONV, P, P, P, P]),
+    'him_deconv2d_bwd_data_ws': (c_size_t, [_DECONV]),
+    'him_deconv2d_bwd_data': (c_int, [_DECONV, P, P, P, P, c_size_t, P]),
     'him_deconv2d_bwd_weight_ws': (c_size_t, [_DECONV]),
     'him_deconv2d_bwd_weight': (c_int, [_DECONV, P, P, P, P, c_int, P, c_size_t, P]),
     'him_instnorm_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_float, c_int, c_float, P]),

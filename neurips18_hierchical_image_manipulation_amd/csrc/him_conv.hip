@@ -16,6 +16,8 @@
 // A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; accumulator register r of lane l is
 // D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31]  -> putting the spatial index on j makes every accumulator
 // register a 128-byte coalesced NCHW row segment.
+#include <stdlib.h>
+
 #include <algorithm>
 #include <type_traits>
 
@@ -24,6 +26,8 @@
 namespace him {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef const __attribute__((address_space(1))) char* gchar_p;    // explicit global address space: keeps
+typedef const __attribute__((address_space(1))) float* gfloat_p;  // global_load (not flat_load) after asm laundering
 
 // ==============================================================================================
 // gconv
@@ -36,6 +40,9 @@ struct GPhase {
   int NA, NC;      // output sub-grid of this phase
   int oy0, ox0;    // dest origin (dest y = oy0 + oys*a)
   int offy, offx;  // source origin (src y = a*sy + jh*dy + offy)
+  // fast path: weights regrouped tap-major, channel-padded: At[m][(jh*JW + jw)*C2p + c2]
+  const float* At;
+  int C2p;
 };
 
 struct GConvP {
@@ -47,8 +54,264 @@ struct GConvP {
   int pad_mode, act;
   float slope;
   int nphase;
+  int fast;  // 1: ph[].At valid -> gconv_fast_kernel
   GPhase ph[4];
 };
+
+// =============================================================================================
+// gconv, fast path (C2 >= 16): the reduction index runs TAP-MAJOR, k' = (jh*JW + jw)*C2p + c2, so one K-step of
+// 16 holds 16 channels of ONE filter tap.  The gather address is then (per-thread tap offset, computed once per
+// K-step) + (wave-uniform channel offset folded into the scalar base) = one global_load per element, and the
+// weight tile is plain contiguous float4s.  LDS rows are [row][16 k + 4 pad]; with the k <-> (lane>>5) pairing
+// k = 8*(lane>>5) + kp each lane's 8 operands of a K-step are two aligned ds_read_b128 (conflict-free at stride 20
+// dwords), and the tile writes are ds_write_b128 as well.  ~2 non-MFMA instructions per MFMA instead of ~19.
+// =============================================================================================
+template <int WM, int WN, int TM, int TN, bool REFLECT, bool CLAMPC>
+__global__ __launch_bounds__(256) void gconv_fast_kernel(const GConvP p) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 16, LD = 20;
+  constexpr int A_V4 = BM * BK / 4 / 256;  // float4 loads per thread for the weight tile
+  constexpr int KPT = BK * BN / 256;       // consecutive channels per thread in the gathered tile (8 or 4)
+  static_assert(WM * WN == 4, "4 waves");
+  static_assert((A_V4 == 1 || A_V4 == 2) && (KPT == 4 || KPT == 8), "tile shape");
+  __shared__ __attribute__((aligned(16))) float sA[2][BM * LD];
+  __shared__ __attribute__((aligned(16))) float sB[2][BN * LD];
+
+  const GPhase& ph = p.ph[blockIdx.z];
+  const int plane = ph.NA * ph.NC;
+  const int Ntot = p.B * plane;
+  // XCD-aware tile order: workgroup L runs on XCD L % 8 (observed dispatch; speed only, never correctness), so give
+  // each XCD a CONTIGUOUS run of m-major tiles: its 32 CUs then share one weight panel through their private L2.
+  int m0, n0;
+  {
+    const int nmt = (p.M + BM - 1) / BM, nnt = gridDim.x / nmt;
+    const int total = nmt * nnt, L = blockIdx.x;
+    const int q = total >> 3, r = total & 7, xcd = L & 7, slot = L >> 3;
+    const int T = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    const int mt = T / nnt;
+    m0 = mt * BM;
+    n0 = (T - mt * nnt) * BN;
+  }
+  if (n0 >= Ntot) return;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const float* __restrict__ At = ph.At;
+  const float* __restrict__ src = p.src;
+  const int C2 = p.C2, C2p = ph.C2p, CB = C2p / BK;
+  const int JW = ph.JW;
+  const int nk = ph.JH * JW * CB;
+  const uint32_t Kp = (uint32_t)nk * BK;
+
+  // weight tile: thread -> (row = t/4 + 64 i, k quad = t%4)
+  const int arow = t >> 2, akq = t & 3;
+  uint32_t aoff[A_V4];
+#pragma unroll
+  for (int i = 0; i < A_V4; ++i) aoff[i] = (uint32_t)min(m0 + arow + i * 64, p.M - 1) * Kp + akq * 4;
+
+  // gathered tile: thread -> (column nl, channel group kg)
+  const int nl = t % BN;
+  const int kg = __builtin_amdgcn_readfirstlane(t / BN);
+  const int n = min(n0 + nl, Ntot - 1);
+  const int b = n / plane;
+  const int rr = n - b * plane;
+  const int a = rr / ph.NC;
+  const int c = rr - a * ph.NC;
+  const int by = a * p.sy + ph.offy, bx = c * p.sx + ph.offx;
+  const int SH = p.SH, SW = p.SW;
+  const uint32_t SHSW = (uint32_t)SH * SW;
+  const uint32_t boff = (uint32_t)b * C2 * SHSW;
+  const int ddy = p.dy, ddx = p.dx;
+
+  // Two register sets (X, Y): tile kt+2 is in flight into one while tile kt+1 (landed an iteration ago) is written to
+  // LDS from the other -> two full MFMA blocks (~4k cycles) of cover for HBM/MALL latency.
+  float4 xa0, xa1, ya0, ya1;
+  float xb[KPT], yb[KPT];
+  xa1 = ya1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  int c_cb = 0, c_jh = 0, c_jw = 0;  // wave-uniform cursor of the tile being loaded: (tap row, tap col, channel block)
+  const char* __restrict__ Atb = (const char*)At;
+  const char* __restrict__ srcb = (const char*)src;
+  const size_t chan_bytes = (size_t)SHSW * 4;
+
+  // issue the global loads of tile kt (weights: contiguous float4; gather: one load per element with the channel
+  // offset folded into the wave-uniform base pointer -> "global_load v, v_off, s[base]" addressing, no 64-bit VALU)
+#define HIM_LOAD_TILE(kt_, RA0, RA1, RB)                                                                     \
+  {                                                                                                          \
+    const uint32_t kbyte = (uint32_t)(kt_) * (BK * 4);                                                        \
+    RA0 = *(const float4*)(Atb + (aoff[0] * 4u + kbyte));                                                    \
+    if (A_V4 > 1) RA1 = *(const float4*)(Atb + (aoff[A_V4 - 1] * 4u + kbyte));                               \
+    int iy = by + c_jh * ddy, ix = bx + c_jw * ddx;                                                           \
+    bool ok = true;                                                                                          \
+    if (REFLECT) {                                                                                           \
+      iy = iy < 0 ? -iy : iy;                                                                                \
+      iy = iy >= SH ? 2 * (SH - 1) - iy : iy;                                                                \
+      ix = ix < 0 ? -ix : ix;                                                                                \
+      ix = ix >= SW ? 2 * (SW - 1) - ix : ix;                                                                \
+    } else {                                                                                                 \
+      const int cy = min(max(iy, 0), SH - 1), cx = min(max(ix, 0), SW - 1);                                  \
+      ok = (cy == iy) && (cx == ix);                                                                         \
+      iy = cy;                                                                                               \
+      ix = cx;                                                                                               \
+    }                                                                                                        \
+    const uint32_t tapbyte = (boff + (uint32_t)iy * (uint32_t)SW + (uint32_t)ix) * 4u;                        \
+    const int c0 = c_cb * BK + kg * KPT;                                                                     \
+    gchar_p sp = (gchar_p)srcb + (size_t)(CLAMPC ? min(c0, C2 - 1) : c0) * chan_bytes;                       \
+    _Pragma("unroll") for (int i = 0; i < KPT; ++i) {                                                        \
+      asm volatile("" : "+s"(sp)); /* keep the wave-uniform base in SGPRs: saddr + 32-bit voffset load */    \
+      const float v = *(gfloat_p)(sp + tapbyte);                                                             \
+      RB[i] = ok ? v : 0.f;                                                                                  \
+      sp += (CLAMPC && c0 + i + 1 > C2 - 1) ? 0 : chan_bytes;                                                \
+    }                                                                                                        \
+  }
+#define HIM_STORE_TILE(buf_, RA0, RA1, RB)                                                                    \
+  {                                                                                                          \
+    *(float4*)&sA[buf_][arow * LD + akq * 4] = RA0;                                                          \
+    if (A_V4 > 1) *(float4*)&sA[buf_][(arow + 64) * LD + akq * 4] = RA1;                                     \
+    _Pragma("unroll") for (int q = 0; q < KPT / 4; ++q) *(float4*)&sB[buf_][nl * LD + kg * KPT + q * 4] =     \
+        make_float4(RB[q * 4], RB[q * 4 + 1], RB[q * 4 + 2], RB[q * 4 + 3]);                                 \
+  }
+#define HIM_ADVANCE()                \
+  {                                  \
+    ++c_cb;                          \
+    const bool w1 = c_cb == CB;      \
+    c_cb = w1 ? 0 : c_cb;            \
+    c_jw += w1 ? 1 : 0;              \
+    const bool w2 = c_jw == JW;      \
+    c_jw = w2 ? 0 : c_jw;            \
+    c_jh += w2 ? 1 : 0;              \
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  HIM_LOAD_TILE(0, xa0, xa1, xb)
+  HIM_STORE_TILE(0, xa0, xa1, xb)
+  if (nk > 1) HIM_ADVANCE()
+  HIM_LOAD_TILE(min(1, nk - 1), ya0, ya1, yb)   // tile 1 stays in flight in set Y
+  __syncthreads();
+
+  // one K-step: prefetch tile kt+2 into (LA0,LA1,LB), run the MFMAs of tile kt from LDS buffer kt&1, write tile kt+1
+  // (SA0,SA1,SB) into the other buffer.  Past-the-end tiles are clamped re-loads that are never consumed.
+#define HIM_KSTEP(kt_, LA0, LA1, LB, SA0, SA1, SB)                                                           \
+  {                                                                                                          \
+    const int buf = (kt_) & 1;                                                                               \
+    if ((kt_) + 2 < nk) HIM_ADVANCE()                                                                        \
+    const float4* __restrict__ pa = (const float4*)&sA[buf][(wm * TM * 32 + l31) * LD + lh * 8];            \
+    const float4* __restrict__ pb = (const float4*)&sB[buf][(wn * TN * 32 + l31) * LD + lh * 8];            \
+    float4 a0[TM], a1[TM], b0[TN], b1[TN];                                                                   \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                         \
+      a0[i] = pa[i * 32 * LD / 4];                                                                           \
+      a1[i] = pa[i * 32 * LD / 4 + 1];                                                                       \
+    }                                                                                                        \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                         \
+      b0[j] = pb[j * 32 * LD / 4];                                                                           \
+      b1[j] = pb[j * 32 * LD / 4 + 1];                                                                       \
+    }                                                                                                        \
+    HIM_LOAD_TILE(min((kt_) + 2, nk - 1), LA0, LA1, LB)                                                      \
+    HIM_MFMA_STEP(a0[i].x, b0[j].x)                                                                          \
+    HIM_MFMA_STEP(a0[i].y, b0[j].y)                                                                          \
+    HIM_MFMA_STEP(a0[i].z, b0[j].z)                                                                          \
+    HIM_MFMA_STEP(a0[i].w, b0[j].w)                                                                          \
+    HIM_MFMA_STEP(a1[i].x, b1[j].x)                                                                          \
+    HIM_MFMA_STEP(a1[i].y, b1[j].y)                                                                          \
+    HIM_MFMA_STEP(a1[i].z, b1[j].z)                                                                          \
+    HIM_MFMA_STEP(a1[i].w, b1[j].w)                                                                          \
+    HIM_STORE_TILE(buf ^ 1, SA0, SA1, SB)                                                                    \
+    __syncthreads();                                                                                         \
+  }
+#define HIM_MFMA_STEP(AX, BX)                                                                                 \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] =   \
+      __builtin_amdgcn_mfma_f32_32x32x2f32(AX, BX, acc[i][j], 0, 0, 0);
+
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    HIM_KSTEP(kt, xa0, xa1, xb, ya0, ya1, yb)
+    HIM_KSTEP(kt + 1, ya0, ya1, yb, xa0, xa1, xb)
+  }
+  if (kt < nk) HIM_KSTEP(kt, xa0, xa1, xb, ya0, ya1, yb)
+#undef HIM_MFMA_STEP
+#undef HIM_KSTEP
+#undef HIM_ADVANCE
+#undef HIM_LOAD_TILE
+#undef HIM_STORE_TILE
+
+
+  const int act = p.act;
+  const float slope = p.slope;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int nn = n0 + wn * TN * 32 + j * 32 + l31;
+    if (nn >= Ntot) continue;
+    const int bb = nn / plane;
+    const int r2 = nn - bb * plane;
+    const int aa = r2 / ph.NC, cc = r2 - aa * ph.NC;
+    const int oy = ph.oy0 + p.oys * aa, ox = ph.ox0 + p.oxs * cc;
+    float* __restrict__ out = p.dst + ((size_t)bb * p.M * p.DH + oy) * p.DW + ox;
+    const size_t mstride = (size_t)p.DH * p.DW;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < p.M) {
+          float v = acc[i][j][r];
+          if (p.bias) v += p.bias[m];
+          out[(size_t)m * mstride] = apply_act(v, act, slope);
+        }
+      }
+    }
+  }
+}
+
+template <int WM, int WN, int TM, int TN>
+static void launch_fast_cfg(const GConvP& p, dim3 grid, hipStream_t st) {
+  const bool clampc = (p.C2 % 16) != 0;
+  if (p.pad_mode == HIM_PAD_REFLECT) {
+    if (clampc) hipLaunchKernelGGL((gconv_fast_kernel<WM, WN, TM, TN, true, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gconv_fast_kernel<WM, WN, TM, TN, true, false>), grid, dim3(256), 0, st, p);
+  } else {
+    if (clampc) hipLaunchKernelGGL((gconv_fast_kernel<WM, WN, TM, TN, false, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gconv_fast_kernel<WM, WN, TM, TN, false, false>), grid, dim3(256), 0, st, p);
+  }
+}
+
+// ---- weight regrouping for the fast path: out[m][(jh*JW + jw)*C2p + c2] = W[base + m*sm + c2*sc + jh*sh + jw*sw]
+struct WT2Phase {
+  float* out;
+  int JH, JW;
+  long long sh, sw, base;
+  long long total;  // M*JH*JW*C2p
+};
+struct WT2P {
+  const float* W;
+  int M, C2, C2p;
+  long long sm, sc;
+  WT2Phase ph[4];
+};
+__global__ void wtrans2_kernel(const WT2P p) {
+  const WT2Phase& q = p.ph[blockIdx.y];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < q.total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c2 = (int)(i % p.C2p);
+    long long r = i / p.C2p;
+    const int jw = (int)(r % q.JW);
+    r /= q.JW;
+    const int jh = (int)(r % q.JH);
+    const long long m = r / q.JH;
+    q.out[i] = c2 < p.C2 ? p.W[q.base + m * p.sm + c2 * p.sc + jh * q.sh + jw * q.sw] : 0.f;
+  }
+}
+
+static bool use_fast(int M, int C2) {
+  static int force_generic = -1;
+  if (force_generic < 0) force_generic = getenv("HIM_GENERIC_CONV") ? 1 : 0;
+  return !force_generic && M > 4 && C2 >= 16;
+}
+static int pad16(int c) { return (c + 15) / 16 * 16; }
 
 template <int WM, int WN, int TM, int TN, bool REFLECT>
 __global__ __launch_bounds__(256) void gconv_kernel(const GConvP p) {
@@ -219,13 +482,18 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GConvP p) {
 // M rows would waste >= 87 % of a 32-wide MFMA tile, so this path is a direct VALU convolution: one thread
 // per output position, MM accumulators, wave-uniform weights (scalar loads), coalesced gathers along x.
 // TJ = compile-time tap count per axis (0: run-time JH/JW).
-template <int MM, int TJ, bool REFLECT>
+// CS = channel slices per workgroup (1: thread = one position, all channels; 4: 64 positions x 4 channel quarters,
+// LDS-reduced) -- the latter feeds the few-thousand-position PatchGAN heads whose reduction is 8192 long.
+template <int MM, int TJ, bool REFLECT, int CS>
 __global__ __launch_bounds__(256) void gconv_small_kernel(const GConvP p) {
+  __shared__ float red[CS > 1 ? 256 * MM : 1];
+  constexpr int NPB = 256 / CS;  // positions per block
   const GPhase& ph = p.ph[blockIdx.z];
   const int plane = ph.NA * ph.NC;
   const int Ntot = p.B * plane;
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (blockIdx.x * 256 >= Ntot) return;
+  const int cs = threadIdx.x / NPB;
+  const int n = blockIdx.x * NPB + threadIdx.x % NPB;
+  if (blockIdx.x * NPB >= Ntot) return;
   const int nc = min(n, Ntot - 1);
   const int b = nc / plane;
   const int rr = nc - b * plane;
@@ -272,7 +540,10 @@ __global__ __launch_bounds__(256) void gconv_small_kernel(const GConvP p) {
       iy = cy;
     }
     const float* __restrict__ row = src + (size_t)iy * SW;
-    for (int c2 = 0; c2 < C2; ++c2) {
+    const int cbeg = CS > 1 ? cs * ((C2 + CS - 1) / CS) : 0;
+    const int cend = CS > 1 ? min(C2, cbeg + (C2 + CS - 1) / CS) : C2;
+#pragma unroll 4
+    for (int c2 = cbeg; c2 < cend; ++c2) {
       const float* __restrict__ r = row + (size_t)c2 * SH * SW;
       const int kb = (c2 * JH + jh) * JW;
 #pragma unroll
@@ -283,6 +554,19 @@ __global__ __launch_bounds__(256) void gconv_small_kernel(const GConvP p) {
 #pragma unroll
         for (int m = 0; m < MM; ++m) acc[m] = fmaf(A[(size_t)m * K + kb + j], v, acc[m]);
       }
+    }
+  }
+  if (CS > 1) {
+#pragma unroll
+    for (int m = 0; m < MM; ++m) red[threadIdx.x * MM + m] = acc[m];
+    __syncthreads();
+    if (cs != 0) return;
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < CS; ++q) v += red[(q * NPB + threadIdx.x) * MM + m];
+      acc[m] = v;
     }
   }
   if (n < Ntot) {
@@ -298,11 +582,21 @@ __global__ __launch_bounds__(256) void gconv_small_kernel(const GConvP p) {
 }
 
 template <int MM, int TJ>
-static void launch_small_cfg(const GConvP& p, dim3 grid, hipStream_t st) {
-  if (p.pad_mode == HIM_PAD_REFLECT)
-    hipLaunchKernelGGL((gconv_small_kernel<MM, TJ, true>), grid, dim3(256), 0, st, p);
-  else
-    hipLaunchKernelGGL((gconv_small_kernel<MM, TJ, false>), grid, dim3(256), 0, st, p);
+static void launch_small_cfg(const GConvP& p, long long maxN, hipStream_t st) {
+  const bool split = maxN < 256 * 512 && p.C2 >= 64;  // too few positions to fill 256 CUs: split the channels
+  if (split) {
+    dim3 grid(cdiv(maxN, 64), 1, p.nphase);
+    if (p.pad_mode == HIM_PAD_REFLECT)
+      hipLaunchKernelGGL((gconv_small_kernel<MM, TJ, true, 4>), grid, dim3(256), 0, st, p);
+    else
+      hipLaunchKernelGGL((gconv_small_kernel<MM, TJ, false, 4>), grid, dim3(256), 0, st, p);
+  } else {
+    dim3 grid(cdiv(maxN, 256), 1, p.nphase);
+    if (p.pad_mode == HIM_PAD_REFLECT)
+      hipLaunchKernelGGL((gconv_small_kernel<MM, TJ, true, 1>), grid, dim3(256), 0, st, p);
+    else
+      hipLaunchKernelGGL((gconv_small_kernel<MM, TJ, false, 1>), grid, dim3(256), 0, st, p);
+  }
 }
 
 // returns true when the tiny-M path took the launch
@@ -313,13 +607,12 @@ static bool launch_gconv_small(const GConvP& p, long long maxN, hipStream_t st) 
   for (int i = 0; i < p.nphase; ++i)
     if (p.ph[i].JH > 8 || p.ph[i].JW > 8) return false;
   const int tj = (same && p.ph[0].JH == p.ph[0].JW) ? p.ph[0].JH : 0;
-  dim3 grid(cdiv(maxN, 256), 1, p.nphase);
 #define HIM_SMALL(MMv)                                      \
   case MMv:                                                 \
-    if (tj == 7) launch_small_cfg<MMv, 7>(p, grid, st);      \
-    else if (tj == 4) launch_small_cfg<MMv, 4>(p, grid, st); \
-    else if (tj == 3) launch_small_cfg<MMv, 3>(p, grid, st); \
-    else launch_small_cfg<MMv, 0>(p, grid, st);              \
+    if (tj == 7) launch_small_cfg<MMv, 7>(p, maxN, st);      \
+    else if (tj == 4) launch_small_cfg<MMv, 4>(p, maxN, st); \
+    else if (tj == 3) launch_small_cfg<MMv, 3>(p, maxN, st); \
+    else launch_small_cfg<MMv, 0>(p, maxN, st);              \
     break;
   switch (p.M) {
     HIM_SMALL(1)
@@ -347,6 +640,25 @@ static int launch_gconv(const GConvP& p, hipStream_t st) {
   }
   if (maxN == 0 || p.M <= 0) return HIM_OK;
   if (launch_gconv_small(p, maxN, st)) return check_launch("gconv_small");
+  if (p.fast) {
+    static int tile_override = -2;
+    if (tile_override == -2) tile_override = getenv("HIM_GCONV_TILE") ? atoi(getenv("HIM_GCONV_TILE")) : -1;
+    if (p.M <= 64) {
+      dim3 grid(cdiv(maxN, 128) * cdiv(p.M, 64), 1, p.nphase);
+      launch_fast_cfg<2, 2, 1, 2>(p, grid, st);
+    } else {
+      const long long tiles128 = (long long)cdiv(maxN, 128) * cdiv(p.M, 128) * p.nphase;
+      const bool big = tile_override >= 0 ? tile_override == 1 : tiles128 >= 200;
+      if (big) {
+        dim3 grid(cdiv(maxN, 128) * cdiv(p.M, 128), 1, p.nphase);
+        launch_fast_cfg<2, 2, 2, 2>(p, grid, st);
+      } else {
+        dim3 grid(cdiv(maxN, 64) * cdiv(p.M, 128), 1, p.nphase);
+        launch_fast_cfg<2, 2, 2, 1>(p, grid, st);
+      }
+    }
+    return check_launch("gconv_fast");
+  }
   if (p.M <= 32) {
     dim3 grid(cdiv(maxN, 256), cdiv(p.M, 32), p.nphase);
     launch_gconv_cfg<1, 4, 1, 2>(p, grid, st);
@@ -951,10 +1263,47 @@ static void fill_fprop(GConvP& g, const HimConv2d* d, const float* x, const floa
   P.offy = P.offx = -d->pad;
 }
 
+static size_t fprop_ws_bytes(const HimConv2d* d) {
+  if (!use_fast(d->Cout, d->Cin)) return 0;
+  return (size_t)d->Cout * d->KH * d->KW * pad16(d->Cin) * sizeof(float) + 256;
+}
+static int run_fprop(const HimConv2d* d, const float* x, const float* w, const float* bias, float* y, void* ws,
+                     size_t ws_bytes, hipStream_t st) {
+  GConvP g;
+  fill_fprop(g, d, x, w, bias, y);
+  if (use_fast(d->Cout, d->Cin)) {
+    const size_t need = fprop_ws_bytes(d);
+    if (!ws || ws_bytes < need) return fail(HIM_E_WORKSPACE, "conv fwd needs %zu ws bytes, got %zu", need, ws_bytes);
+    WT2P t;
+    memset(&t, 0, sizeof(t));
+    const int KK = d->KH * d->KW;
+    t.W = w;
+    t.M = d->Cout;
+    t.C2 = d->Cin;
+    t.C2p = pad16(d->Cin);
+    t.sm = (long long)d->Cin * KK;
+    t.sc = KK;
+    t.ph[0].out = (float*)ws;
+    t.ph[0].JH = d->KH;
+    t.ph[0].JW = d->KW;
+    t.ph[0].sh = d->KW;
+    t.ph[0].sw = 1;
+    t.ph[0].base = 0;
+    t.ph[0].total = (long long)d->Cout * KK * t.C2p;
+    hipLaunchKernelGGL(wtrans2_kernel, dim3(std::min<long long>(cdiv(t.ph[0].total, 256), 4096), 1), dim3(256), 0, st, t);
+    int rc = check_launch("wtrans2");
+    if (rc) return rc;
+    g.fast = 1;
+    g.ph[0].At = (const float*)ws;
+    g.ph[0].C2p = t.C2p;
+  }
+  return launch_gconv(g, st);
+}
+
 // data gradient of the conv described by `d` (also the forward of its transposed conv):
 // out (B,Cin,H,W) = sum W * g (B,Cout,OH,OW); for reflect mode goes through the padded gradient + fold.
 static size_t dgrad_ws_bytes(const HimConv2d* d) {
-  size_t n = (size_t)d->Cin * d->Cout * d->KH * d->KW;
+  size_t n = (size_t)d->Cin * pad16(d->Cout) * d->KH * d->KW + 64;
   if (d->pad_mode == HIM_PAD_REFLECT)
     n += (size_t)d->B * d->Cin * (d->H + 2 * d->pad) * (d->W + 2 * d->pad);
   return n * sizeof(float) + 256;
@@ -971,7 +1320,34 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
   memset(&wt, 0, sizeof(wt));
   wt.W = w;
   const int IH = refl ? d->H + 2 * d->pad : d->H, IW = refl ? d->W + 2 * d->pad : d->W;
-  const long long nw = setup_dgrad(g, wt, d->Cout, d->Cin, d->KH, d->KW, d->stride, refl ? 0 : d->pad, IH, IW, Wt);
+  long long nw = setup_dgrad(g, wt, d->Cout, d->Cin, d->KH, d->KW, d->stride, refl ? 0 : d->pad, IH, IW, Wt);
+  const bool fast = use_fast(d->Cin, d->Cout);
+  WT2P t2;
+  if (fast) {  // regroup tap-major with the Cout axis padded to 16: At_q[ci][(jh*JW+jw)*Cop + co]
+    memset(&t2, 0, sizeof(t2));
+    const int KK = d->KH * d->KW, Cop = pad16(d->Cout);
+    t2.W = w;
+    t2.M = d->Cin;
+    t2.C2 = d->Cout;
+    t2.C2p = Cop;
+    t2.sm = KK;
+    t2.sc = (long long)d->Cin * KK;
+    long long off = 0;
+    for (int q = 0; q < g.nphase; ++q) {
+      t2.ph[q].out = Wt + off;
+      t2.ph[q].JH = g.ph[q].JH;
+      t2.ph[q].JW = g.ph[q].JW;
+      t2.ph[q].sh = (long long)d->stride * d->KW;
+      t2.ph[q].sw = d->stride;
+      t2.ph[q].base = (long long)wt.ph[q] * d->KW + wt.pw[q];
+      t2.ph[q].total = (long long)d->Cin * g.ph[q].JH * g.ph[q].JW * Cop;
+      g.ph[q].At = Wt + off;
+      g.ph[q].C2p = Cop;
+      off += t2.ph[q].total;
+    }
+    nw = off;
+    g.fast = 1;
+  }
   float* dpad = Wt + ((nw + 63) / 64) * 64;
   g.src = gy;
   g.dst = refl ? dpad : out;
@@ -985,8 +1361,16 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
   g.DW = IW;
   g.act = refl ? HIM_ACT_NONE : act;
   g.slope = slope;
-  hipLaunchKernelGGL(wtrans_kernel, dim3(std::min<long long>(cdiv(nw, 256), 8192)), dim3(256), 0, st, wt);
-  int rc = check_launch("wtrans");
+  int rc;
+  if (fast) {
+    long long mx = 0;
+    for (int q = 0; q < g.nphase; ++q) mx = std::max(mx, t2.ph[q].total);
+    hipLaunchKernelGGL(wtrans2_kernel, dim3(std::min<long long>(cdiv(mx, 256), 4096), g.nphase), dim3(256), 0, st, t2);
+    rc = check_launch("wtrans2");
+  } else {
+    hipLaunchKernelGGL(wtrans_kernel, dim3(std::min<long long>(cdiv(nw, 256), 8192)), dim3(256), 0, st, wt);
+    rc = check_launch("wtrans");
+  }
   if (rc) return rc;
   rc = launch_gconv(g, st);
   if (rc) return rc;
@@ -1030,13 +1414,13 @@ using namespace him;
 
 extern "C" {
 
-int him_conv2d_fwd(const HimConv2d* d, const float* x, const float* w, const float* bias, float* y,
-                   void* stream) {
+size_t him_conv2d_fwd_ws(const HimConv2d* d) { return d ? fprop_ws_bytes(d) : 0; }
+
+int him_conv2d_fwd(const HimConv2d* d, const float* x, const float* w, const float* bias, float* y, void* ws,
+                   size_t ws_bytes, void* stream) {
   int rc = check_conv(d);
   if (rc) return rc;
-  GConvP g;
-  fill_fprop(g, d, x, w, bias, y);
-  return launch_gconv(g, (hipStream_t)stream);
+  return run_fprop(d, x, w, bias, y, ws, ws_bytes, (hipStream_t)stream);
 }
 
 size_t him_conv2d_bwd_data_ws(const HimConv2d* d) { return d ? dgrad_ws_bytes(d) : 0; }
@@ -1085,13 +1469,18 @@ int him_deconv2d_fwd(const HimDeconv2d* t, const float* x, const float* w, const
   return run_dgrad(&c, x, w, y, bias, t->act, t->slope, ws, ws_bytes, (hipStream_t)stream);
 }
 
-int him_deconv2d_bwd_data(const HimDeconv2d* t, const float* dy, const float* w, float* dx, void* stream) {
+size_t him_deconv2d_bwd_data_ws(const HimDeconv2d* t) {
+  HimConv2d c;
+  if (adjoint_of(t, &c)) return 0;
+  return fprop_ws_bytes(&c);
+}
+
+int him_deconv2d_bwd_data(const HimDeconv2d* t, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes,
+                          void* stream) {
   HimConv2d c;
   int rc = adjoint_of(t, &c);
   if (rc) return rc;
-  GConvP g;
-  fill_fprop(g, &c, dy, w, nullptr, dx);
-  return launch_gconv(g, (hipStream_t)stream);
+  return run_fprop(&c, dy, w, nullptr, dx, ws, ws_bytes, (hipStream_t)stream);
 }
 
 size_t him_deconv2d_bwd_weight_ws(const HimDeconv2d* t) {

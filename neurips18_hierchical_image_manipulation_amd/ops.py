@@ -75,7 +75,9 @@ class _Conv2d(torch.autograd.Function):
         _chk(x, w, b)
         d = _conv_desc(x, w, stride, pad, pad_mode, act, slope)
         y = torch.empty((d.B, d.Cout, d.OH, d.OW), dtype=torch.float32, device=x.device)
-        lib.him_conv2d_fwd(ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), _stream())
+        nb = lib.him_conv2d_fwd_ws(ctypes.byref(d))
+        ws = _ws(nb, x)
+        lib.him_conv2d_fwd(ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), _p(ws), nb, _stream())
         ctx.d = d
         ctx.x, ctx.w, ctx.b = x, w, b
         ctx.y = y if act != ACT_NONE else None
@@ -155,7 +157,9 @@ class _Deconv2d(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            lib.him_deconv2d_bwd_data(ctypes.byref(d), _p(dz), _p(w), _p(dx), st)
+            nb = lib.him_deconv2d_bwd_data_ws(ctypes.byref(d))
+            ws = _ws(nb, x)
+            lib.him_deconv2d_bwd_data(ctypes.byref(d), _p(dz), _p(w), _p(dx), _p(ws), nb, st)
         need_w = ctx.needs_input_grad[1]
         need_b = b is not None and ctx.needs_input_grad[2]
         if need_w or need_b:

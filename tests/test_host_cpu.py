@@ -32,10 +32,10 @@ def test_descriptor_validation_without_gpu():
     from neurips18_hierchical_image_manipulation_amd import _cabi
     d = _cabi.HimConv2d(1, 3, 8, 8, 4, 3, 3, 1, 1, 0, 9, 8, 0, 0.0)       # wrong OH
     with pytest.raises(_cabi.HimError, match='OH/OW'):
-        _cabi.lib.him_conv2d_fwd(ctypes.byref(d), 0, 0, 0, 0, 0)
+        _cabi.lib.him_conv2d_fwd(ctypes.byref(d), 0, 0, 0, 0, 0, 0, 0)
     d = _cabi.HimConv2d(1, 3, 8, 8, 4, 3, 3, 3, 1, 0, 3, 3, 0, 0.0)       # stride 3
     with pytest.raises(_cabi.HimError, match='stride'):
-        _cabi.lib.him_conv2d_fwd(ctypes.byref(d), 0, 0, 0, 0, 0)
+        _cabi.lib.him_conv2d_fwd(ctypes.byref(d), 0, 0, 0, 0, 0, 0, 0)
     ok = _cabi.HimConv2d(8, 1024, 16, 32, 1024, 3, 3, 1, 1, 1, 16, 32, 0, 0.0)
     assert _cabi.lib.him_conv2d_bwd_data_ws(ctypes.byref(ok)) >= 4 * (1024 * 1024 * 9 + 8 * 1024 * 18 * 34)
     with pytest.raises(_cabi.HimError, match='ws'):
