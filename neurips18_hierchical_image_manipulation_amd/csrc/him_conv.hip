@@ -120,7 +120,6 @@ __global__ __launch_bounds__(256) void gconv_fast_kernel(const GConvP p) {
   const uint32_t SHSW = (uint32_t)SH * SW;
   const uint32_t boff = (uint32_t)b * C2 * SHSW;
   const int ddy = p.dy, ddx = p.dx;
-
   // Two register sets (X, Y): tile kt+2 is in flight into one while tile kt+1 (landed an iteration ago) is written to
   // LDS from the other -> two full MFMA blocks (~4k cycles) of cover for HBM/MALL latency.
   float4 xa0, xa1, ya0, ya1;
@@ -138,7 +137,12 @@ __global__ __launch_bounds__(256) void gconv_fast_kernel(const GConvP p) {
     const uint32_t kbyte = (uint32_t)(kt_) * (BK * 4);                                                        \
     RA0 = *(const float4*)(Atb + (aoff[0] * 4u + kbyte));                                                    \
     if (A_V4 > 1) RA1 = *(const float4*)(Atb + (aoff[A_V4 - 1] * 4u + kbyte));                               \
-    int iy = by + c_jh * ddy, ix = bx + c_jw * ddx;                                                           \
+    HIM_GATHER(by, bx, RB)                                                                                   \
+  }
+  // one gather pass: tap coordinates once per K-step, then one saddr load per channel
+#define HIM_GATHER(YY, XX, RBC)                                                                        \
+  {                                                                                                          \
+    int iy = (YY) + c_jh * ddy, ix = (XX) + c_jw * ddx;                                                       \
     bool ok = true;                                                                                          \
     if (REFLECT) {                                                                                           \
       iy = iy < 0 ? -iy : iy;                                                                                \
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(256) void gconv_fast_kernel(const GConvP p) {
     _Pragma("unroll") for (int i = 0; i < KPT; ++i) {                                                        \
       asm volatile("" : "+s"(sp)); /* keep the wave-uniform base in SGPRs: saddr + 32-bit voffset load */    \
       const float v = *(gfloat_p)(sp + tapbyte);                                                             \
-      RB[i] = ok ? v : 0.f;                                                                                  \
+      RBC[i] = ok ? v : 0.f;                                                                                 \
       sp += (CLAMPC && c0 + i + 1 > C2 - 1) ? 0 : chan_bytes;                                                \
     }                                                                                                        \
   }
@@ -237,6 +241,7 @@ __global__ __launch_bounds__(256) void gconv_fast_kernel(const GConvP p) {
 #undef HIM_KSTEP
 #undef HIM_ADVANCE
 #undef HIM_LOAD_TILE
+#undef HIM_GATHER
 #undef HIM_STORE_TILE
 
 
@@ -1314,6 +1319,7 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
   if (!ws || ws_bytes < need) return fail(HIM_E_WORKSPACE, "dgrad needs %zu ws bytes, got %zu", need, ws_bytes);
   float* Wt = (float*)ws;
   const bool refl = d->pad_mode == HIM_PAD_REFLECT;
+  const bool fast = use_fast(d->Cin, d->Cout);
   GConvP g;
   memset(&g, 0, sizeof(g));
   WTransP wt;
@@ -1321,7 +1327,6 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
   wt.W = w;
   const int IH = refl ? d->H + 2 * d->pad : d->H, IW = refl ? d->W + 2 * d->pad : d->W;
   long long nw = setup_dgrad(g, wt, d->Cout, d->Cin, d->KH, d->KW, d->stride, refl ? 0 : d->pad, IH, IW, Wt);
-  const bool fast = use_fast(d->Cin, d->Cout);
   WT2P t2;
   if (fast) {  // regroup tap-major with the Cout axis padded to 16: At_q[ci][(jh*JW+jw)*Cop + co]
     memset(&t2, 0, sizeof(t2));
