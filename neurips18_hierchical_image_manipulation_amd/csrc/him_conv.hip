@@ -961,6 +961,198 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradP p) {
   }
 }
 
+// =============================================================================================
+// wgrad, fast path (C % 64 == 0, OH*OW % 4 == 0): the filter-column index runs TAP-MAJOR, n' = tap*C + ci, so a
+// 64/128-column tile is ONE filter tap x consecutive input channels: the gather coordinates (ih, iw, validity) are
+// computed once per K-step per thread and every element is one saddr global_load.  dY tiles are contiguous float4s.
+// LDS rows are [row][32 k + 4 pad] with the k <-> (lane>>5) pairing k = 16*(lane>>5) + kp (4 aligned ds_read_b128 per
+// operand tile per K-step).  Partial results go to tap-major slabs; wgrad_finish_kernel sums the split-K slabs in
+// fixed order and scatters into the reference (Cout,Cin,KH,KW) layout (+= for the gradient arena).
+// =============================================================================================
+template <int TM, int TN, bool REFLECT>
+__global__ __launch_bounds__(256) void wgrad_fast_kernel(const WGradP p) {
+  constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32, BK = 32, LD = 36;
+  constexpr int A_V4 = BM * BK / 4 / 256;  // 4 or 2
+  constexpr int RB = BN / 8;               // gathered rows per thread (16 or 8)
+  __shared__ __attribute__((aligned(16))) float sA[2][BM * LD];
+  __shared__ __attribute__((aligned(16))) float sB[2][BN * LD];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+  const int OHW = p.OH * p.OW, HW = p.H * p.W, C = p.C;
+  const int kbeg = blockIdx.z * p.kchunk;
+  const int kend = min(p.Kdim, kbeg + p.kchunk);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  // the tile's filter tap (wave-uniform) and first input channel
+  const int tap = n0 / C, ci0 = n0 - tap * C;
+  const int th = tap / p.KW, tw = tap - th * p.KW;
+  const int dh = th - p.pad, dw = tw - p.pad;
+  const int H = p.H, W = p.W, stride = p.stride;
+
+  // dY tile: thread -> (row = t/8 + 32 i, k quad = t%8)
+  const int arow = t >> 3, akq = t & 7;
+  uint32_t arowoff[A_V4];
+#pragma unroll
+  for (int i = 0; i < A_V4; ++i) arowoff[i] = (uint32_t)min(m0 + arow + 32 * i, p.M - 1) * (uint32_t)OHW;
+  // gathered tile: thread -> (k = t%32, row group rg = t/32; rows rg + 8 i)
+  const int kkl = t & 31, rg = t >> 5;
+
+  const char* __restrict__ dyc = (const char*)p.dy;
+  gchar_p xbase = (gchar_p)p.x + (size_t)(ci0) * HW * 4;
+  const size_t step8 = (size_t)8 * HW * 4;
+
+  float4 ra[A_V4];
+  float rb[RB];
+  // per-thread cursors of the NEXT tile: A quad position and gather position, as (image, offset in image)
+  int ka = kbeg + akq * 4, ba = ka / OHW, spa = ka - ba * OHW;
+  int kb = kbeg + kkl, bb = kb / OHW, spb = kb - bb * OHW;
+
+#define HIM_WLOAD()                                                                                           \
+  {                                                                                                           \
+    const bool av = ka < kend;                                                                                \
+    const uint32_t abase = av ? ((uint32_t)ba * (uint32_t)p.M * (uint32_t)OHW + (uint32_t)spa) : 0u;            \
+    _Pragma("unroll") for (int i = 0; i < A_V4; ++i) {                                                        \
+      const float4 v = *(const float4*)(dyc + (size_t)(abase + arowoff[i]) * 4);                              \
+      ra[i] = av ? v : make_float4(0.f, 0.f, 0.f, 0.f);                                                       \
+    }                                                                                                         \
+    const bool bv = kb < kend;                                                                                \
+    const int sp = bv ? spb : 0;                                                                              \
+    const int oh = (int)fdiv((uint32_t)sp, p.fOW);                                                            \
+    const int ow = sp - oh * p.OW;                                                                            \
+    int ih = oh * stride + dh, iw = ow * stride + dw;                                                         \
+    bool ok = true;                                                                                           \
+    if (REFLECT) {                                                                                            \
+      ih = ih < 0 ? -ih : ih;                                                                                 \
+      ih = ih >= H ? 2 * (H - 1) - ih : ih;                                                                   \
+      iw = iw < 0 ? -iw : iw;                                                                                 \
+      iw = iw >= W ? 2 * (W - 1) - iw : iw;                                                                   \
+    } else {                                                                                                  \
+      const int ch = min(max(ih, 0), H - 1), cw = min(max(iw, 0), W - 1);                                     \
+      ok = (ch == ih) && (cw == iw);                                                                          \
+      ih = ch;                                                                                                \
+      iw = cw;                                                                                                \
+    }                                                                                                         \
+    const uint32_t voff = ((uint32_t)(bv ? bb : 0) * (uint32_t)C * (uint32_t)HW + (uint32_t)rg * (uint32_t)HW + \
+                           (uint32_t)ih * (uint32_t)W + (uint32_t)iw) * 4u;                                    \
+    gchar_p sp8 = xbase;                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < RB; ++i) {                                                          \
+      asm volatile("" : "+s"(sp8));                                                                           \
+      const float v = *(gfloat_p)(sp8 + voff);                                                                \
+      rb[i] = ok ? v : 0.f; /* A is zero beyond kend, so bv needs no select here */                           \
+      sp8 += step8;                                                                                           \
+    }                                                                                                         \
+    ka += BK;                                                                                                 \
+    spa += BK;                                                                                                \
+    while (spa >= OHW) {                                                                                      \
+      spa -= OHW;                                                                                             \
+      ++ba;                                                                                                   \
+    }                                                                                                         \
+    kb += BK;                                                                                                 \
+    spb += BK;                                                                                                \
+    while (spb >= OHW) {                                                                                      \
+      spb -= OHW;                                                                                             \
+      ++bb;                                                                                                   \
+    }                                                                                                         \
+  }
+#define HIM_WSTORE(buf_)                                                                                       \
+  {                                                                                                           \
+    _Pragma("unroll") for (int i = 0; i < A_V4; ++i) *(float4*)&sA[buf_][(arow + 32 * i) * LD + akq * 4] = ra[i]; \
+    _Pragma("unroll") for (int i = 0; i < RB; ++i) sB[buf_][(rg + 8 * i) * LD + kkl] = rb[i];                 \
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  if (nk > 0) {
+    HIM_WLOAD()
+    HIM_WSTORE(0)
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    const float4* __restrict__ pa = (const float4*)&sA[buf][(wm * TM * 32 + l31) * LD + lh * 16];
+    const float4* __restrict__ pb = (const float4*)&sB[buf][(wn * TN * 32 + l31) * LD + lh * 16];
+    float4 af[TM][4], bf[TN][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) af[i][q] = pa[i * 32 * LD / 4 + q];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bf[j][q] = pb[j * 32 * LD / 4 + q];
+    HIM_WLOAD()  // past the end: both operands' validity is false -> zeros, addresses clamped to element 0
+#define HIM_WM(Q, CMP)                                                                                         \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] =    \
+      __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][Q].CMP, bf[j][Q].CMP, acc[i][j], 0, 0, 0);
+    HIM_WM(0, x) HIM_WM(0, y) HIM_WM(0, z) HIM_WM(0, w)
+    HIM_WM(1, x) HIM_WM(1, y) HIM_WM(1, z) HIM_WM(1, w)
+    HIM_WM(2, x) HIM_WM(2, y) HIM_WM(2, z) HIM_WM(2, w)
+    HIM_WM(3, x) HIM_WM(3, y) HIM_WM(3, z) HIM_WM(3, w)
+#undef HIM_WM
+    HIM_WSTORE(buf ^ 1)
+    __syncthreads();
+  }
+#undef HIM_WLOAD
+#undef HIM_WSTORE
+
+  // tap-major slab: out[z][m][n']
+  float* __restrict__ out = p.out + (size_t)blockIdx.z * p.M * p.Np;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int np = n0 + wn * TN * 32 + j * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < p.M) out[(size_t)m * p.Np + np] = acc[i][j][r];
+      }
+    }
+  }
+}
+
+// dW[m][ci][tap] (+)= sum_z slab[z][m][tap*C + ci]   (fixed summation order; coalesced on the dW side)
+__global__ void wgrad_finish_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int M, int C, int KK,
+                                    int splits, int accumulate) {
+  const long long n = (long long)M * C * KK;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % KK);
+    const long long r = i / KK;
+    const int ci = (int)(r % C);
+    const long long m = r / C;
+    const size_t src = (size_t)m * C * KK + (size_t)tap * C + ci;
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += slabs[(size_t)z * n + src];
+    dw[i] = accumulate ? dw[i] + s : s;
+  }
+}
+
+static bool wgrad_fast_ok(int M, int C, int OH, int OW) {
+  static int force_generic = -1;
+  if (force_generic < 0) force_generic = getenv("HIM_GENERIC_CONV") ? 1 : 0;
+  return !force_generic && M > 4 && (C % 64) == 0 && ((OH * OW) % 4) == 0;
+}
+static void wgrad_fast_cfg(int M, int C, int Kdim, int KK, int* BM, int* BN, int* splits) {
+  *BM = M > 64 ? 128 : 64;
+  *BN = (C % 128) == 0 ? 128 : 64;
+  const long long tiles = (long long)cdiv(M, *BM) * ((long long)C * KK / *BN);
+  int s = (int)((768 + tiles - 1) / tiles);
+  const int maxs = cdiv(Kdim, 32 * 8);
+  if (s > maxs) s = maxs;
+  if (s < 1) s = 1;
+  if (s > 256) s = 256;
+  *splits = s;
+}
+
 // ---- tiny-M weight gradient (M = Cout <= 4: the G tanh head).  Direct VALU reduction: one workgroup per
 // (input channel, slice of the B*OH*OW positions); every thread keeps the MM x TJ x TJ partial filter in
 // registers, then a wave64-shuffle + LDS reduction writes one slab per slice (summed in fixed order later).
@@ -1107,6 +1299,15 @@ static size_t wgrad_slab_bytes(int M, int C, int KH, int KW, int Kdim) {
   size_t slabs;
   if (small_wgrad_ok(M, KH, KW)) {
     slabs = (size_t)small_wgrad_slices(C, Kdim) * M * Np * sizeof(float);
+  } else if (wgrad_fast_ok(M, C, 1, 4) && Kdim % 4 == 0) {  /* upper bound; the runner re-checks OH*OW */
+    int BM, BN, sp;
+    wgrad_fast_cfg(M, C, Kdim, KH * KW, &BM, &BN, &sp);
+    slabs = (size_t)sp * M * Np * sizeof(float);
+    int BM2, BN2;
+    wgrad_tile(M, &BM2, &BN2);
+    const int s2 = wgrad_splits(M, Np, Kdim, BM2, BN2);
+    const size_t alt = s2 > 1 ? (size_t)s2 * M * Np * sizeof(float) : 0;
+    if (alt > slabs) slabs = alt;
   } else {
     int BM, BN;
     wgrad_tile(M, &BM, &BN);
@@ -1168,6 +1369,35 @@ static int run_wgrad(const float* dy, const float* x, float* dw, int M, int C, i
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(std::min<long long>(cdiv(n, 256), 4096)), dim3(256), 0, st,
                        (const float*)ws, dw, n, slices, accumulate);
     return check_launch("slab_reduce");
+  }
+  if (wgrad_fast_ok(M, C, OH, OW)) {
+    int fBM, fBN, fs;
+    wgrad_fast_cfg(M, C, p.Kdim, KH * KW, &fBM, &fBN, &fs);
+    const size_t need = (size_t)fs * M * p.Np * sizeof(float);
+    if (ws_bytes < need || !ws) return fail(HIM_E_WORKSPACE, "wgrad needs %zu ws bytes, got %zu", need, ws_bytes);
+    p.splits = fs;
+    p.accumulate = 0;
+    int kc = cdiv(p.Kdim, fs);
+    p.kchunk = ((kc + 31) / 32) * 32;
+    p.out = (float*)ws;
+    dim3 grid(p.Np / fBN, cdiv(M, fBM), fs), block(256);
+    const bool refl = pad_mode == HIM_PAD_REFLECT;
+#define HIM_WF(TMv, TNv)                                                                      \
+  {                                                                                           \
+    if (refl) hipLaunchKernelGGL((wgrad_fast_kernel<TMv, TNv, true>), grid, block, 0, st, p);  \
+    else hipLaunchKernelGGL((wgrad_fast_kernel<TMv, TNv, false>), grid, block, 0, st, p);      \
+  }
+    if (fBM == 128 && fBN == 128) HIM_WF(2, 2)
+    else if (fBM == 128) HIM_WF(2, 1)
+    else if (fBN == 128) HIM_WF(1, 2)
+    else HIM_WF(1, 1)
+#undef HIM_WF
+    int rc0 = check_launch("wgrad_fast");
+    if (rc0) return rc0;
+    const long long n = (long long)M * p.Np;
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(std::min<long long>(cdiv(n, 256), 8192)), dim3(256), 0, st,
+                       (const float*)ws, dw, M, C, KH * KW, fs, accumulate);
+    return check_launch("wgrad_finish");
   }
   int BM, BN;
   wgrad_tile(M, &BM, &BN);
