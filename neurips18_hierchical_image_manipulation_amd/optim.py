@@ -74,6 +74,16 @@ class FusedAdam(object):
                           a.total, float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
                           self.step_count, _stream())
 
+    def load_moments(self, exp_avgs, exp_avg_sqs, step):
+        """Adopt per-parameter Adam moments (e.g. from a torch.optim.Adam) -- used by checkpoint import and by the
+        teacher-forced parity tests."""
+        a = self.arena
+        for p, o, m, v in zip(a.params, a.offsets, exp_avgs, exp_avg_sqs):
+            n = p.numel()
+            self.exp_avg[o:o + n].copy_(m.reshape(-1))
+            self.exp_avg_sq[o:o + n].copy_(v.reshape(-1))
+        self.step_count = int(step)
+
     def state_dict(self):
         return dict(step=self.step_count, exp_avg=self.exp_avg.cpu(), exp_avg_sq=self.exp_avg_sq.cpu(),
                     param_groups=[{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups])

@@ -1,0 +1,65 @@
+"""How far does the REFERENCE algorithm drift from ITSELF when only the fp32 summation order changes?
+
+Runs the CPU oracle (bit-identical to the reference, see make_golden.py) with a different OpenMP thread count
+(= different reduction order inside oneDNN) and compares the 20-step loss trajectory with the golden one that was
+generated with 8 threads.  The resulting envelope (tests/golden/chaos_envelope.json) is the yard-stick for the
+free-running HIP trajectories: GAN training with Adam amplifies 1e-7 rounding differences by ~10x per step, so no
+implementation with a different summation order -- including the reference on another core count -- can hold
+1e-3 over 20 free-running steps.  Per-step parity is therefore asserted with teacher forcing (test_model_gpu.py).
+
+    python tests/golden/chaos_envelope.py        # build container only (needs ~3 min)
+"""
+import json
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, '..', '..'))
+
+WORKER = r'''
+import sys, json, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from oracle import ref_cpu
+from neurips18_hierchical_image_manipulation_amd import synth
+tag, threads, pert = sys.argv[1], int(sys.argv[2]), float(sys.argv[3])
+torch.set_num_threads(threads)
+g = np.load(%r + '/' + tag + '.npz'); flags = json.loads(str(g['flags']))
+B, H, W = int(g['B']), int(g['H']), int(g['W'])
+om = ref_cpu.Mask2ImageModel(ref_cpu.Opt(**flags))
+om.netG.load_state_dict(synth.init_state_dict(om.netG.state_dict(), 1))
+om.netD.load_state_dict(synth.init_state_dict(om.netD.state_dict(), 2))
+om.vgg.load_state_dict(synth.init_state_dict(om.vgg.state_dict(), 3, 'vgg'))
+if pert:
+    gen = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        for p in list(om.netG.parameters()) + list(om.netD.parameters()):
+            p.mul_(1 + pert * torch.randn(p.shape, generator=gen))
+rel = []
+for s in range(g['losses'].shape[0]):
+    ld = om.optimize_parameters(synth.make_batch(s, 0, B, H, W, flags.get('label_nc', 35)))
+    got = np.array([ld[k] for k in ref_cpu.Mask2ImageModel.loss_names]); ref = g['losses'][s].astype(np.float64)
+    rel.append(float((np.abs(got - ref) / np.abs(ref)).max()))
+print('RESULT ' + json.dumps(rel))
+''' % (ROOT, os.path.join(ROOT, 'tests'), HERE)
+
+
+def run(tag, threads, pert=0.0):
+    out = subprocess.run([sys.executable, '-c', WORKER, tag, str(threads), str(pert)], stdout=subprocess.PIPE,
+                         stderr=subprocess.DEVNULL, text=True, check=True).stdout
+    line = [l for l in out.splitlines() if l.startswith('RESULT ')][-1]
+    return json.loads(line[7:])
+
+
+if __name__ == '__main__':
+    res = {
+        'note': 'max over the 5 losses of |loss - golden| / |golden| per step; golden = reference on 8 threads',
+        'tiny_global_threads1_vs_8': run('tiny_global', 1),
+        'tiny_global_weights_perturbed_1e-7': run('tiny_global', 8, 1e-7),
+        'c1_threads4_vs_8': run('c1_traj', 4),
+    }
+    with open(os.path.join(HERE, 'chaos_envelope.json'), 'w') as f:
+        json.dump(res, f, indent=1)
+    for k, v in res.items():
+        if k != 'note':
+            print(k, ' '.join('%.1e' % x for x in v))
