@@ -55,6 +55,8 @@ struct GConvP {
   float slope;
   int nphase;
   int fast;  // 1: ph[].At valid -> gconv_fast_kernel
+  float* small_part;  // tiny-M path: [nsplit][M][Ntot] partial sums when the channels are split over grid.y
+  int small_nsplit;
   GPhase ph[4];
 };
 
@@ -504,7 +506,8 @@ __global__ __launch_bounds__(256) void gconv_small_kernel(const GConvP p) {
   const GPhase& ph = p.ph[blockIdx.z];
   const int plane = ph.NA * ph.NC;
   const int Ntot = p.B * plane;
-  const int cs = threadIdx.x / NPB;
+  // wave-uniform channel slice (NPB is a multiple of 64): keeps the weight reads on the scalar unit
+  const int cs = CS > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x / NPB) : 0;
   const int n = blockIdx.x * NPB + threadIdx.x % NPB;
   if (blockIdx.x * NPB >= Ntot) return;
   const int nc = min(n, Ntot - 1);
@@ -553,21 +556,28 @@ __global__ __launch_bounds__(256) void gconv_small_kernel(const GConvP p) {
       iy = cy;
     }
     const float* __restrict__ row = src + (size_t)iy * SW;
-    const int cbeg = CS > 1 ? cs * ((C2 + CS - 1) / CS) : 0;
-    const int cend = CS > 1 ? min(C2, cbeg + (C2 + CS - 1) / CS) : C2;
+    // channel range of this thread: grid.y slices (partials summed by gconv_small_finish_kernel) x CS in-block slices
+    const int nsl = gridDim.y * CS, sl = blockIdx.y * CS + cs;
+    const int cchunk = (C2 + nsl - 1) / nsl;
+    const int cbeg = sl * cchunk, cend = min(C2, cbeg + cchunk);
+#define HIM_SMALL_BODY()                                                                      \
+  {                                                                                           \
+    const float* __restrict__ r = row + (size_t)c2 * SH * SW;                                 \
+    const int kb = (c2 * JH + jh) * JW;                                                       \
+    _Pragma("unroll") for (int j = 0; j < MAXJ; ++j) {                                        \
+      if (TJ == 0 && j >= JW) break;                                                          \
+      float v = r[ixs[j]];                                                                    \
+      v = (oky && okx[j]) ? v : 0.f;                                                          \
+      _Pragma("unroll") for (int m = 0; m < MM; ++m) acc[m] = fmaf(A[(size_t)m * K + kb + j], v, acc[m]); \
+    }                                                                                         \
+  }
+    if (TJ > 0 && TJ <= 4) {  // short tap rows: keep 4 channels of loads in flight
 #pragma unroll 4
-    for (int c2 = cbeg; c2 < cend; ++c2) {
-      const float* __restrict__ r = row + (size_t)c2 * SH * SW;
-      const int kb = (c2 * JH + jh) * JW;
-#pragma unroll
-      for (int j = 0; j < MAXJ; ++j) {
-        if (TJ == 0 && j >= JW) break;
-        float v = r[ixs[j]];
-        v = (oky && okx[j]) ? v : 0.f;
-#pragma unroll
-        for (int m = 0; m < MM; ++m) acc[m] = fmaf(A[(size_t)m * K + kb + j], v, acc[m]);
-      }
+      for (int c2 = cbeg; c2 < cend; ++c2) HIM_SMALL_BODY()
+    } else {
+      for (int c2 = cbeg; c2 < cend; ++c2) HIM_SMALL_BODY()
     }
+#undef HIM_SMALL_BODY
   }
   if (CS > 1) {
 #pragma unroll
@@ -583,6 +593,11 @@ __global__ __launch_bounds__(256) void gconv_small_kernel(const GConvP p) {
     }
   }
   if (n < Ntot) {
+    if (gridDim.y > 1) {
+#pragma unroll
+      for (int m = 0; m < MM; ++m) p.small_part[((size_t)blockIdx.y * MM + m) * Ntot + n] = acc[m];
+      return;
+    }
     const int oy = ph.oy0 + p.oys * a, ox = ph.ox0 + p.oxs * c;
     float* __restrict__ out = p.dst + ((size_t)b * p.M * p.DH + oy) * p.DW + ox;
 #pragma unroll
@@ -594,11 +609,29 @@ __global__ __launch_bounds__(256) void gconv_small_kernel(const GConvP p) {
   }
 }
 
+// sums the channel-slice partials in fixed order, adds bias, applies the activation (single-phase launches only)
+__global__ void gconv_small_finish_kernel(const GConvP p) {
+  const GPhase& ph = p.ph[0];
+  const int plane = ph.NA * ph.NC;
+  const int Ntot = p.B * plane;
+  const long long total = (long long)p.M * Ntot;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int m = (int)(i / Ntot), n = (int)(i - (long long)m * Ntot);
+    float v = 0.f;
+    for (int z = 0; z < p.small_nsplit; ++z) v += p.small_part[((size_t)z * p.M + m) * Ntot + n];
+    if (p.bias) v += p.bias[m];
+    const int b = n / plane, rr = n - b * plane, a = rr / ph.NC, c = rr - a * ph.NC;
+    const int oy = ph.oy0 + p.oys * a, ox = ph.ox0 + p.oxs * c;
+    p.dst[(((size_t)b * p.M + m) * p.DH + oy) * p.DW + ox] = apply_act(v, p.act, p.slope);
+  }
+}
+
 template <int MM, int TJ>
 static void launch_small_cfg(const GConvP& p, long long maxN, hipStream_t st) {
   const bool split = maxN < 256 * 512 && p.C2 >= 64;  // too few positions to fill 256 CUs: split the channels
   if (split) {
-    dim3 grid(cdiv(maxN, 64), 1, p.nphase);
+    dim3 grid(cdiv(maxN, 64), p.small_nsplit > 1 ? p.small_nsplit : 1, p.nphase);
     if (p.pad_mode == HIM_PAD_REFLECT)
       hipLaunchKernelGGL((gconv_small_kernel<MM, TJ, true, 4>), grid, dim3(256), 0, st, p);
     else
@@ -634,6 +667,10 @@ static bool launch_gconv_small(const GConvP& p, long long maxN, hipStream_t st) 
     HIM_SMALL(4)
   }
 #undef HIM_SMALL
+  if (p.small_nsplit > 1 && maxN < 256 * 512 && p.C2 >= 64) {
+    const long long total = (long long)p.M * maxN;
+    hipLaunchKernelGGL(gconv_small_finish_kernel, dim3(std::min<long long>(cdiv(total, 256), 4096)), dim3(256), 0, st, p);
+  }
   return true;
 }
 
@@ -661,7 +698,7 @@ static int launch_gconv(const GConvP& p, hipStream_t st) {
       launch_fast_cfg<2, 2, 1, 2>(p, grid, st);
     } else {
       const long long tiles128 = (long long)cdiv(maxN, 128) * cdiv(p.M, 128) * p.nphase;
-      const bool big = tile_override >= 0 ? tile_override == 1 : tiles128 >= 200;
+      const bool big = tile_override >= 0 ? tile_override == 1 : (tiles128 >= 512 || (tiles128 >= 200 && tiles128 <= 256));
       if (big) {
         dim3 grid(cdiv(maxN, 128) * cdiv(p.M, 128), 1, p.nphase);
         launch_fast_cfg<2, 2, 2, 2>(p, grid, st);
@@ -1506,7 +1543,12 @@ static void fill_fprop(GConvP& g, const HimConv2d* d, const float* x, const floa
   P.offy = P.offx = -d->pad;
 }
 
+static const int SMALL_NSPLIT = 8;
+static bool small_split_ok(const HimConv2d* d) {
+  return d->Cout <= 4 && d->Cin >= 256 && (long long)d->B * d->OH * d->OW < 256 * 512;
+}
 static size_t fprop_ws_bytes(const HimConv2d* d) {
+  if (small_split_ok(d)) return (size_t)SMALL_NSPLIT * d->Cout * d->B * d->OH * d->OW * sizeof(float) + 256;
   if (!use_fast(d->Cout, d->Cin)) return 0;
   return (size_t)d->Cout * d->KH * d->KW * pad16(d->Cin) * sizeof(float) + 256;
 }
@@ -1514,6 +1556,11 @@ static int run_fprop(const HimConv2d* d, const float* x, const float* w, const f
                      size_t ws_bytes, hipStream_t st) {
   GConvP g;
   fill_fprop(g, d, x, w, bias, y);
+  if (small_split_ok(d)) {
+    if (!ws || ws_bytes < fprop_ws_bytes(d)) return fail(HIM_E_WORKSPACE, "conv fwd ws too small");
+    g.small_part = (float*)ws;
+    g.small_nsplit = SMALL_NSPLIT;
+  }
   if (use_fast(d->Cout, d->Cin)) {
     const size_t need = fprop_ws_bytes(d);
     if (!ws || ws_bytes < need) return fail(HIM_E_WORKSPACE, "conv fwd needs %zu ws bytes, got %zu", need, ws_bytes);
