@@ -55,6 +55,8 @@ struct GConvP {
   float slope;
   int nphase;
   int fast;  // 1: ph[].At valid -> gconv_fast_kernel
+  float* kpart;       // fast path split-K: [ksplit] slabs shaped like dst (raw sums; bias/act in gconv_splitk_finish)
+  int ksplit;
   float* small_part;  // tiny-M path: [nsplit][M][Ntot] partial sums when the channels are split over grid.y
   int small_nsplit;
   GPhase ph[4];
@@ -69,11 +71,13 @@ struct GConvP {
 // dwords), and the tile writes are ds_write_b128 as well.  ~2 non-MFMA instructions per MFMA instead of ~19.
 // =============================================================================================
 template <int WM, int WN, int TM, int TN, bool REFLECT, bool CLAMPC>
-__global__ __launch_bounds__(256) void gconv_fast_kernel(const GConvP p) {
+__global__ __launch_bounds__(WM * WN * 64) void gconv_fast_kernel(const GConvP p) {
+  constexpr int NT = WM * WN * 64;  // 4 waves (one per SIMD) or 8 waves (two per SIMD: they cover each other's LDS/barrier bubbles)
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 16, LD = 20;
-  constexpr int A_V4 = BM * BK / 4 / 256;  // float4 loads per thread for the weight tile
-  constexpr int KPT = BK * BN / 256;       // consecutive channels per thread in the gathered tile (8 or 4)
-  static_assert(WM * WN == 4, "4 waves");
+  constexpr int A_V4 = BM * BK / 4 / NT;  // float4 loads per thread for the weight tile
+  constexpr int AROWS = NT / 4;           // weight-tile rows covered per pass
+  constexpr int KPT = BK * BN / NT;       // consecutive channels per thread in the gathered tile (8 or 4)
+  static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
   static_assert((A_V4 == 1 || A_V4 == 2) && (KPT == 4 || KPT == 8), "tile shape");
   __shared__ __attribute__((aligned(16))) float sA[2][BM * LD];
   __shared__ __attribute__((aligned(16))) float sB[2][BN * LD];
@@ -100,14 +104,19 @@ __global__ __launch_bounds__(256) void gconv_fast_kernel(const GConvP p) {
   const float* __restrict__ src = p.src;
   const int C2 = p.C2, C2p = ph.C2p, CB = C2p / BK;
   const int JW = ph.JW, JH = ph.JH;
-  const int nk = JH * JW * CB;
-  const uint32_t Kp = (uint32_t)nk * BK;
+  const int nk_all = JH * JW * CB;
+  const uint32_t Kp = (uint32_t)nk_all * BK;
+  // split-K (grid.y): this workgroup reduces K-steps [kt0, kt0 + nk); two half-K workgroups per CU run out of phase
+  // and cover each other's LDS/barrier bubbles when the launch has only ~one output tile per CU
+  const int ksplit = gridDim.y;
+  const int kt0 = (int)(((long long)nk_all * blockIdx.y) / ksplit);
+  const int nk = (int)(((long long)nk_all * (blockIdx.y + 1)) / ksplit) - kt0;
 
-  // weight tile: thread -> (row = t/4 + 64 i, k quad = t%4)
+  // weight tile: thread -> (row = t/4 + AROWS i, k quad = t%4)
   const int arow = t >> 2, akq = t & 3;
   uint32_t aoff[A_V4];
 #pragma unroll
-  for (int i = 0; i < A_V4; ++i) aoff[i] = (uint32_t)min(m0 + arow + i * 64, p.M - 1) * Kp + akq * 4;
+  for (int i = 0; i < A_V4; ++i) aoff[i] = (uint32_t)min(m0 + arow + i * AROWS, p.M - 1) * Kp + akq * 4;
 
   // gathered tile: thread -> (column nl, channel group kg)
   const int nl = t % BN;
@@ -127,8 +136,11 @@ __global__ __launch_bounds__(256) void gconv_fast_kernel(const GConvP p) {
   float4 xa0, xa1, ya0, ya1;
   float xb[KPT], yb[KPT];
   xa1 = ya1 = make_float4(0.f, 0.f, 0.f, 0.f);
-  int c_cb = 0, c_jh = 0, c_jw = 0;  // wave-uniform cursor of the tile being loaded: (tap row, tap col, channel block)
-  const char* __restrict__ Atb = (const char*)At;
+  // wave-uniform cursor of the tile being loaded: (channel block, tap row, tap col), starting at K-step kt0
+  int c_cb = kt0 / (JH * JW);
+  int c_jh = (kt0 - c_cb * JH * JW) / JW;
+  int c_jw = kt0 - c_cb * JH * JW - c_jh * JW;
+  const char* __restrict__ Atb = (const char*)At + (size_t)kt0 * (BK * 4);
   const char* __restrict__ srcb = (const char*)src;
   const size_t chan_bytes = (size_t)SHSW * 4;
 
@@ -170,7 +182,7 @@ __global__ __launch_bounds__(256) void gconv_fast_kernel(const GConvP p) {
 #define HIM_STORE_TILE(buf_, RA0, RA1, RB)                                                                    \
   {                                                                                                          \
     *(float4*)&sA[buf_][arow * LD + akq * 4] = RA0;                                                          \
-    if (A_V4 > 1) *(float4*)&sA[buf_][(arow + 64) * LD + akq * 4] = RA1;                                     \
+    if (A_V4 > 1) *(float4*)&sA[buf_][(arow + AROWS) * LD + akq * 4] = RA1;                                  \
     _Pragma("unroll") for (int q = 0; q < KPT / 4; ++q) *(float4*)&sB[buf_][nl * LD + kg * KPT + q * 4] =     \
         make_float4(RB[q * 4], RB[q * 4 + 1], RB[q * 4 + 2], RB[q * 4 + 3]);                                 \
   }
@@ -252,6 +264,8 @@ __global__ __launch_bounds__(256) void gconv_fast_kernel(const GConvP p) {
 
   const int act = p.act;
   const float slope = p.slope;
+  const bool partial = ksplit > 1;
+  float* __restrict__ dstbase = partial ? p.kpart + (size_t)blockIdx.y * p.B * p.M * p.DH * p.DW : p.dst;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int nn = n0 + wn * TN * 32 + j * 32 + l31;
@@ -260,7 +274,7 @@ __global__ __launch_bounds__(256) void gconv_fast_kernel(const GConvP p) {
     const int r2 = nn - bb * plane;
     const int aa = r2 / ph.NC, cc = r2 - aa * ph.NC;
     const int oy = ph.oy0 + p.oys * aa, ox = ph.ox0 + p.oxs * cc;
-    float* __restrict__ out = p.dst + ((size_t)bb * p.M * p.DH + oy) * p.DW + ox;
+    float* __restrict__ out = dstbase + ((size_t)bb * p.M * p.DH + oy) * p.DW + ox;
     const size_t mstride = (size_t)p.DH * p.DW;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -269,23 +283,40 @@ __global__ __launch_bounds__(256) void gconv_fast_kernel(const GConvP p) {
         const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (m < p.M) {
           float v = acc[i][j][r];
-          if (p.bias) v += p.bias[m];
-          out[(size_t)m * mstride] = apply_act(v, act, slope);
+          if (!partial) {
+            if (p.bias) v += p.bias[m];
+            v = apply_act(v, act, slope);
+          }
+          out[(size_t)m * mstride] = v;
         }
       }
     }
   }
 }
 
+// dst = act(sum_z kpart[z] + bias[channel])  (fixed order), float4 streams
+__global__ void gconv_splitk_finish_kernel(const float* __restrict__ part, float* __restrict__ dst,
+                                           const float* __restrict__ bias, long long n, int ksplit, int M, int plane,
+                                           int act, float slope) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    for (int z = 0; z < ksplit; ++z) v += part[(size_t)z * n + i];
+    if (bias) v += bias[(int)((i / plane) % M)];
+    dst[i] = apply_act(v, act, slope);
+  }
+}
+
 template <int WM, int WN, int TM, int TN>
 static void launch_fast_cfg(const GConvP& p, dim3 grid, hipStream_t st) {
   const bool clampc = (p.C2 % 16) != 0;
+  const dim3 blk(WM * WN * 64);
   if (p.pad_mode == HIM_PAD_REFLECT) {
-    if (clampc) hipLaunchKernelGGL((gconv_fast_kernel<WM, WN, TM, TN, true, true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((gconv_fast_kernel<WM, WN, TM, TN, true, false>), grid, dim3(256), 0, st, p);
+    if (clampc) hipLaunchKernelGGL((gconv_fast_kernel<WM, WN, TM, TN, true, true>), grid, blk, 0, st, p);
+    else hipLaunchKernelGGL((gconv_fast_kernel<WM, WN, TM, TN, true, false>), grid, blk, 0, st, p);
   } else {
-    if (clampc) hipLaunchKernelGGL((gconv_fast_kernel<WM, WN, TM, TN, false, true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((gconv_fast_kernel<WM, WN, TM, TN, false, false>), grid, dim3(256), 0, st, p);
+    if (clampc) hipLaunchKernelGGL((gconv_fast_kernel<WM, WN, TM, TN, false, true>), grid, blk, 0, st, p);
+    else hipLaunchKernelGGL((gconv_fast_kernel<WM, WN, TM, TN, false, false>), grid, blk, 0, st, p);
   }
 }
 
@@ -693,21 +724,30 @@ static int launch_gconv(const GConvP& p, hipStream_t st) {
   if (p.fast) {
     static int tile_override = -2;
     if (tile_override == -2) tile_override = getenv("HIM_GCONV_TILE") ? atoi(getenv("HIM_GCONV_TILE")) : -1;
+    const int ks = p.ksplit > 1 ? p.ksplit : 1;
     if (p.M <= 64) {
-      dim3 grid(cdiv(maxN, 128) * cdiv(p.M, 64), 1, p.nphase);
+      dim3 grid(cdiv(maxN, 128) * cdiv(p.M, 64), ks, p.nphase);
       launch_fast_cfg<2, 2, 1, 2>(p, grid, st);
     } else {
       const long long tiles128 = (long long)cdiv(maxN, 128) * cdiv(p.M, 128) * p.nphase;
       const bool big = tile_override >= 0 ? tile_override == 1 : (tiles128 >= 512 || (tiles128 >= 200 && tiles128 <= 256));
-      if (big) {
-        dim3 grid(cdiv(maxN, 128) * cdiv(p.M, 128), 1, p.nphase);
+      if (tile_override == 2) {
+        dim3 grid(cdiv(maxN, 128) * cdiv(p.M, 128), ks, p.nphase);
+        launch_fast_cfg<2, 4, 2, 1>(p, grid, st);  // 8 waves per 128x128 tile (measured: lockstep, no better than 4)
+      } else if (big || ks > 1) {
+        dim3 grid(cdiv(maxN, 128) * cdiv(p.M, 128), ks, p.nphase);
         launch_fast_cfg<2, 2, 2, 2>(p, grid, st);
       } else {
-        dim3 grid(cdiv(maxN, 64) * cdiv(p.M, 128), 1, p.nphase);
+        dim3 grid(cdiv(maxN, 64) * cdiv(p.M, 128), ks, p.nphase);
         launch_fast_cfg<2, 2, 2, 1>(p, grid, st);
       }
     }
-    return check_launch("gconv_fast");
+    int rcf = check_launch("gconv_fast");
+    if (rcf || ks == 1) return rcf;
+    const long long n = (long long)p.B * p.M * p.DH * p.DW;
+    hipLaunchKernelGGL(gconv_splitk_finish_kernel, dim3(std::min<long long>(cdiv(n, 256), 8192)), dim3(256), 0, st,
+                       (const float*)p.kpart, p.dst, p.bias, n, ks, p.M, p.DH * p.DW, p.act, p.slope);
+    return check_launch("gconv_splitk_finish");
   }
   if (p.M <= 32) {
     dim3 grid(cdiv(maxN, 256), cdiv(p.M, 32), p.nphase);
@@ -1547,10 +1587,25 @@ static const int SMALL_NSPLIT = 8;
 static bool small_split_ok(const HimConv2d* d) {
   return d->Cout <= 4 && d->Cin >= 256 && (long long)d->B * d->OH * d->OW < 256 * 512;
 }
+// split-K factor of a single-phase fast launch: aim at >= 2 workgroups per CU when the output has few tiles
+static int fast_ksplit(int M, long long N, int nk) {
+  static int off = -1;
+  if (off < 0) off = getenv("HIM_NO_SPLITK") ? 1 : 0;
+  if (off) return 1;
+  const long long tiles = (M <= 64 ? (long long)cdiv(N, 128) * cdiv(M, 64) : (long long)cdiv(N, 128) * cdiv(M, 128));
+  if (tiles > 256) return 1;
+  int ks = (int)((512 + tiles - 1) / tiles);
+  const int maxs = nk / 48;  // keep >= 48 K-steps per workgroup
+  if (ks > maxs) ks = maxs;
+  if (ks > 16) ks = 16;
+  return ks < 1 ? 1 : ks;
+}
 static size_t fprop_ws_bytes(const HimConv2d* d) {
   if (small_split_ok(d)) return (size_t)SMALL_NSPLIT * d->Cout * d->B * d->OH * d->OW * sizeof(float) + 256;
   if (!use_fast(d->Cout, d->Cin)) return 0;
-  return (size_t)d->Cout * d->KH * d->KW * pad16(d->Cin) * sizeof(float) + 256;
+  const int ks = fast_ksplit(d->Cout, (long long)d->B * d->OH * d->OW, d->KH * d->KW * (pad16(d->Cin) / 16));
+  const size_t wts = ((size_t)d->Cout * d->KH * d->KW * pad16(d->Cin) * sizeof(float) + 255) / 256 * 256;
+  return wts + (ks > 1 ? (size_t)ks * d->B * d->Cout * d->OH * d->OW * sizeof(float) : 0) + 256;
 }
 static int run_fprop(const HimConv2d* d, const float* x, const float* w, const float* bias, float* y, void* ws,
                      size_t ws_bytes, hipStream_t st) {
@@ -1586,6 +1641,12 @@ static int run_fprop(const HimConv2d* d, const float* x, const float* w, const f
     g.fast = 1;
     g.ph[0].At = (const float*)ws;
     g.ph[0].C2p = t.C2p;
+    const int ks = fast_ksplit(d->Cout, (long long)d->B * d->OH * d->OW, KK * (t.C2p / 16));
+    if (ks > 1) {
+      const size_t wts = ((size_t)d->Cout * KK * t.C2p * sizeof(float) + 255) / 256 * 256;
+      g.ksplit = ks;
+      g.kpart = (float*)((char*)ws + wts);
+    }
   }
   return launch_gconv(g, st);
 }
