@@ -352,6 +352,45 @@ __global__ void wtrans2_kernel(const WT2P p) {
   }
 }
 
+// Contiguous-run specialisations of the regrouping (stride-1 convs = 95 % of the weight bytes): both read and
+// write 16*KK-float (>= 576 B) contiguous runs through an LDS tile instead of 4-byte strided gathers.
+//   forward  : out[m][cb][tap][c16] = W[m][16cb + c16][tap]           one wave per (m, cb)
+__global__ __launch_bounds__(64) void wt_fwd_kernel(const float* __restrict__ W, float* __restrict__ out, int M, int C2,
+                                                    int CB, int KK) {
+  __shared__ float sm[16 * 64];
+  const int cb = blockIdx.x, m = blockIdx.y;
+  const int n = 16 * KK;
+  const int cvalid = min(16, C2 - cb * 16);
+  const float* __restrict__ src = W + ((size_t)m * C2 + (size_t)cb * 16) * KK;
+  for (int i = threadIdx.x; i < n; i += 64) sm[i] = i < cvalid * KK ? src[i] : 0.f;  // [c16][tap]
+  __syncthreads();
+  float* __restrict__ dst = out + ((size_t)m * CB + cb) * n;
+  for (int i = threadIdx.x; i < n; i += 64) {
+    const int tap = i >> 4, c16 = i & 15;
+    dst[i] = sm[c16 * KK + tap];
+  }
+}
+//   data grad: out[ci][cob][tap][co16] = W[16cob + co16][ci][tap]      one workgroup per (16 ci, cob)
+__global__ __launch_bounds__(256) void wt_dgrad_kernel(const float* __restrict__ W, float* __restrict__ out, int Co,
+                                                       int Ci, int COB, int KK) {
+  __shared__ float sm[16][16 * 49 + 1];
+  const int cib = blockIdx.x, cob = blockIdx.y;
+  const int civalid = min(16, Ci - cib * 16), covalid = min(16, Co - cob * 16);
+  const int n = 16 * KK;  // floats per co row in this tile
+  for (int r = threadIdx.x >> 4; r < 16; r += 16) {
+    const float* __restrict__ src = W + (((size_t)cob * 16 + r) * Ci + (size_t)cib * 16) * KK;
+    for (int i = threadIdx.x & 15; i < n; i += 16) sm[r][i] = (r < covalid && i < civalid * KK) ? src[i] : 0.f;
+  }
+  __syncthreads();
+  for (int ci = threadIdx.x >> 4; ci < civalid; ci += 16) {
+    float* __restrict__ dst = out + (((size_t)cib * 16 + ci) * COB + cob) * n;
+    for (int i = threadIdx.x & 15; i < n; i += 16) {  // i = tap*16 + co16; lanes of a 16-group write 64 B runs
+      const int tap = i >> 4, co16 = i & 15;
+      dst[i] = sm[co16][ci * KK + tap];
+    }
+  }
+}
+
 static bool use_fast(int M, int C2) {
   static int force_generic = -1;
   if (force_generic < 0) force_generic = getenv("HIM_GENERIC_CONV") ? 1 : 0;
@@ -1635,7 +1674,11 @@ static int run_fprop(const HimConv2d* d, const float* x, const float* w, const f
     t.ph[0].sw = 1;
     t.ph[0].base = 0;
     t.ph[0].total = (long long)d->Cout * KK * t.C2p;
-    hipLaunchKernelGGL(wtrans2_kernel, dim3(std::min<long long>(cdiv(t.ph[0].total, 256), 4096), 1), dim3(256), 0, st, t);
+    if (KK <= 64)
+      hipLaunchKernelGGL(wt_fwd_kernel, dim3(t.C2p / 16, d->Cout), dim3(64), 0, st, w, (float*)ws, d->Cout, d->Cin,
+                         t.C2p / 16, KK);
+    else
+      hipLaunchKernelGGL(wtrans2_kernel, dim3(std::min<long long>(cdiv(t.ph[0].total, 256), 4096), 1), dim3(256), 0, st, t);
     int rc = check_launch("wtrans2");
     if (rc) return rc;
     g.fast = 1;
@@ -1714,9 +1757,14 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
   g.slope = slope;
   int rc;
   if (fast) {
-    long long mx = 0;
-    for (int q = 0; q < g.nphase; ++q) mx = std::max(mx, t2.ph[q].total);
-    hipLaunchKernelGGL(wtrans2_kernel, dim3(std::min<long long>(cdiv(mx, 256), 4096), g.nphase), dim3(256), 0, st, t2);
+    if (d->stride == 1 && d->KH * d->KW <= 49) {
+      hipLaunchKernelGGL(wt_dgrad_kernel, dim3(cdiv(d->Cin, 16), pad16(d->Cout) / 16), dim3(256), 0, st, w, Wt, d->Cout,
+                         d->Cin, pad16(d->Cout) / 16, d->KH * d->KW);
+    } else {
+      long long mx = 0;
+      for (int q = 0; q < g.nphase; ++q) mx = std::max(mx, t2.ph[q].total);
+      hipLaunchKernelGGL(wtrans2_kernel, dim3(std::min<long long>(cdiv(mx, 256), 4096), g.nphase), dim3(256), 0, st, t2);
+    }
     rc = check_launch("wtrans2");
   } else {
     hipLaunchKernelGGL(wtrans_kernel, dim3(std::min<long long>(cdiv(nw, 256), 8192)), dim3(256), 0, st, wt);
