@@ -44,7 +44,12 @@ def _event_ms(fn, iters):
 
 def dominant_kernel_roofline(device):
     """ResnetBlock conv: refpad(1) + conv3x3 1024->1024 on (8,1024,16,32): GEMM M=1024, N=4096, K=9216 =
-    77.31 GFLOP per launch; 18 of them = 70.6 % of the generator's forward FLOPs.  MFMA-bound (AI >> ridge)."""
+    77.31 GFLOP per launch; 18 of them = 70.6 % of the generator's forward FLOPs (and the same GEMM again in every
+    data/weight gradient).  MFMA-bound (algorithmic intensity ~1090 FLOP/B >> the fp32 ridge of ~25).
+    Timed with HIP events on the launch stream; the time includes the weight-regroup and split-K finish kernels
+    that belong to the launch (so `achieved` is a lower bound for the MFMA kernel itself).
+    `traffic` = HBM-side bytes per launch from the committed PMC passes (profiles/r01_pmc_dominant_kernel.json:
+    FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE), null if that file is absent."""
     from neurips18_hierchical_image_manipulation_amd import ops
     x = torch.randn(BS, 1024, 16, 32, device=device)
     w = torch.randn(1024, 1024, 3, 3, device=device) * 0.02
@@ -56,9 +61,15 @@ def dominant_kernel_roofline(device):
         ms = _event_ms(fn, 20)
     flops = 2.0 * 1024 * (BS * 16 * 32) * (1024 * 9)
     ach = flops / (ms * 1e-3) / 1e12
-    return dict(bound='mfma', kernel='gconv_kernel<2,2,2,1> (ResnetBlock conv3x3 1024->1024 @16x32, bs 8)',
+    traffic = None
+    pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_dominant_kernel.json')
+    if os.path.isfile(pmc):
+        with open(pmc) as f:
+            traffic = int(json.load(f)['traffic_bytes_corrected'])
+    return dict(bound='mfma', kernel='gconv_fast_kernel<2,2,2,2,reflect> (ResnetBlock conv3x3 1024->1024 @16x32, bs 8)',
                 achieved=round(ach, 2), peak=PEAK_F32_MFMA, unit='TFLOP/s', frac=round(ach / PEAK_F32_MFMA, 4),
-                traffic=None, flop_per_launch=flops, avg_launch_ms=round(ms, 4))
+                traffic=traffic, traffic_unit='bytes/launch (PMC, corrected)', algorithmic_bytes=71303168,
+                flop_per_launch=flops, avg_launch_ms=round(ms, 4))
 
 
 def g_forward_roofline(model, batch):
@@ -155,7 +166,7 @@ def main():
                                    '(182.6M params) + 3-scale PatchGAN + VGG19 loss (synthetic weights), full '
                                    'train step G+D Adam, fp32', 'global_batch': BS * world, 'per_gpu_batch': BS,
                        'parallelism': 'dp%d' % world},
-            'last_losses': {k: round(float(v), 5) for k, v in losses.items()},
+            'last_losses': {k: round(float(v.detach()), 5) for k, v in losses.items()},
         }
         if not args.no_roofline:
             out['roofline'] = dominant_kernel_roofline(device)

@@ -42,9 +42,10 @@ class GradReducer(object):
     ``ranges``  list of (start, end) element ranges, one per parameter, in FORWARD order.
     """
 
-    def __init__(self, flat, ranges, bucket_bytes=64 << 20, group=None):
+    def __init__(self, flat, ranges, bucket_bytes=64 << 20, group=None, force=False):
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())   # force: exercise the path on 1 rank
         self.ranges = list(ranges)
         self.range_to_bucket = {}
         self.buckets = []            # (start, end, n_params) ; bucket 0 = LAST parameters (first ready in backward)
@@ -77,7 +78,7 @@ class GradReducer(object):
     def begin(self, contributions=1):
         """``contributions``: how many wgrad writes each parameter receives in the coming backward (the
         discriminator is run twice with live weights inside loss_D)."""
-        if self.world <= 1:
+        if not self.active:
             return
         self.pending = [b[2] * contributions for b in self.buckets]
         self.launched = [False] * len(self.buckets)
@@ -110,7 +111,7 @@ class GradReducer(object):
 
     def finish(self):
         """Launch whatever has not been triggered and make the current stream wait for the exchange."""
-        if self.world <= 1 or not self.armed:
+        if not self.active or not self.armed:
             return
         for b in range(len(self.buckets)):
             if not self.launched[b]:
@@ -120,14 +121,14 @@ class GradReducer(object):
         self.armed = False
 
 
-def attach_data_parallel(model, bucket_bytes=64 << 20):
-    """Give a mask2image model per-network reducers (no-op for world size 1)."""
-    if not dist.is_initialized() or dist.get_world_size() <= 1:
+def attach_data_parallel(model, bucket_bytes=64 << 20, force=False):
+    """Give a mask2image model per-network reducers (no-op for world size 1 unless ``force``)."""
+    if not dist.is_initialized() or (dist.get_world_size() <= 1 and not force):
         return model
     for tag in ('G', 'D'):
         opt = getattr(model, 'optimizer_' + tag)
         arena = opt.arena
-        red = GradReducer(arena.grad, [p._him_arena_range for p in arena.params], bucket_bytes)
+        red = GradReducer(arena.grad, [p._him_arena_range for p in arena.params], bucket_bytes, force=force)
         red.attach(arena.params)
         setattr(model, 'reducer_' + tag, red)
     return model

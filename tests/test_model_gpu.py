@@ -276,3 +276,15 @@ def test_cpu_tensor_into_hip_op_fails_loudly():
     from neurips18_hierchical_image_manipulation_amd._cabi import HimError
     with pytest.raises(HimError):
         ops.conv2d(torch.zeros(1, 3, 8, 8), torch.zeros(4, 3, 3, 3))
+
+
+def test_rccl_reducer_path_single_rank_is_identity():
+    """The bucketed all-reduce path (side stream, wgrad-completion triggers, ReduceOp.AVG over RCCL) driven by
+    torch.distributed.run with ONE rank on the GPU: must be bit-identical to the un-attached model."""
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1', '--master-addr',
+           '127.0.0.1', '--master-port', str(29600 + os.getpid() % 300), os.path.join(root, 'tools', 'ddp_selfcheck.py')]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and 'DDP SELFCHECK OK' in r.stdout, r.stdout[-3000:]
