@@ -1632,12 +1632,24 @@ static int fast_ksplit(int M, long long N, int nk) {
   if (off < 0) off = getenv("HIM_NO_SPLITK") ? 1 : 0;
   if (off) return 1;
   const long long tiles = (M <= 64 ? (long long)cdiv(N, 128) * cdiv(M, 64) : (long long)cdiv(N, 128) * cdiv(M, 128));
-  if (tiles > 256) return 1;
-  int ks = (int)((512 + tiles - 1) / tiles);
-  const int maxs = nk / 48;  // keep >= 48 K-steps per workgroup
-  if (ks > maxs) ks = maxs;
-  if (ks > 16) ks = 16;
-  return ks < 1 ? 1 : ks;
+  if (tiles >= 1024) return 1;
+  // makespan model in units of one full-K tile on one of 256 CUs: rounds/ks, a 7 % bonus once every CU hosts >= 2
+  // independent workgroups (they cover each other's LDS/barrier bubbles), 2 % for the finish pass
+  int best = 1;
+  double best_cost = 1e30;
+  const int cand[] = {1, 2, 3, 4, 6, 8, 12, 16};
+  for (int ks : cand) {
+    if (ks > 1 && nk / ks < 32) break;  // keep >= 32 K-steps per workgroup
+    const long long wg = tiles * ks;
+    double cost = (double)cdiv(wg, 256) / ks;
+    if (wg >= 512) cost *= 0.93;
+    if (ks > 1) cost += 0.02;
+    if (cost < best_cost - 1e-9) {
+      best_cost = cost;
+      best = ks;
+    }
+  }
+  return best;
 }
 static size_t fprop_ws_bytes(const HimConv2d* d) {
   if (small_split_ok(d)) return (size_t)SMALL_NSPLIT * d->Cout * d->B * d->OH * d->OW * sizeof(float) + 256;
@@ -1696,10 +1708,18 @@ static int run_fprop(const HimConv2d* d, const float* x, const float* w, const f
 
 // data gradient of the conv described by `d` (also the forward of its transposed conv):
 // out (B,Cin,H,W) = sum W * g (B,Cout,OH,OW); for reflect mode goes through the padded gradient + fold.
+static int dgrad_ksplit(const HimConv2d* d) {
+  if (d->stride != 1 || !use_fast(d->Cin, d->Cout)) return 1;
+  const bool refl = d->pad_mode == HIM_PAD_REFLECT;
+  const long long N = (long long)d->B * (refl ? d->H + 2 * d->pad : d->H) * (refl ? d->W + 2 * d->pad : d->W);
+  return fast_ksplit(d->Cin, N, d->KH * d->KW * (pad16(d->Cout) / 16));
+}
 static size_t dgrad_ws_bytes(const HimConv2d* d) {
   size_t n = (size_t)d->Cin * pad16(d->Cout) * d->KH * d->KW + 64;
-  if (d->pad_mode == HIM_PAD_REFLECT)
-    n += (size_t)d->B * d->Cin * (d->H + 2 * d->pad) * (d->W + 2 * d->pad);
+  const size_t outn = (size_t)d->B * d->Cin * (d->H + 2 * d->pad) * (d->W + 2 * d->pad);
+  if (d->pad_mode == HIM_PAD_REFLECT) n += outn + 64;
+  const int ks = dgrad_ksplit(d);
+  if (ks > 1) n += (size_t)ks * outn + 64;
   return n * sizeof(float) + 256;
 }
 static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float* out, const float* bias, int act,
@@ -1743,6 +1763,14 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
     g.fast = 1;
   }
   float* dpad = Wt + ((nw + 63) / 64) * 64;
+  if (fast && g.nphase == 1) {
+    const int ks = dgrad_ksplit(d);
+    if (ks > 1) {
+      const size_t outn = (size_t)d->B * d->Cin * IH * IW;
+      g.ksplit = ks;
+      g.kpart = dpad + (refl ? ((outn + 63) / 64) * 64 : 0);
+    }
+  }
   g.src = gy;
   g.dst = refl ? dpad : out;
   g.bias = refl ? nullptr : bias;
