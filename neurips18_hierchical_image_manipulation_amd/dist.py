@@ -113,6 +113,9 @@ class GradReducer(object):
         """Launch whatever has not been triggered and make the current stream wait for the exchange."""
         if not self.active or not self.armed:
             return
+        if self.on_gpu:
+            from .ops import join_side_stream
+            join_side_stream(self.flat.device)   # side-stream weight gradients of never-triggered buckets
         for b in range(len(self.buckets)):
             if not self.launched[b]:
                 self._launch(b)

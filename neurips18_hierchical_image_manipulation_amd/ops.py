@@ -10,6 +10,7 @@ of the arena, zeroed by ``zero_grad``) and autograd receives ``None`` -- no per-
 bucket copies for the RCCL all-reduce.
 """
 import ctypes
+import os
 
 import torch
 
@@ -46,6 +47,52 @@ def _ws(nbytes, like):
 
 def _direct(p):
     return getattr(p, '_him_direct_grad', False) and p.grad is not None
+
+
+# Weight gradients that go straight into a gradient arena are not needed by anything until the optimizer / the
+# all-reduce, so they run on a SIDE stream next to the data-gradient chain: the two MFMA kernels of a layer fill each
+# other's partial last waves (every launch here has an imperfect tile count for 256 CUs).  ``join_side_stream`` makes
+# the current stream wait for them (called by FusedAdam.step / zero_grad and the reducer).
+_SIDE = {}
+_SIDE_ON = os.environ.get('HIM_WGRAD_STREAM', '1') != '0'
+
+
+def _side_stream(device):
+    s = _SIDE.get(device)
+    if s is None:
+        s = _SIDE[device] = torch.cuda.Stream(device=device)
+    return s
+
+
+def join_side_stream(device=None):
+    for dev, s in _SIDE.items():
+        if device is None or dev == device:
+            torch.cuda.current_stream(dev).wait_stream(s)
+
+
+class _wgrad_stream(object):
+    """Context: run the enclosed launches on the side stream, after everything enqueued so far on the current one."""
+
+    def __init__(self, *tensors):
+        self.tensors = [t for t in tensors if t is not None]
+
+    def __enter__(self):
+        if not _SIDE_ON:
+            return None
+        dev = self.tensors[0].device
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev)
+        side.wait_stream(main)
+        for t in self.tensors:
+            t.record_stream(side)
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return side
+
+    def __exit__(self, *a):
+        if _SIDE_ON:
+            self.ctx.__exit__(*a)
+        return False
 
 
 def _notify(p):
@@ -103,14 +150,16 @@ class _Conv2d(torch.autograd.Function):
         need_b = b is not None and ctx.needs_input_grad[2]
         if need_w or need_b:
             nb = lib.him_conv2d_bwd_weight_ws(ctypes.byref(d))
-            ws = _ws(nb, x)
             if need_w and _direct(w) and (not need_b or _direct(b)):
-                lib.him_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dz), _p(w.grad), _p(b.grad) if need_b else 0,
-                                          1, _p(ws), nb, st)
-                _notify(w)
-                if need_b:
-                    _notify(b)
+                with _wgrad_stream(x, dz):
+                    ws = _ws(nb, x)
+                    lib.him_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dz), _p(w.grad),
+                                              _p(b.grad) if need_b else 0, 1, _p(ws), nb, _stream())
+                    _notify(w)
+                    if need_b:
+                        _notify(b)
             else:
+                ws = _ws(nb, x)
                 dw = torch.empty_like(w) if need_w else None
                 db = torch.empty_like(b) if need_b else None
                 lib.him_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dz), _p(dw), _p(db), 0, _p(ws), nb, st)
@@ -164,14 +213,16 @@ class _Deconv2d(torch.autograd.Function):
         need_b = b is not None and ctx.needs_input_grad[2]
         if need_w or need_b:
             nb = lib.him_deconv2d_bwd_weight_ws(ctypes.byref(d))
-            ws = _ws(nb, x)
             if need_w and _direct(w) and (not need_b or _direct(b)):
-                lib.him_deconv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dz), _p(w.grad), _p(b.grad) if need_b else 0,
-                                            1, _p(ws), nb, st)
-                _notify(w)
-                if need_b:
-                    _notify(b)
+                with _wgrad_stream(x, dz):
+                    ws = _ws(nb, x)
+                    lib.him_deconv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dz), _p(w.grad),
+                                                _p(b.grad) if need_b else 0, 1, _p(ws), nb, _stream())
+                    _notify(w)
+                    if need_b:
+                        _notify(b)
             else:
+                ws = _ws(nb, x)
                 dw = torch.empty_like(w) if need_w else None
                 db = torch.empty_like(b) if need_b else None
                 lib.him_deconv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dz), _p(dw), _p(db), 0, _p(ws), nb, st)

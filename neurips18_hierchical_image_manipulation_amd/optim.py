@@ -48,6 +48,8 @@ class FlatArena(object):
 
     def zero_grad(self):
         self.rebind()
+        from .ops import join_side_stream
+        join_side_stream(self.grad.device)     # no weight-gradient kernel may still be writing
         lib.him_fill(self.grad.data_ptr(), self.total, 0.0, _stream())
 
 
@@ -70,6 +72,8 @@ class FusedAdam(object):
         g = self.param_groups[0]
         self.step_count += 1
         a = self.arena
+        from .ops import join_side_stream
+        join_side_stream(a.grad.device)        # wait for the side-stream weight gradients
         lib.him_adam_step(a.data.data_ptr(), a.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                           a.total, float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
                           self.step_count, _stream())
