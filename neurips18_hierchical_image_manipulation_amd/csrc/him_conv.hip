@@ -57,6 +57,7 @@ struct GConvP {
   int fast;  // 1: ph[].At valid -> gconv_fast_kernel
   float* kpart;       // fast path split-K: [ksplit] slabs shaped like dst (raw sums; bias/act in gconv_splitk_finish)
   int ksplit;
+  int kno_finish;     // the caller sums the split-K slabs itself (reflection fold)
   float* small_part;  // tiny-M path: [nsplit][M][Ntot] partial sums when the channels are split over grid.y
   int small_nsplit;
   GPhase ph[4];
@@ -294,10 +295,30 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_fast_kernel(const GConvP p
   }
 }
 
-// dst = act(sum_z kpart[z] + bias[channel])  (fixed order), float4 streams
+// dst = act(sum_z kpart[z] + bias[channel])  (fixed order)
 __global__ void gconv_splitk_finish_kernel(const float* __restrict__ part, float* __restrict__ dst,
                                            const float* __restrict__ bias, long long n, int ksplit, int M, int plane,
                                            int act, float slope) {
+  if ((n & 3) == 0 && (plane & 3) == 0) {
+    const float4* __restrict__ p4 = (const float4*)part;
+    float4* __restrict__ d4 = (float4*)dst;
+    const long long n4 = n >> 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (long long)gridDim.x * blockDim.x) {
+      float4 v = p4[i];
+      for (int z = 1; z < ksplit; ++z) {
+        const float4 w = p4[(size_t)z * n4 + i];
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+      }
+      const float bb = bias ? bias[(int)(((i << 2) / plane) % M)] : 0.f;
+      v.x = apply_act(v.x + bb, act, slope);
+      v.y = apply_act(v.y + bb, act, slope);
+      v.z = apply_act(v.z + bb, act, slope);
+      v.w = apply_act(v.w + bb, act, slope);
+      d4[i] = v;
+    }
+    return;
+  }
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
     float v = 0.f;
@@ -782,7 +803,7 @@ static int launch_gconv(const GConvP& p, hipStream_t st) {
       }
     }
     int rcf = check_launch("gconv_fast");
-    if (rcf || ks == 1) return rcf;
+    if (rcf || ks == 1 || p.kno_finish) return rcf;
     const long long n = (long long)p.B * p.M * p.DH * p.DW;
     hipLaunchKernelGGL(gconv_splitk_finish_kernel, dim3(std::min<long long>(cdiv(n, 256), 8192)), dim3(256), 0, st,
                        (const float*)p.kpart, p.dst, p.bias, n, ks, p.M, p.DH * p.DW, p.act, p.slope);
@@ -888,7 +909,8 @@ static long long setup_dgrad(GConvP& g, WTransP& wt, int Cout, int Cin, int KH, 
 
 // ---- reflection-pad backward: dx[y][x] = sum of dpad over the padded positions that mirror onto (y,x)
 __global__ void reflect_fold_kernel(const float* __restrict__ dpad, float* __restrict__ dx, int planes, int H,
-                                    int W, int p) {
+                                    int W, int p, int nslab, size_t slab_stride) {
+  // nslab > 1: dpad holds split-K partial slabs that are summed here (fixed order), saving the finish pass
   const int PH = H + 2 * p, PW = W + 2 * p;
   const long long total = (long long)planes * H * W;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -906,8 +928,11 @@ __global__ void reflect_fold_kernel(const float* __restrict__ dpad, float* __res
     if (x >= W - 1 - p && x <= W - 2) xs[nx++] = p + 2 * (W - 1) - x;
     const float* base = dpad + pl * PH * PW;
     float s = 0.f;
-    for (int a = 0; a < ny; ++a)
-      for (int b = 0; b < nx; ++b) s += base[ys[a] * PW + xs[b]];
+    for (int z = 0; z < nslab; ++z) {
+      const float* bz = base + (size_t)z * slab_stride;
+      for (int a = 0; a < ny; ++a)
+        for (int b = 0; b < nx; ++b) s += bz[ys[a] * PW + xs[b]];
+    }
     dx[i] = s;
   }
 }
@@ -1244,20 +1269,24 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WGradP p) {
 }
 
 // dW[m][ci][tap] (+)= sum_z slab[z][m][tap*C + ci]   (fixed summation order; coalesced on the dW side)
-__global__ void wgrad_finish_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int M, int C, int KK,
-                                    int splits, int accumulate) {
-  const long long n = (long long)M * C * KK;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int tap = (int)(i % KK);
-    const long long r = i / KK;
-    const int ci = (int)(r % C);
-    const long long m = r / C;
-    const size_t src = (size_t)m * C * KK + (size_t)tap * C + ci;
-    float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += slabs[(size_t)z * n + src];
-    dw[i] = accumulate ? dw[i] + s : s;
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
+                                                           int M, int C, int KK, int splits, int accumulate) {
+  // one workgroup per (m, 64-channel chunk): slab rows [tap][64 ci] are read as 256-B runs (summed over the split-K
+  // slabs in fixed order), transposed through LDS and written/accumulated as one contiguous [64 ci][KK] run
+  __shared__ float sm[64 * 49];
+  const int m = blockIdx.y, c0 = blockIdx.x * 64;
+  const size_t n = (size_t)M * C * KK;
+  const int nel = 64 * KK;
+  for (int i = threadIdx.x; i < nel; i += 256) {
+    const int tap = i >> 6, ci = i & 63;
+    const size_t src = (size_t)m * C * KK + (size_t)tap * C + c0 + ci;
+    float v = 0.f;
+    for (int z = 0; z < splits; ++z) v += slabs[(size_t)z * n + src];
+    sm[ci * KK + tap] = v;
   }
+  __syncthreads();
+  float* __restrict__ dst = dw + ((size_t)m * C + c0) * KK;
+  for (int i = threadIdx.x; i < nel; i += 256) dst[i] = accumulate ? dst[i] + sm[i] : sm[i];
 }
 
 static bool wgrad_fast_ok(int M, int C, int OH, int OW) {
@@ -1373,12 +1402,18 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __res
 }
 
 // dbias[c] (+)= sum_{b,sp} dy[b][c][sp]: stage 1 = (channel, slice) partial sums, stage 2 = fixed-order finish.
-constexpr int BIAS_SLICES = 32;
+constexpr int BIAS_SLICES = 32;  // maximum; small planes use fewer (bias_slices())
+static int bias_slices(int B, int hw) {
+  long long per = ((long long)B * hw + 8191) / 8192;  // ~8k elements per workgroup
+  if (per > BIAS_SLICES) per = BIAS_SLICES;
+  if (per > hw) per = hw;
+  return per < 1 ? 1 : (int)per;
+}
 __global__ __launch_bounds__(256) void bias_grad1_kernel(const float* __restrict__ dy, float* __restrict__ part,
                                                          int B, int C, int hw) {
   __shared__ float sh[8];
   const int c = blockIdx.x, sl = blockIdx.y;
-  const int chunk = (hw + BIAS_SLICES - 1) / BIAS_SLICES;
+  const int chunk = (hw + gridDim.y - 1) / gridDim.y;
   const int beg = sl * chunk, end = min(hw, beg + chunk);
   float s = 0.f;
   for (int b = 0; b < B; ++b) {
@@ -1388,11 +1423,12 @@ __global__ __launch_bounds__(256) void bias_grad1_kernel(const float* __restrict
   s = block_sum_256(s, sh);
   if (threadIdx.x == 0) part[c * BIAS_SLICES + sl] = s;
 }
-__global__ void bias_grad2_kernel(const float* __restrict__ part, float* __restrict__ db, int C, int accumulate) {
+__global__ void bias_grad2_kernel(const float* __restrict__ part, float* __restrict__ db, int C, int nsl,
+                                  int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float s = 0.f;
-  for (int i = 0; i < BIAS_SLICES; ++i) s += part[c * BIAS_SLICES + i];
+  for (int i = 0; i < nsl; ++i) s += part[c * BIAS_SLICES + i];
   db[c] = accumulate ? db[c] + s : s;
 }
 static size_t bias_ws_bytes(int C) { return (size_t)C * BIAS_SLICES * sizeof(float) + 256; }
@@ -1519,8 +1555,9 @@ static int run_wgrad(const float* dy, const float* x, float* dw, int M, int C, i
     int rc0 = check_launch("wgrad_fast");
     if (rc0) return rc0;
     const long long n = (long long)M * p.Np;
-    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(std::min<long long>(cdiv(n, 256), 8192)), dim3(256), 0, st,
-                       (const float*)ws, dw, M, C, KH * KW, fs, accumulate);
+    (void)n;
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(C / 64, M), dim3(256), 0, st, (const float*)ws, dw, M, C, KH * KW, fs,
+                       accumulate);
     return check_launch("wgrad_finish");
   }
   int BM, BN;
@@ -1564,8 +1601,9 @@ static int run_wgrad(const float* dy, const float* x, float* dw, int M, int C, i
 static int run_bias_grad(const float* dy, float* db, int B, int C, int hw, int accumulate, void* ws, size_t ws_bytes,
                          hipStream_t st) {
   if (!ws || ws_bytes < bias_ws_bytes(C)) return fail(HIM_E_WORKSPACE, "bias grad ws too small");
-  hipLaunchKernelGGL(bias_grad1_kernel, dim3(C, BIAS_SLICES), dim3(256), 0, st, dy, (float*)ws, B, C, hw);
-  hipLaunchKernelGGL(bias_grad2_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, (const float*)ws, db, C, accumulate);
+  const int nsl = bias_slices(B, hw);
+  hipLaunchKernelGGL(bias_grad1_kernel, dim3(C, nsl), dim3(256), 0, st, dy, (float*)ws, B, C, hw);
+  hipLaunchKernelGGL(bias_grad2_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, (const float*)ws, db, C, nsl, accumulate);
   return check_launch("bias_grad");
 }
 
@@ -1769,6 +1807,7 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
       const size_t outn = (size_t)d->B * d->Cin * IH * IW;
       g.ksplit = ks;
       g.kpart = dpad + (refl ? ((outn + 63) / 64) * 64 : 0);
+      g.kno_finish = refl ? 1 : 0;
     }
   }
   g.src = gy;
@@ -1803,8 +1842,10 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
   if (rc) return rc;
   if (refl) {
     const long long tot = (long long)d->B * d->Cin * d->H * d->W;
+    const bool slabs = g.ksplit > 1;
     hipLaunchKernelGGL(reflect_fold_kernel, dim3(std::min<long long>(cdiv(tot, 256), 16384)), dim3(256), 0, st,
-                       (const float*)dpad, out, d->B * d->Cin, d->H, d->W, d->pad);
+                       (const float*)(slabs ? g.kpart : dpad), out, d->B * d->Cin, d->H, d->W, d->pad,
+                       slabs ? g.ksplit : 1, (size_t)d->B * d->Cin * IH * IW);
     rc = check_launch("reflect_fold");
   }
   return rc;
