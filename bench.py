@@ -87,19 +87,21 @@ def g_forward_roofline(model, batch):
 
 def cpu_baseline():
     """The CPU oracle (validated bit-exact against the imported reference) timed on this box's host cores on a
-    bounded sample of the same workload: ONE full training step at 512x256 with batch 2 (not 8)."""
+    bounded sample of the same workload: full training steps at 512x256 with batch 2 (not 8): one untimed warm-up
+    step (oneDNN primitive creation), then one timed step."""
     from oracle import ref_cpu
     from neurips18_hierchical_image_manipulation_amd import synth
     cores = torch.get_num_threads()
     bs = 2
     om = ref_cpu.Mask2ImageModel(ref_cpu.Opt(**C2))
-    b = synth.make_batch(0, 0, bs, H, W)
+    om.optimize_parameters(synth.make_batch(0, 0, bs, H, W))
+    b = synth.make_batch(1, 0, bs, H, W)
     t0 = time.time()
     om.optimize_parameters(b)
     dt = time.time() - t0
     return dict(value=round(bs / dt, 4), unit='images/s', cores=cores, kind='port',
-                sample='1 full training step (no warm-up), 512x256, batch %d of the bs-8 workload, torch CPU fp32, '
-                       '%d threads: %.1f s' % (bs, cores, dt))
+                sample='1 timed full training step after 1 warm-up step, 512x256, batch %d of the bs-8 workload, '
+                       'torch CPU fp32 oracle, %d threads: %.1f s' % (bs, cores, dt))
 
 
 def main():

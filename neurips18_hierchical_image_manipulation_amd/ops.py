@@ -537,7 +537,7 @@ class _SNSigma(torch.autograd.Function):
     @staticmethod
     def forward(ctx, W, u):
         W2 = W.contiguous().view(W.shape[0], -1)
-        u = u.contiguous()
+        u = u.detach().clone()      # the layer overwrites its persistent u in place after this call
         _chk(W2, u)
         rows, cols = W2.shape
         v = torch.empty(cols, dtype=torch.float32, device=W.device)

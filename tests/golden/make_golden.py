@@ -162,6 +162,11 @@ TINY_COLOR = dict(TINY_TWO, model='pix2pixHD_condImgColor', label_nc=49)
 C1 = dict(model='pix2pixHD_condImg', netG='global', ngf=64, ndf=64, n_downsample_global=4, n_blocks_global=9,
           num_D=1, n_layers_D=3, label_nc=35, no_instance=True)
 C2 = dict(C1, num_D=3)
+# BASELINE config 4: ADE20K-shaped 256x256, colour two-stream path (the shipped recipe flags of
+# scripts/train_mask2image_ade.sh + the colour model), label_nc 49, num_D 2
+C4 = dict(model='pix2pixHD_condImgColor', netG='global_twostream', ngf=64, ndf=64, n_downsample_global=4,
+          n_blocks_global=9, num_D=2, n_layers_D=3, label_nc=49, no_instance=True, no_imgCond=True,
+          which_encoder='ctx_label', use_skip=True, use_output_gate=True, mask_gan_input=True)
 
 if __name__ == '__main__':
     what = sys.argv[1:] or ['tiny']
@@ -177,3 +182,5 @@ if __name__ == '__main__':
         trajectory('c1_traj', C1, 1, 128, 256, 20)
     if 'c2' in what:
         trajectory('c2_traj', C2, 8, 256, 512, 20)
+    if 'c4' in what:
+        trajectory('c4_traj', C4, 4, 256, 256, 3, color=True)   # bs 4 of the bs-16 config keeps it to minutes
