@@ -127,6 +127,12 @@ class Pix2PixHDModel_condImg(BaseModel):
             self.optimizer_G = FusedAdam(self.netG.parameters(), lr=opt.lr, betas=(opt.beta1, 0.999))
             self.optimizer_D = FusedAdam(self.netD.parameters(), lr=opt.lr, betas=(opt.beta1, 0.999))
             self.reducer_G = self.reducer_D = None
+            # gradient routing of the shared fake-image discriminator pass (see forward)
+            self._d_weight_ids = set(id(p) for p in self.netD.parameters())
+            self._d_first_weight_ids = set(id(getattr(self.netD, 'scale%d_layer0' % i)[0].weight)
+                                           for i in range(opt.num_D))
+            self._fake_gate = None
+            self._share_fake_pass = False
         self.loss_G = self.loss_D = None
 
     def name(self):
@@ -188,16 +194,29 @@ class Pix2PixHDModel_condImg(BaseModel):
         netD_cond = input_mask if self.no_imgCond else buf
         mask_cond = mask_in if not self.use_soft_mask else self._dev(mask_out)
 
-        # Fake detection and loss / real detection and loss (:218-223)
-        pred_fake_pool = self.discriminate(netD_cond, fake_image, mask_cond, True)
+        # Fake detection and loss / real detection and loss / GAN loss (:218-233).  The reference runs the discriminator
+        # on the fake image twice -- once detached (loss_D_fake) and once attached (loss_G_GAN + feature matching) --
+        # with identical weights and identical input values, i.e. identical activations.  With an empty image pool, and
+        # when optimize_parameters() drives the step (a caller doing its own loss.backward() calls gets the reference's
+        # three separate passes), the pass is computed ONCE and the gradients are routed at backward time: during
+        # loss_G.backward() they
+        # reach the generator but D's weight gradients are skipped (the reference computes and discards them,
+        # train_mask2image.py:84); during loss_D.backward() they reach D's weights and stop in front of the generator.
+        share = opt.pool_size == 0 and self._share_fake_pass   # only optimize_parameters() owns both backward calls
+        if share:
+            self._fake_gate = {'open': True}
+            pred_fake = self.netD.forward(self._d_input(netD_cond, ops.grad_switch(fake_image, self._fake_gate),
+                                                        mask_cond))
+            pred_fake_pool = pred_fake
+        else:
+            self._fake_gate = None
+            pred_fake_pool = self.discriminate(netD_cond, fake_image, mask_cond, True)
         loss_D_fake = self.criterionGAN(pred_fake_pool, False)
         pred_real = self.discriminate(netD_cond, real_image, mask_cond, False)
         loss_D_real = self.criterionGAN(pred_real, True)
-
-        # GAN loss (fake passability): gradients reach G only; D's weight gradients of this pass are the ones
-        # the reference computes and zeroes (train_mask2image.py:84), so they are never computed here.
-        with frozen_params():
-            pred_fake = self.netD.forward(self._d_input(netD_cond, fake_image, mask_cond))
+        if not share:
+            with frozen_params():
+                pred_fake = self.netD.forward(self._d_input(netD_cond, fake_image, mask_cond))
         loss_G_GAN = self.criterionGAN(pred_fake, True)
 
         loss_G_GAN_Feat = torch.zeros(1, device=self.device)
@@ -253,12 +272,34 @@ class Pix2PixHDModel_condImg(BaseModel):
         self.loss_G = loss_dict['G_GAN'] + loss_dict['G_GAN_Feat'] + loss_dict['G_VGG']
         return loss_dict
 
+    def _run_backward_G(self):
+        """loss_G.backward() with the shared fake-image D pass routed to the generator only."""
+        shared = self._fake_gate is not None
+        if shared:
+            self._fake_gate['open'] = True
+            ops.SKIP_WGRAD.update(self._d_weight_ids)
+        try:
+            self.loss_G.backward(retain_graph=shared)
+        finally:
+            ops.SKIP_WGRAD.difference_update(self._d_weight_ids)
+
+    def _run_backward_D(self):
+        """loss_D.backward() with the shared fake-image D pass routed to D's weights only."""
+        shared = self._fake_gate is not None
+        if shared:
+            self._fake_gate['open'] = False
+            ops.SKIP_DGRAD.update(self._d_first_weight_ids)
+        try:
+            self.loss_D.backward()
+        finally:
+            ops.SKIP_DGRAD.difference_update(self._d_first_weight_ids)
+
     def backward_G(self):
         """optimizer_G.zero_grad(); loss_G.backward(); optimizer_G.step()   (:78-80)."""
         self.optimizer_G.zero_grad()
         if self.reducer_G is not None:
             self.reducer_G.begin()
-        self.loss_G.backward()
+        self._run_backward_G()
         if self.reducer_G is not None:
             self.reducer_G.finish()
         self.optimizer_G.step()
@@ -268,7 +309,7 @@ class Pix2PixHDModel_condImg(BaseModel):
         self.optimizer_D.zero_grad()
         if self.reducer_D is not None:
             self.reducer_D.begin(contributions=2)
-        self.loss_D.backward()
+        self._run_backward_D()
         if self.reducer_D is not None:
             self.reducer_D.finish()
         self.optimizer_D.step()
@@ -283,7 +324,11 @@ class Pix2PixHDModel_condImg(BaseModel):
                   mask_out=data['mask_out'], infer=infer)
         if 'obj_mask' in data:
             kw['obj_mask'] = data['obj_mask']
-        losses, generated = self.forward(**kw)
+        self._share_fake_pass = os.environ.get('HIM_SHARE_FAKE_PASS', '1') != '0'
+        try:
+            losses, generated = self.forward(**kw)
+        finally:
+            self._share_fake_pass = False
         loss_dict = self.combine_losses(losses)
         if self.reducer_G is None:
             self.backward_G()
@@ -292,11 +337,11 @@ class Pix2PixHDModel_condImg(BaseModel):
         else:
             self.optimizer_G.zero_grad()
             self.reducer_G.begin()
-            self.loss_G.backward()
+            self._run_backward_G()
             if not self.opt.no_gan:
                 self.optimizer_D.zero_grad()
                 self.reducer_D.begin(contributions=2)
-                self.loss_D.backward()
+                self._run_backward_D()
             self.reducer_G.finish()
             self.optimizer_G.step()
             if not self.opt.no_gan:

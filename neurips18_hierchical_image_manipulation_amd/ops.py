@@ -95,6 +95,31 @@ class _wgrad_stream(object):
         return False
 
 
+# Run-time gradient routing for graphs that are shared between the generator loss and the discriminator loss (the
+# fake-image discriminator pass is computed ONCE, see Pix2PixHDModel_condImg.forward): ids of weights whose weight
+# gradient / whose layer-input gradient must not be computed during the current backward.
+SKIP_WGRAD = set()
+SKIP_DGRAD = set()
+
+
+class _GradSwitch(torch.autograd.Function):
+    """Identity whose backward passes the gradient only while ``state['open']`` is true."""
+
+    @staticmethod
+    def forward(ctx, x, state):
+        ctx.set_materialize_grads(False)   # an undefined gradient stays None: backward returns early
+        ctx.state = state
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g if (g is not None and ctx.state['open']) else None), None
+
+
+def grad_switch(x, state):
+    return _GradSwitch.apply(x, state)
+
+
 def _notify(p):
     """Tell the data-parallel reducer (if any) that this parameter's gradient for the step is final."""
     r = getattr(p, '_him_reducer', None)
@@ -118,6 +143,7 @@ def _conv_desc(x, w, stride, pad, pad_mode, act, slope):
 class _Conv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, pad, pad_mode, act, slope):
+        ctx.set_materialize_grads(False)   # an undefined gradient stays None: backward returns early
         x = x.contiguous()
         _chk(x, w, b)
         d = _conv_desc(x, w, stride, pad, pad_mode, act, slope)
@@ -132,6 +158,8 @@ class _Conv2d(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if dy is None:
+            return (None,) * 8
         d, x, w, b = ctx.d, ctx.x, ctx.w, ctx.b
         dy = dy.contiguous()
         st = _stream()
@@ -141,13 +169,14 @@ class _Conv2d(torch.autograd.Function):
         else:
             dz = dy
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and id(w) not in SKIP_DGRAD:
             dx = torch.empty_like(x)
             nb = lib.him_conv2d_bwd_data_ws(ctypes.byref(d))
             ws = _ws(nb, x)
             lib.him_conv2d_bwd_data(ctypes.byref(d), _p(dz), _p(w), _p(dx), _p(ws), nb, st)
-        need_w = ctx.needs_input_grad[1]
-        need_b = b is not None and ctx.needs_input_grad[2]
+        skip_w = id(w) in SKIP_WGRAD
+        need_w = ctx.needs_input_grad[1] and not skip_w
+        need_b = b is not None and ctx.needs_input_grad[2] and not skip_w
         if need_w or need_b:
             nb = lib.him_conv2d_bwd_weight_ws(ctypes.byref(d))
             if need_w and _direct(w) and (not need_b or _direct(b)):
@@ -175,6 +204,7 @@ def conv2d(x, w, b=None, stride=1, pad=0, pad_mode='zero', act='none', slope=0.2
 class _Deconv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, pad, out_pad, act, slope):
+        ctx.set_materialize_grads(False)   # an undefined gradient stays None: backward returns early
         x = x.contiguous()
         _chk(x, w, b)
         B, Cin, H, W = x.shape
@@ -195,6 +225,8 @@ class _Deconv2d(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if dy is None:
+            return (None,) * 8
         d, x, w, b = ctx.d, ctx.x, ctx.w, ctx.b
         dy = dy.contiguous()
         st = _stream()
@@ -239,6 +271,7 @@ def conv_transpose2d(x, w, b=None, stride=2, pad=1, out_pad=1, act='none', slope
 class _InstNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, residual, act, slope, eps):
+        ctx.set_materialize_grads(False)   # an undefined gradient stays None: backward returns early
         x = x.contiguous()
         if residual is not None:
             residual = residual.contiguous()
@@ -256,6 +289,8 @@ class _InstNorm(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if dy is None:
+            return (None,) * 5
         dy = dy.contiguous()
         planes, hw, act, slope = ctx.cfg
         dx = None
@@ -278,6 +313,7 @@ def instance_norm(x, residual=None, act='none', slope=0.2, eps=1e-5):
 class _AvgPool3s2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
+        ctx.set_materialize_grads(False)   # an undefined gradient stays None: backward returns early
         x = x.contiguous()
         _chk(x)
         B, Cn, H, W = x.shape
@@ -289,6 +325,8 @@ class _AvgPool3s2(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if dy is None:
+            return None
         B, Cn, H, W, OH, OW = ctx.shape
         dy = dy.contiguous()
         dx = torch.empty((B, Cn, H, W), dtype=torch.float32, device=dy.device)
@@ -304,6 +342,7 @@ def avgpool3s2(x):
 class _MaxPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, k):
+        ctx.set_materialize_grads(False)   # an undefined gradient stays None: backward returns early
         x = x.contiguous()
         _chk(x)
         B, Cn, H, W = x.shape
@@ -314,6 +353,8 @@ class _MaxPool(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if dy is None:
+            return None, None
         x, k = ctx.x, ctx.k
         B, Cn, H, W = x.shape
         dy = dy.contiguous()
@@ -334,6 +375,7 @@ class _CatMask(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, mask, mode, *ts):
+        ctx.set_materialize_grads(False)   # an undefined gradient stays None: backward returns early
         ts = [t.contiguous() for t in ts]
         _chk(mask, *ts)
         B, _, H, W = ts[0].shape
@@ -349,6 +391,8 @@ class _CatMask(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        if dout is None:
+            return (None,) * (2 + len(ctx.chs))
         dout = dout.contiguous()
         B, Ctot, H, W = dout.shape
         st, c0, grads = _stream(), 0, []
@@ -377,6 +421,7 @@ class _Blend(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, a0, b, m):
+        ctx.set_materialize_grads(False)   # an undefined gradient stays None: backward returns early
         a, b, m = a.contiguous(), b.contiguous(), m.contiguous()
         _chk(a, b, m)
         B, Cn, H, W = b.shape
@@ -387,6 +432,8 @@ class _Blend(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        if dout is None:
+            return None, None, None, None
         dout = dout.contiguous()
         B, Cn, H, W = dout.shape
         st = _stream()
@@ -410,6 +457,7 @@ def blend(a, b, m, a0=0):
 class _Add(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
+        ctx.set_materialize_grads(False)   # an undefined gradient stays None: backward returns early
         a, b = a.contiguous(), b.contiguous()
         _chk(a, b)
         out = torch.empty_like(a)
@@ -479,6 +527,7 @@ def masked_mean_color(image, obj_mask, noise=None):
 class _L1Mean(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
+        ctx.set_materialize_grads(False)   # an undefined gradient stays None: backward returns early
         a, b = a.contiguous(), b.contiguous()
         _chk(a, b)
         if a.shape != b.shape:
@@ -492,6 +541,8 @@ class _L1Mean(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return None, None
         a, b = ctx.a, ctx.b
         g = g.contiguous()
         da = torch.empty_like(a)
@@ -507,6 +558,7 @@ def l1_mean(a, b):
 class _MSEConst(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, target):
+        ctx.set_materialize_grads(False)   # an undefined gradient stays None: backward returns early
         x = x.contiguous()
         _chk(x)
         out = torch.empty((), dtype=torch.float32, device=x.device)
@@ -518,6 +570,8 @@ class _MSEConst(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return None, None
         x = ctx.x
         g = g.contiguous()
         dx = torch.empty_like(x)
@@ -536,6 +590,7 @@ def mse_const(x, target):
 class _SNSigma(torch.autograd.Function):
     @staticmethod
     def forward(ctx, W, u):
+        ctx.set_materialize_grads(False)   # an undefined gradient stays None: backward returns early
         W2 = W.contiguous().view(W.shape[0], -1)
         u = u.detach().clone()      # the layer overwrites its persistent u in place after this call
         _chk(W2, u)
@@ -553,6 +608,8 @@ class _SNSigma(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, _gu):
+        if g is None:
+            return None, None
         W2 = ctx.W
         rows, cols = W2.shape
         g = g.contiguous()
@@ -573,6 +630,7 @@ def sn_max_singular_value(W, u):
 class _DivScalar(torch.autograd.Function):
     @staticmethod
     def forward(ctx, W, sigma):
+        ctx.set_materialize_grads(False)   # an undefined gradient stays None: backward returns early
         W = W.contiguous()
         sigma = sigma.contiguous()
         _chk(W, sigma)
@@ -583,6 +641,8 @@ class _DivScalar(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        if dout is None:
+            return None, None
         W, sigma = ctx.W, ctx.sigma
         dout = dout.contiguous()
         dW = torch.empty_like(W)
