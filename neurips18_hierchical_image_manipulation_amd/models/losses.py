@@ -33,11 +33,16 @@ class VGGLoss(nn.Module):
         self.vgg = Vgg19()
         self.weights = [1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0]
 
-    def forward(self, x, y):
+    def target_features(self, y):
+        """VGG features of the (detached) target; may be computed ahead of time on another stream."""
         import torch
-        x_vgg = self.vgg(x)
         with torch.no_grad():
-            y_vgg = self.vgg(y)
+            return self.vgg(y)
+
+    def forward(self, x, y, y_vgg=None):
+        x_vgg = self.vgg(x)
+        if y_vgg is None:
+            y_vgg = self.target_features(y)
         loss = 0
         for i in range(len(x_vgg)):
             loss = loss + self.weights[i] * ops.l1_mean(x_vgg[i], y_vgg[i])

@@ -177,6 +177,30 @@ class Pix2PixHDModel_condImg(BaseModel):
             x = self.fake_pool.query(x)
         return self.netD.forward(x)
 
+    def _real_branch_ahead(self, netD_cond, real_image, mask_cond):
+        """D(real) + LSGAN loss and VGG(real) on the side stream (None when disabled)."""
+        if os.environ.get('HIM_REAL_AHEAD', '1') == '0':
+            return None
+        main = torch.cuda.current_stream(self.device)
+        side = ops._side_stream(self.device)
+        side.wait_stream(main)
+        out = {'stream': side, 'y_vgg': None}
+        with torch.cuda.stream(side):
+            out['pred_real'] = self.discriminate(netD_cond, real_image, mask_cond, False)
+            out['loss_D_real'] = self.criterionGAN(out['pred_real'], True)
+            if not self.opt.no_vgg_loss:
+                out['y_vgg'] = self.criterionVGG.target_features(real_image)
+        # these tensors were allocated on the side stream and are read on the main one
+        for feats in out['pred_real']:
+            for t in feats:
+                t.record_stream(main)
+        out['loss_D_real'].record_stream(main)
+        for t in (out['y_vgg'] or []):
+            t.record_stream(main)
+        for t in (netD_cond, real_image, mask_cond):
+            t.record_stream(side)
+        return out
+
     def _generate(self, buf, input_mask, cond_image, mask_in):
         if self.netG_type == 'global':
             return self.netG.forward(buf, mask_in)
@@ -189,10 +213,16 @@ class Pix2PixHDModel_condImg(BaseModel):
         input_mask, inst_map, real_image, _, cond_image = self.encode_input(label, inst, image, feat, mask_in=mask_in,
                                                                            obj_mask=obj_mask)
         buf, n_label, n_cond, mask_in = self._enc
-        fake_image = self._generate(buf, input_mask, cond_image, mask_in)
-
         netD_cond = input_mask if self.no_imgCond else buf
         mask_cond = mask_in if not self.use_soft_mask else self._dev(mask_out)
+
+        # Everything that depends only on the REAL image (its discriminator pass and its VGG features) is independent
+        # of the generator: it runs on a side stream next to the generator forward and fills the matrix pipe where the
+        # one-tile-per-CU ResnetBlock launches leave it idle.
+        ahead = self._real_branch_ahead(netD_cond, real_image, mask_cond)
+        fake_image = self._generate(buf, input_mask, cond_image, mask_in)
+        if ahead is not None:
+            torch.cuda.current_stream(self.device).wait_stream(ahead['stream'])
 
         # Fake detection and loss / real detection and loss / GAN loss (:218-233).  The reference runs the discriminator
         # on the fake image twice -- once detached (loss_D_fake) and once attached (loss_G_GAN + feature matching) --
@@ -212,8 +242,11 @@ class Pix2PixHDModel_condImg(BaseModel):
             self._fake_gate = None
             pred_fake_pool = self.discriminate(netD_cond, fake_image, mask_cond, True)
         loss_D_fake = self.criterionGAN(pred_fake_pool, False)
-        pred_real = self.discriminate(netD_cond, real_image, mask_cond, False)
-        loss_D_real = self.criterionGAN(pred_real, True)
+        if ahead is not None:
+            pred_real, loss_D_real = ahead['pred_real'], ahead['loss_D_real']
+        else:
+            pred_real = self.discriminate(netD_cond, real_image, mask_cond, False)
+            loss_D_real = self.criterionGAN(pred_real, True)
         if not share:
             with frozen_params():
                 pred_fake = self.netD.forward(self._d_input(netD_cond, fake_image, mask_cond))
@@ -230,7 +263,8 @@ class Pix2PixHDModel_condImg(BaseModel):
 
         loss_G_VGG = torch.zeros(1, device=self.device)
         if not opt.no_vgg_loss:
-            loss_G_VGG = self.criterionVGG(fake_image, real_image) * opt.lambda_feat
+            loss_G_VGG = self.criterionVGG(fake_image, real_image,
+                                           ahead['y_vgg'] if ahead is not None else None) * opt.lambda_feat
         if opt.lambda_rec > 0:
             loss_G_GAN_Feat = loss_G_GAN_Feat + self.criterionFeat(fake_image, real_image) * opt.lambda_rec
 
