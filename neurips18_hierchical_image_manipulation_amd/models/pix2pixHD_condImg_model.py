@@ -364,23 +364,28 @@ class Pix2PixHDModel_condImg(BaseModel):
         finally:
             self._share_fake_pass = False
         loss_dict = self.combine_losses(losses)
-        if self.reducer_G is None:
-            self.backward_G()
-            if not self.opt.no_gan:
-                self.backward_D()
-        else:
-            self.optimizer_G.zero_grad()
+        # Same arithmetic as backward_G(); backward_D(), reordered: both arenas are zeroed first, the generator's Adam
+        # step (and its all-reduce) is deferred behind loss_D.backward() -- legal because loss_D's graph holds no
+        # generator parameter (the fake is detached / gated) -- so the tail of G's side-stream weight gradients (the
+        # 1 M-position stem and head layers) and the 730 MB gradient exchange hide under D's backward.
+        gan = not self.opt.no_gan
+        self.optimizer_G.zero_grad()
+        if gan:
+            self.optimizer_D.zero_grad()
+        if self.reducer_G is not None:
             self.reducer_G.begin()
-            self._run_backward_G()
-            if not self.opt.no_gan:
-                self.optimizer_D.zero_grad()
+        self._run_backward_G()
+        if gan:
+            if self.reducer_D is not None:
                 self.reducer_D.begin(contributions=2)
-                self._run_backward_D()
+            self._run_backward_D()
+        if self.reducer_G is not None:
             self.reducer_G.finish()
-            self.optimizer_G.step()
-            if not self.opt.no_gan:
+        self.optimizer_G.step()
+        if gan:
+            if self.reducer_D is not None:
                 self.reducer_D.finish()
-                self.optimizer_D.step()
+            self.optimizer_D.step()
         self.generated = generated
         return loss_dict
 
