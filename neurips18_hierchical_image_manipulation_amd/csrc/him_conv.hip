@@ -907,34 +907,36 @@ static long long setup_dgrad(GConvP& g, WTransP& wt, int Cout, int Cin, int KH, 
   return off;
 }
 
-// ---- reflection-pad backward: dx[y][x] = sum of dpad over the padded positions that mirror onto (y,x)
-__global__ void reflect_fold_kernel(const float* __restrict__ dpad, float* __restrict__ dx, int planes, int H,
-                                    int W, int p, int nslab, size_t slab_stride) {
-  // nslab > 1: dpad holds split-K partial slabs that are summed here (fixed order), saving the finish pass
+// ---- reflection-pad backward: dx[y][x] = sum of dpad over the padded positions that mirror onto (y,x).
+// grid = (ceil(H*W/256), planes): no 64-bit index arithmetic; nslab > 1 sums split-K partial slabs in fixed order.
+__global__ __launch_bounds__(256) void reflect_fold_kernel(const float* __restrict__ dpad, float* __restrict__ dx,
+                                                           int planes, int H, int W, int p, int nslab,
+                                                           size_t slab_stride) {
   const int PH = H + 2 * p, PW = W + 2 * p;
-  const long long total = (long long)planes * H * W;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int x = (int)(i % W);
-    const long long r = i / W;
-    const int y = (int)(r % H);
-    const long long pl = r / H;
-    int ys[3], xs[3], ny = 0, nx = 0;
-    ys[ny++] = y + p;
-    if (y >= 1 && y <= p) ys[ny++] = p - y;
-    if (y >= H - 1 - p && y <= H - 2) ys[ny++] = p + 2 * (H - 1) - y;
-    xs[nx++] = x + p;
-    if (x >= 1 && x <= p) xs[nx++] = p - x;
-    if (x >= W - 1 - p && x <= W - 2) xs[nx++] = p + 2 * (W - 1) - x;
-    const float* base = dpad + pl * PH * PW;
-    float s = 0.f;
-    for (int z = 0; z < nslab; ++z) {
-      const float* bz = base + (size_t)z * slab_stride;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= H * W) return;
+  const int y = i / W, x = i - y * W;
+  const int pl = blockIdx.y;
+  int ys[3], xs[3], ny = 0, nx = 0;
+  ys[ny++] = y + p;
+  if (y >= 1 && y <= p) ys[ny++] = p - y;
+  if (y >= H - 1 - p && y <= H - 2) ys[ny++] = p + 2 * (H - 1) - y;
+  xs[nx++] = x + p;
+  if (x >= 1 && x <= p) xs[nx++] = p - x;
+  if (x >= W - 1 - p && x <= W - 2) xs[nx++] = p + 2 * (W - 1) - x;
+  const float* __restrict__ base = dpad + (size_t)pl * PH * PW;
+  float s = 0.f;
+  for (int z = 0; z < nslab; ++z) {
+    const float* __restrict__ bz = base + (size_t)z * slab_stride;
+    float sz = bz[ys[0] * PW + xs[0]];  // the direct position: every thread, coalesced
+    if (ny + nx > 2) {
       for (int a = 0; a < ny; ++a)
-        for (int b = 0; b < nx; ++b) s += bz[ys[a] * PW + xs[b]];
+        for (int b = 0; b < nx; ++b)
+          if (a + b) sz += bz[ys[a] * PW + xs[b]];
     }
-    dx[i] = s;
+    s += sz;
   }
+  dx[(size_t)pl * H * W + i] = s;
 }
 
 // ==============================================================================================
@@ -1843,7 +1845,8 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
   if (refl) {
     const long long tot = (long long)d->B * d->Cin * d->H * d->W;
     const bool slabs = g.ksplit > 1;
-    hipLaunchKernelGGL(reflect_fold_kernel, dim3(std::min<long long>(cdiv(tot, 256), 16384)), dim3(256), 0, st,
+    (void)tot;
+    hipLaunchKernelGGL(reflect_fold_kernel, dim3(cdiv((long long)d->H * d->W, 256), d->B * d->Cin), dim3(256), 0, st,
                        (const float*)(slabs ? g.kpart : dpad), out, d->B * d->Cin, d->H, d->W, d->pad,
                        slabs ? g.ksplit : 1, (size_t)d->B * d->Cin * IH * IW);
     rc = check_launch("reflect_fold");

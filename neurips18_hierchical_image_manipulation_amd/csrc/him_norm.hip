@@ -77,32 +77,29 @@ __global__ __launch_bounds__(256) void instnorm_fwd_kernel(const float* __restri
     }
   } else {
     const bool vec = (hw & 3) == 0;
-    float s = 0.f;
+    // ONE statistics pass: sums of (x - c) and (x - c)^2 with c = the plane's first element (a value inside the data
+    // range, so E[(x-c)^2] - E[x-c]^2 loses at most a few ulps: |mean - c| ~ sigma), then the apply pass.
+    const float c0 = xp[0];
+    float s = 0.f, q = 0.f;
     if (vec) {
       const float4* x4 = (const float4*)xp;
       for (int i = tid; i < hw / 4; i += G) {
         const float4 a = x4[i];
-        s += (a.x + a.y) + (a.z + a.w);
-      }
-    } else {
-      for (int i = tid; i < hw; i += G) s += xp[i];
-    }
-    const float mu = group_sum<G>(s, sh) * inv_n;
-    float q = 0.f;
-    if (vec) {
-      const float4* x4 = (const float4*)xp;
-      for (int i = tid; i < hw / 4; i += G) {
-        const float4 a = x4[i];
-        const float d0 = a.x - mu, d1 = a.y - mu, d2 = a.z - mu, d3 = a.w - mu;
+        const float d0 = a.x - c0, d1 = a.y - c0, d2 = a.z - c0, d3 = a.w - c0;
+        s += (d0 + d1) + (d2 + d3);
         q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
       }
     } else {
       for (int i = tid; i < hw; i += G) {
-        const float d = xp[i] - mu;
+        const float d = xp[i] - c0;
+        s += d;
         q += d * d;
       }
     }
-    const float var = group_sum<G>(q, sh) * inv_n;
+    const float ms = group_sum<G>(s, sh) * inv_n;
+    const float mq = group_sum<G>(q, sh) * inv_n;
+    const float mu = c0 + ms;
+    const float var = fmaxf(mq - ms * ms, 0.f);
     const float rs = 1.f / sqrtf(var + eps);
     if (tid == 0) {
       mean[plane] = mu;
@@ -180,18 +177,48 @@ __global__ __launch_bounds__(256) void instnorm_bwd_kernel(const float* __restri
     }
   } else {
     float s1 = 0.f, s2 = 0.f;
-    for (int i = tid; i < hw; i += G) {
-      const float xh = (xp[i] - mu) * rs;
-      const float dz = gp[i] * act_grad_from_xhat(xh, act, slope);
-      s1 += dz;
-      s2 += dz * xh;
+    const bool vec = (hw & 3) == 0;
+    if (vec) {
+      const float4* x4 = (const float4*)xp;
+      const float4* g4 = (const float4*)gp;
+      for (int i = tid; i < hw / 4; i += G) {
+        const float4 a = x4[i], g = g4[i];
+        const float h0 = (a.x - mu) * rs, h1 = (a.y - mu) * rs, h2 = (a.z - mu) * rs, h3 = (a.w - mu) * rs;
+        const float z0 = g.x * act_grad_from_xhat(h0, act, slope), z1 = g.y * act_grad_from_xhat(h1, act, slope);
+        const float z2 = g.z * act_grad_from_xhat(h2, act, slope), z3 = g.w * act_grad_from_xhat(h3, act, slope);
+        s1 += (z0 + z1) + (z2 + z3);
+        s2 += (z0 * h0 + z1 * h1) + (z2 * h2 + z3 * h3);
+      }
+    } else {
+      for (int i = tid; i < hw; i += G) {
+        const float xh = (xp[i] - mu) * rs;
+        const float dz = gp[i] * act_grad_from_xhat(xh, act, slope);
+        s1 += dz;
+        s2 += dz * xh;
+      }
     }
     const float m1 = group_sum<G>(s1, sh) * inv_n;
     const float m2 = group_sum<G>(s2, sh) * inv_n;
-    for (int i = tid; i < hw; i += G) {
-      const float xh = (xp[i] - mu) * rs;
-      const float dz = gp[i] * act_grad_from_xhat(xh, act, slope);
-      op[i] = rs * (dz - m1 - xh * m2);
+    if (vec) {
+      const float4* x4 = (const float4*)xp;
+      const float4* g4 = (const float4*)gp;
+      float4* o4 = (float4*)op;
+      for (int i = tid; i < hw / 4; i += G) {
+        const float4 a = x4[i], g = g4[i];
+        const float h0 = (a.x - mu) * rs, h1 = (a.y - mu) * rs, h2 = (a.z - mu) * rs, h3 = (a.w - mu) * rs;
+        float4 o;
+        o.x = rs * (g.x * act_grad_from_xhat(h0, act, slope) - m1 - h0 * m2);
+        o.y = rs * (g.y * act_grad_from_xhat(h1, act, slope) - m1 - h1 * m2);
+        o.z = rs * (g.z * act_grad_from_xhat(h2, act, slope) - m1 - h2 * m2);
+        o.w = rs * (g.w * act_grad_from_xhat(h3, act, slope) - m1 - h3 * m2);
+        o4[i] = o;
+      }
+    } else {
+      for (int i = tid; i < hw; i += G) {
+        const float xh = (xp[i] - mu) * rs;
+        const float dz = gp[i] * act_grad_from_xhat(xh, act, slope);
+        op[i] = rs * (dz - m1 - xh * m2);
+      }
     }
   }
 }
