@@ -26,6 +26,7 @@
 namespace him {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define PAD_DFOLD 2  // internal pad mode of the fast kernel (see gconv_fast_kernel), never part of the C ABI
 typedef const __attribute__((address_space(1))) char* gchar_p;    // explicit global address space: keeps
 typedef const __attribute__((address_space(1))) float* gfloat_p;  // global_load (not flat_load) after asm laundering
 
@@ -71,7 +72,9 @@ struct GConvP {
 // k = 8*(lane>>5) + kp each lane's 8 operands of a K-step are two aligned ds_read_b128 (conflict-free at stride 20
 // dwords), and the tile writes are ds_write_b128 as well.  ~2 non-MFMA instructions per MFMA instead of ~19.
 // =============================================================================================
-template <int WM, int WN, int TM, int TN, bool REFLECT, bool CLAMPC>
+// PM: 0 zero padding, 1 reflection gather (forward of a reflect-padded conv), 2 = PAD_DFOLD: data gradient of a
+// reflect-pad-1 3x3 stride-1 conv read from the border-extended gradient built by reflect_extend_kernel (below).
+template <int WM, int WN, int TM, int TN, int PM, bool CLAMPC>
 __global__ __launch_bounds__(WM * WN * 64) void gconv_fast_kernel(const GConvP p) {
   constexpr int NT = WM * WN * 64;  // 4 waves (one per SIMD) or 8 waves (two per SIMD: they cover each other's LDS/barrier bubbles)
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 16, LD = 20;
@@ -159,7 +162,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_fast_kernel(const GConvP p
   {                                                                                                          \
     int iy = (YY) + c_jh * ddy, ix = (XX) + c_jw * ddx;                                                       \
     bool ok = true;                                                                                          \
-    if (REFLECT) {                                                                                           \
+    if (PM == 2) {                                                                                           \
+      const int Hh = SH - 2, Ww = SW - 2; /* rows/cols Hh, Hh+1 / Ww, Ww+1 hold the pre-summed mirror pairs */ \
+      ok = iy >= 0 && iy < Hh && ix >= 0 && ix < Ww;                                                          \
+      iy = (c_jh == 0 && iy == 2) ? Hh : iy;                                                                 \
+      iy = (c_jh == 2 && iy == Hh - 3) ? Hh + 1 : iy;                                                        \
+      ix = (c_jw == 0 && ix == 2) ? Ww : ix;                                                                 \
+      ix = (c_jw == 2 && ix == Ww - 3) ? Ww + 1 : ix;                                                        \
+      iy = min(max(iy, 0), SH - 1);                                                                          \
+      ix = min(max(ix, 0), SW - 1);                                                                          \
+    } else if (PM == 1) {                                                                                    \
       iy = iy < 0 ? -iy : iy;                                                                                \
       iy = iy >= SH ? 2 * (SH - 1) - iy : iy;                                                                \
       ix = ix < 0 ? -ix : ix;                                                                                \
@@ -332,12 +344,15 @@ template <int WM, int WN, int TM, int TN>
 static void launch_fast_cfg(const GConvP& p, dim3 grid, hipStream_t st) {
   const bool clampc = (p.C2 % 16) != 0;
   const dim3 blk(WM * WN * 64);
-  if (p.pad_mode == HIM_PAD_REFLECT) {
-    if (clampc) hipLaunchKernelGGL((gconv_fast_kernel<WM, WN, TM, TN, true, true>), grid, blk, 0, st, p);
-    else hipLaunchKernelGGL((gconv_fast_kernel<WM, WN, TM, TN, true, false>), grid, blk, 0, st, p);
+  if (p.pad_mode == PAD_DFOLD) {
+    if (clampc) hipLaunchKernelGGL((gconv_fast_kernel<WM, WN, TM, TN, 2, true>), grid, blk, 0, st, p);
+    else hipLaunchKernelGGL((gconv_fast_kernel<WM, WN, TM, TN, 2, false>), grid, blk, 0, st, p);
+  } else if (p.pad_mode == HIM_PAD_REFLECT) {
+    if (clampc) hipLaunchKernelGGL((gconv_fast_kernel<WM, WN, TM, TN, 1, true>), grid, blk, 0, st, p);
+    else hipLaunchKernelGGL((gconv_fast_kernel<WM, WN, TM, TN, 1, false>), grid, blk, 0, st, p);
   } else {
-    if (clampc) hipLaunchKernelGGL((gconv_fast_kernel<WM, WN, TM, TN, false, true>), grid, blk, 0, st, p);
-    else hipLaunchKernelGGL((gconv_fast_kernel<WM, WN, TM, TN, false, false>), grid, blk, 0, st, p);
+    if (clampc) hipLaunchKernelGGL((gconv_fast_kernel<WM, WN, TM, TN, 0, true>), grid, blk, 0, st, p);
+    else hipLaunchKernelGGL((gconv_fast_kernel<WM, WN, TM, TN, 0, false>), grid, blk, 0, st, p);
   }
 }
 
@@ -937,6 +952,30 @@ __global__ __launch_bounds__(256) void reflect_fold_kernel(const float* __restri
     s += sz;
   }
   dx[(size_t)pl * H * W + i] = s;
+}
+
+// ---- border-extended gradient for the folded reflect-pad-1 data gradient.  ReflectionPad2d(1) + conv3x3:
+// dx[y][x] = sum_t W_t^T sum_{(o_y,o_x) in R_th(y) x R_tw(x)} dy[o_y][o_x] with R_th(y) = {y+1-th} (if inside), plus
+// {0} when (y,th) = (1,0) and {H-1} when (y,th) = (H-2,2): the mirrored pad row feeds the neighbour of the border.
+// The pair sums are materialised once as two extra rows / columns so that the MFMA kernel still gathers ONE element:
+// ext[r][c], r in [0,H+2): rows 0..H-1 = dy, row H = dy[0]+dy[2], row H+1 = dy[H-3]+dy[H-1]; columns likewise.
+__global__ __launch_bounds__(256) void reflect_extend_kernel(const float* __restrict__ dy, float* __restrict__ ext,
+                                                             int H, int W) {
+  const int EH = H + 2, EW = W + 2;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= EH * EW) return;
+  const int r = i / EW, c = i - r * EW;
+  const float* __restrict__ src = dy + (size_t)blockIdx.y * H * W;
+  const int r0 = r < H ? r : (r == H ? 0 : H - 3), r1 = r < H ? -1 : (r == H ? 2 : H - 1);
+  const int c0 = c < W ? c : (c == W ? 0 : W - 3), c1 = c < W ? -1 : (c == W ? 2 : W - 1);
+  float v = src[r0 * W + c0];
+  if (c1 >= 0) v += src[r0 * W + c1];
+  if (r1 >= 0) {
+    float u = src[r1 * W + c0];
+    if (c1 >= 0) u += src[r1 * W + c1];
+    v += u;
+  }
+  ext[(size_t)blockIdx.y * EH * EW + i] = v;
 }
 
 // ==============================================================================================
@@ -1748,16 +1787,24 @@ static int run_fprop(const HimConv2d* d, const float* x, const float* w, const f
 
 // data gradient of the conv described by `d` (also the forward of its transposed conv):
 // out (B,Cin,H,W) = sum W * g (B,Cout,OH,OW); for reflect mode goes through the padded gradient + fold.
+// reflect-pad-1 3x3 stride-1 (every ResnetBlock conv): gather from the border-extended gradient, no padded GEMM columns
+static bool dfold_ok(const HimConv2d* d) {
+  static int off = -1;
+  if (off < 0) off = getenv("HIM_NO_DFOLD") ? 1 : 0;
+  return !off && d->pad_mode == HIM_PAD_REFLECT && d->pad == 1 && d->KH == 3 && d->KW == 3 && d->stride == 1 &&
+         d->H >= 3 && d->W >= 3 && d->OH == d->H && d->OW == d->W && use_fast(d->Cin, d->Cout);
+}
 static int dgrad_ksplit(const HimConv2d* d) {
   if (d->stride != 1 || !use_fast(d->Cin, d->Cout)) return 1;
-  const bool refl = d->pad_mode == HIM_PAD_REFLECT;
+  const bool refl = d->pad_mode == HIM_PAD_REFLECT && !dfold_ok(d);
   const long long N = (long long)d->B * (refl ? d->H + 2 * d->pad : d->H) * (refl ? d->W + 2 * d->pad : d->W);
   return fast_ksplit(d->Cin, N, d->KH * d->KW * (pad16(d->Cout) / 16));
 }
 static size_t dgrad_ws_bytes(const HimConv2d* d) {
   size_t n = (size_t)d->Cin * pad16(d->Cout) * d->KH * d->KW + 64;
   const size_t outn = (size_t)d->B * d->Cin * (d->H + 2 * d->pad) * (d->W + 2 * d->pad);
-  if (d->pad_mode == HIM_PAD_REFLECT) n += outn + 64;
+  if (dfold_ok(d)) n += (size_t)d->B * d->Cout * (d->OH + 2) * (d->OW + 2) + 64;
+  else if (d->pad_mode == HIM_PAD_REFLECT) n += outn + 64;
   const int ks = dgrad_ksplit(d);
   if (ks > 1) n += (size_t)ks * outn + 64;
   return n * sizeof(float) + 256;
@@ -1767,7 +1814,8 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
   const size_t need = dgrad_ws_bytes(d);
   if (!ws || ws_bytes < need) return fail(HIM_E_WORKSPACE, "dgrad needs %zu ws bytes, got %zu", need, ws_bytes);
   float* Wt = (float*)ws;
-  const bool refl = d->pad_mode == HIM_PAD_REFLECT;
+  const bool dfold = dfold_ok(d);
+  const bool refl = d->pad_mode == HIM_PAD_REFLECT && !dfold;
   const bool fast = use_fast(d->Cin, d->Cout);
   GConvP g;
   memset(&g, 0, sizeof(g));
@@ -1776,6 +1824,7 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
   wt.W = w;
   const int IH = refl ? d->H + 2 * d->pad : d->H, IW = refl ? d->W + 2 * d->pad : d->W;
   long long nw = setup_dgrad(g, wt, d->Cout, d->Cin, d->KH, d->KW, d->stride, refl ? 0 : d->pad, IH, IW, Wt);
+  if (dfold) g.pad_mode = PAD_DFOLD;
   WT2P t2;
   if (fast) {  // regroup tap-major with the Cout axis padded to 16: At_q[ci][(jh*JW+jw)*Cop + co]
     memset(&t2, 0, sizeof(t2));
@@ -1808,18 +1857,19 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
     if (ks > 1) {
       const size_t outn = (size_t)d->B * d->Cin * IH * IW;
       g.ksplit = ks;
-      g.kpart = dpad + (refl ? ((outn + 63) / 64) * 64 : 0);
+      const size_t extn = dfold ? (size_t)d->B * d->Cout * (d->OH + 2) * (d->OW + 2) : 0;
+      g.kpart = dpad + (refl ? ((outn + 63) / 64) * 64 : ((extn + 63) / 64) * 64);
       g.kno_finish = refl ? 1 : 0;
     }
   }
-  g.src = gy;
+  g.src = dfold ? dpad : gy;
   g.dst = refl ? dpad : out;
   g.bias = refl ? nullptr : bias;
   g.M = d->Cin;
   g.C2 = d->Cout;
   g.B = d->B;
-  g.SH = d->OH;
-  g.SW = d->OW;
+  g.SH = dfold ? d->OH + 2 : d->OH;
+  g.SW = dfold ? d->OW + 2 : d->OW;
   g.DH = IH;
   g.DW = IW;
   g.act = refl ? HIM_ACT_NONE : act;
@@ -1840,6 +1890,12 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
     rc = check_launch("wtrans");
   }
   if (rc) return rc;
+  if (dfold) {
+    hipLaunchKernelGGL(reflect_extend_kernel, dim3(cdiv((long long)(d->OH + 2) * (d->OW + 2), 256), d->B * d->Cout),
+                       dim3(256), 0, st, gy, dpad, d->OH, d->OW);
+    rc = check_launch("reflect_extend");
+    if (rc) return rc;
+  }
   rc = launch_gconv(g, st);
   if (rc) return rc;
   if (refl) {

@@ -50,6 +50,10 @@ CONV_CASES = [
     (2, 3, 16, 32, 64, 3, 1, 1, 'zero', 'relu'),         # VGG conv1_1 + bias + ReLU
     (1, 256, 8, 16, 256, 3, 1, 1, 'zero', 'relu'),       # VGG mid
     (3, 8, 5, 7, 8, 3, 1, 1, 'reflect', 'none'),         # tiny everything
+    (1, 16, 3, 3, 16, 3, 1, 1, 'reflect', 'none'),       # folded reflect dgrad: both mirror rows hit y = 1
+    (2, 20, 4, 5, 24, 3, 1, 1, 'reflect', 'none'),       # folded reflect dgrad, channel tails (Cout 24)
+    (1, 32, 2, 4, 16, 3, 1, 1, 'reflect', 'none'),       # H = 2: padded-gradient + fold fallback
+    (2, 256, 16, 32, 256, 3, 1, 1, 'reflect', 'none'),   # folded reflect dgrad under split-K
 ]
 
 
