@@ -614,8 +614,15 @@ __global__ __launch_bounds__(256) void gconv_small_kernel(const GConvP p) {
   const int Ntot = p.B * plane;
   // wave-uniform channel slice (NPB is a multiple of 64): keeps the weight reads on the scalar unit
   const int cs = CS > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x / NPB) : 0;
-  const int n = blockIdx.x * NPB + threadIdx.x % NPB;
-  if (blockIdx.x * NPB >= Ntot) return;
+  // XCD-aware block order (workgroup L runs on XCD L % 8): each XCD gets a CONTIGUOUS band of positions, so vertically
+  // adjacent rows -- which share KH-1 of their KH input rows -- are served by the same L2
+  int blk = blockIdx.x;
+  {
+    const int total = gridDim.x, q = total >> 3, r = total & 7, xcd = blk & 7, slot = blk >> 3;
+    blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int n = blk * NPB + threadIdx.x % NPB;
+  if (blk * NPB >= Ntot) return;
   const int nc = min(n, Ntot - 1);
   const int b = nc / plane;
   const int rr = nc - b * plane;
@@ -650,41 +657,45 @@ __global__ __launch_bounds__(256) void gconv_small_kernel(const GConvP p) {
     ixs[j] = ix;
     okx[j] = ok;
   }
-  for (int jh = 0; jh < JH; ++jh) {
-    int iy = by + jh * p.dy;
-    bool oky = true;
-    if (REFLECT) {
-      iy = iy < 0 ? -iy : iy;
-      iy = iy >= SH ? 2 * (SH - 1) - iy : iy;
-    } else {
-      const int cy = min(max(iy, 0), SH - 1);
-      oky = cy == iy;
-      iy = cy;
-    }
-    const float* __restrict__ row = src + (size_t)iy * SW;
-    // channel range of this thread: grid.y slices (partials summed by gconv_small_finish_kernel) x CS in-block slices
-    const int nsl = gridDim.y * CS, sl = blockIdx.y * CS + cs;
-    const int cchunk = (C2 + nsl - 1) / nsl;
-    const int cbeg = sl * cchunk, cend = min(C2, cbeg + cchunk);
-#define HIM_SMALL_BODY()                                                                      \
-  {                                                                                           \
-    const float* __restrict__ r = row + (size_t)c2 * SH * SW;                                 \
-    const int kb = (c2 * JH + jh) * JW;                                                       \
-    _Pragma("unroll") for (int j = 0; j < MAXJ; ++j) {                                        \
-      if (TJ == 0 && j >= JW) break;                                                          \
-      float v = r[ixs[j]];                                                                    \
-      v = (oky && okx[j]) ? v : 0.f;                                                          \
+  // channel range of this thread: grid.y slices (partials summed by gconv_small_finish_kernel) x CS in-block slices
+  const int nsl = gridDim.y * CS, sl = blockIdx.y * CS + cs;
+  const int cchunk = (C2 + nsl - 1) / nsl;
+  const int cbeg = sl * cchunk, cend = min(C2, cbeg + cchunk);
+  // channel OUTER, tap rows inner: the KH rows of one channel plane are read back to back (L1/L2 reuse across the
+  // vertical neighbours), instead of sweeping all channels once per tap row
+#define HIM_SMALL_ROW()                                                                                  \
+  {                                                                                                      \
+    int iy = by + jh * p.dy;                                                                             \
+    bool oky = true;                                                                                     \
+    if (REFLECT) {                                                                                       \
+      iy = iy < 0 ? -iy : iy;                                                                            \
+      iy = iy >= SH ? 2 * (SH - 1) - iy : iy;                                                            \
+      iy = min(max(iy, 0), SH - 1);                                                                      \
+    } else {                                                                                             \
+      const int cy = min(max(iy, 0), SH - 1);                                                            \
+      oky = cy == iy;                                                                                    \
+      iy = cy;                                                                                           \
+    }                                                                                                    \
+    const float* __restrict__ r = pl + iy * SW;                                                          \
+    const int kb = kc + jh * JW;                                                                         \
+    _Pragma("unroll") for (int j = 0; j < MAXJ; ++j) {                                                   \
+      if (TJ == 0 && j >= JW) break;                                                                     \
+      float v = r[ixs[j]];                                                                               \
+      v = (oky && okx[j]) ? v : 0.f;                                                                     \
       _Pragma("unroll") for (int m = 0; m < MM; ++m) acc[m] = fmaf(A[(size_t)m * K + kb + j], v, acc[m]); \
-    }                                                                                         \
+    }                                                                                                    \
   }
-    if (TJ > 0 && TJ <= 4) {  // short tap rows: keep 4 channels of loads in flight
-#pragma unroll 4
-      for (int c2 = cbeg; c2 < cend; ++c2) HIM_SMALL_BODY()
+  for (int c2 = cbeg; c2 < cend; ++c2) {
+    const float* __restrict__ pl = src + (size_t)c2 * SH * SW;
+    const int kc = c2 * JH * JW;
+    if (TJ > 0 && TJ <= 4) {  // short tap rows: all KH*KW loads of a channel in flight
+#pragma unroll
+      for (int jh = 0; jh < TJ; ++jh) HIM_SMALL_ROW()
     } else {
-      for (int c2 = cbeg; c2 < cend; ++c2) HIM_SMALL_BODY()
+      for (int jh = 0; jh < JH; ++jh) HIM_SMALL_ROW()
     }
-#undef HIM_SMALL_BODY
   }
+#undef HIM_SMALL_ROW
   if (CS > 1) {
 #pragma unroll
     for (int m = 0; m < MM; ++m) red[threadIdx.x * MM + m] = acc[m];
@@ -1344,6 +1355,7 @@ static void wgrad_fast_cfg(int M, int C, int Kdim, int KK, int* BM, int* BN, int
   if (s > maxs) s = maxs;
   if (s < 1) s = 1;
   if (s > 256) s = 256;
+  if (getenv("HIM_WGRAD_SPLITS")) s = std::max(1, std::min(maxs, atoi(getenv("HIM_WGRAD_SPLITS"))));
   *splits = s;
 }
 

@@ -366,8 +366,8 @@ class Pix2PixHDModel_condImg(BaseModel):
         loss_dict = self.combine_losses(losses)
         # Same arithmetic as backward_G(); backward_D(), reordered: both arenas are zeroed first, the generator's Adam
         # step (and its all-reduce) is deferred behind loss_D.backward() -- legal because loss_D's graph holds no
-        # generator parameter (the fake is detached / gated) -- so the tail of G's side-stream weight gradients (the
-        # 1 M-position stem and head layers) and the 730 MB gradient exchange hide under D's backward.
+        # generator parameter (the fake is detached / gated) -- so the 730 MB gradient exchange and G's Adam step hide
+        # under D's backward.
         gan = not self.opt.no_gan
         self.optimizer_G.zero_grad()
         if gan:
@@ -375,13 +375,20 @@ class Pix2PixHDModel_condImg(BaseModel):
         if self.reducer_G is not None:
             self.reducer_G.begin()
         self._run_backward_G()
+        # G's exchange + Adam step (5 GB of HBM traffic, no matrix work) go to their own stream: they wait for G's
+        # data-gradient chain (main) and weight gradients (side stream), then run under D's backward
+        main = torch.cuda.current_stream(self.device)
+        opt_stream = ops._opt_stream(self.device)
+        opt_stream.wait_stream(main)
+        with torch.cuda.stream(opt_stream):
+            if self.reducer_G is not None:
+                self.reducer_G.finish()
+            self.optimizer_G.step()
         if gan:
             if self.reducer_D is not None:
                 self.reducer_D.begin(contributions=2)
             self._run_backward_D()
-        if self.reducer_G is not None:
-            self.reducer_G.finish()
-        self.optimizer_G.step()
+        main.wait_stream(opt_stream)
         if gan:
             if self.reducer_D is not None:
                 self.reducer_D.finish()

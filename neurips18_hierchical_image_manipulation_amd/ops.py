@@ -64,6 +64,17 @@ def _side_stream(device):
     return s
 
 
+_OPT = {}
+
+
+def _opt_stream(device):
+    """Stream of the generator's optimizer step (runs next to the discriminator's backward)."""
+    s = _OPT.get(device)
+    if s is None:
+        s = _OPT[device] = torch.cuda.Stream(device=device)
+    return s
+
+
 def join_side_stream(device=None):
     for dev, s in _SIDE.items():
         if device is None or dev == device:

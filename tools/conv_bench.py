@@ -21,6 +21,7 @@ SHAPES = [
     ('d_41_64_s2', 8, 41, 256, 512, 64, 4, 2, 2, 'zero'),
     ('d_head', 8, 512, 34, 66, 1, 4, 1, 2, 'zero'),
     ('g_head', 8, 64, 256, 512, 3, 7, 1, 3, 'reflect'),
+    ('vgg_3_64', 8, 3, 256, 512, 64, 3, 1, 1, 'zero'),
 ]
 
 
