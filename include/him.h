@@ -95,6 +95,37 @@ int him_deconv2d_bwd_weight(const HimDeconv2d* d, const float* x, const float* d
                             int accumulate, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Weight panels.  The MFMA kernels read the weights regrouped (forward: [Cout][Cin/16][KH][KW][16]; data
+ * gradient: the transpose, per stride phase).  The plain entry points above rebuild that panel inside the
+ * workspace on EVERY launch (75 MB of HBM traffic for a 1024x1024x3x3 ResnetBlock conv); weights only change
+ * once per optimizer step, so a trainer builds each panel once after the Adam update (on a side stream, under
+ * the other network's backward) and calls the *_panel variants.  torch.nn has no counterpart: cuDNN/MIOpen
+ * hide the same transform inside their "find"/workspace logic (reference call sites: every nn.Conv2d /
+ * nn.ConvTranspose2d of models/Pix2Pix_NET.py:63-135, models/Discriminator_NET.py:62-125,
+ * models/layer_util.py:340-378,400-440).
+ *   kind HIM_PANEL_FWD      -> consumed by him_conv2d_fwd_panel      / him_deconv2d_fwd_panel
+ *   kind HIM_PANEL_BWD_DATA -> consumed by him_conv2d_bwd_data_panel / him_deconv2d_bwd_data_panel
+ * *_panel_bytes returns 0 when that kernel reads the raw weights (Cout <= 4 heads, Cin < 16 stems):
+ * use the plain entry point.  Workspace sizes are those of the plain entry points.
+ * -------------------------------------------------------------------------------------------*/
+#define HIM_PANEL_FWD 0
+#define HIM_PANEL_BWD_DATA 1
+size_t him_conv2d_panel_bytes(const HimConv2d* d, int kind);
+int him_conv2d_panel_build(const HimConv2d* d, int kind, const float* w, void* panel, size_t panel_bytes,
+                           void* stream);
+int him_conv2d_fwd_panel(const HimConv2d* d, const float* x, const void* panel, const float* bias, float* y,
+                         void* ws, size_t ws_bytes, void* stream);
+int him_conv2d_bwd_data_panel(const HimConv2d* d, const float* dy, const void* panel, float* dx, void* ws,
+                              size_t ws_bytes, void* stream);
+size_t him_deconv2d_panel_bytes(const HimDeconv2d* d, int kind);
+int him_deconv2d_panel_build(const HimDeconv2d* d, int kind, const float* w, void* panel, size_t panel_bytes,
+                             void* stream);
+int him_deconv2d_fwd_panel(const HimDeconv2d* d, const float* x, const void* panel, const float* bias, float* y,
+                           void* ws, size_t ws_bytes, void* stream);
+int him_deconv2d_bwd_data_panel(const HimDeconv2d* d, const float* dy, const void* panel, float* dx, void* ws,
+                                size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * InstanceNorm2d(affine=False, eps) fused with the activation behind it and, for the second half of a
  * ResnetBlock, the residual add.  Replaces get_norm_layer('instance') models/layer_util.py:19-26 and
  * the `x + conv_block(x)` of models/layer_util.py:376-378.  Per-(n,c) reductions are wave64 shuffles.

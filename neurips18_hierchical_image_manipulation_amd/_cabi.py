@@ -46,6 +46,14 @@ _SIGS = {
     'him_deconv2d_bwd_data': (c_int, [_DECONV, P, P, P, P, c_size_t, P]),
     'him_deconv2d_bwd_weight_ws': (c_size_t, [_DECONV]),
     'him_deconv2d_bwd_weight': (c_int, [_DECONV, P, P, P, P, c_int, P, c_size_t, P]),
+    'him_conv2d_panel_bytes': (c_size_t, [_CONV, c_int]),
+    'him_conv2d_panel_build': (c_int, [_CONV, c_int, P, P, c_size_t, P]),
+    'him_conv2d_fwd_panel': (c_int, [_CONV, P, P, P, P, P, c_size_t, P]),
+    'him_conv2d_bwd_data_panel': (c_int, [_CONV, P, P, P, P, c_size_t, P]),
+    'him_deconv2d_panel_bytes': (c_size_t, [_DECONV, c_int]),
+    'him_deconv2d_panel_build': (c_int, [_DECONV, c_int, P, P, c_size_t, P]),
+    'him_deconv2d_fwd_panel': (c_int, [_DECONV, P, P, P, P, P, c_size_t, P]),
+    'him_deconv2d_bwd_data_panel': (c_int, [_DECONV, P, P, P, P, c_size_t, P]),
     'him_instnorm_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_float, c_int, c_float, P]),
     'him_instnorm_bwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_float, P]),
     'him_act_bwd': (c_int, [P, P, P, c_size_t, c_int, c_float, P]),

@@ -1749,8 +1749,14 @@ static size_t fprop_ws_bytes(const HimConv2d* d) {
   const size_t wts = ((size_t)d->Cout * d->KH * d->KW * pad16(d->Cin) * sizeof(float) + 255) / 256 * 256;
   return wts + (ks > 1 ? (size_t)ks * d->B * d->Cout * d->OH * d->OW * sizeof(float) : 0) + 256;
 }
+// floats of the regrouped weight panel the forward kernel reads (0: it reads the raw weights)
+static size_t fprop_panel_floats(const HimConv2d* d) {
+  if (small_split_ok(d) || d->Cout <= 4 || !use_fast(d->Cout, d->Cin)) return 0;
+  return (size_t)d->Cout * d->KH * d->KW * pad16(d->Cin);
+}
+// panel == nullptr: regroup the weights into the workspace on every call; build_only: write the panel to ws and return
 static int run_fprop(const HimConv2d* d, const float* x, const float* w, const float* bias, float* y, void* ws,
-                     size_t ws_bytes, hipStream_t st) {
+                     size_t ws_bytes, hipStream_t st, const float* panel = nullptr, bool build_only = false) {
   GConvP g;
   fill_fprop(g, d, x, w, bias, y);
   if (small_split_ok(d)) {
@@ -1759,7 +1765,7 @@ static int run_fprop(const HimConv2d* d, const float* x, const float* w, const f
     g.small_nsplit = SMALL_NSPLIT;
   }
   if (use_fast(d->Cout, d->Cin)) {
-    const size_t need = fprop_ws_bytes(d);
+    const size_t need = build_only ? fprop_panel_floats(d) * sizeof(float) : fprop_ws_bytes(d);
     if (!ws || ws_bytes < need) return fail(HIM_E_WORKSPACE, "conv fwd needs %zu ws bytes, got %zu", need, ws_bytes);
     WT2P t;
     memset(&t, 0, sizeof(t));
@@ -1777,15 +1783,17 @@ static int run_fprop(const HimConv2d* d, const float* x, const float* w, const f
     t.ph[0].sw = 1;
     t.ph[0].base = 0;
     t.ph[0].total = (long long)d->Cout * KK * t.C2p;
-    if (KK <= 64)
-      hipLaunchKernelGGL(wt_fwd_kernel, dim3(t.C2p / 16, d->Cout), dim3(64), 0, st, w, (float*)ws, d->Cout, d->Cin,
-                         t.C2p / 16, KK);
-    else
-      hipLaunchKernelGGL(wtrans2_kernel, dim3(std::min<long long>(cdiv(t.ph[0].total, 256), 4096), 1), dim3(256), 0, st, t);
-    int rc = check_launch("wtrans2");
-    if (rc) return rc;
+    if (!panel) {
+      if (KK <= 64)
+        hipLaunchKernelGGL(wt_fwd_kernel, dim3(t.C2p / 16, d->Cout), dim3(64), 0, st, w, (float*)ws, d->Cout, d->Cin,
+                           t.C2p / 16, KK);
+      else
+        hipLaunchKernelGGL(wtrans2_kernel, dim3(std::min<long long>(cdiv(t.ph[0].total, 256), 4096), 1), dim3(256), 0, st, t);
+      int rc = check_launch("wtrans2");
+      if (rc || build_only) return rc;
+    }
     g.fast = 1;
-    g.ph[0].At = (const float*)ws;
+    g.ph[0].At = panel ? panel : (const float*)ws;
     g.ph[0].C2p = t.C2p;
     const int ks = fast_ksplit(d->Cout, (long long)d->B * d->OH * d->OW, KK * (t.C2p / 16));
     if (ks > 1) {
@@ -1821,11 +1829,16 @@ static size_t dgrad_ws_bytes(const HimConv2d* d) {
   if (ks > 1) n += (size_t)ks * outn + 64;
   return n * sizeof(float) + 256;
 }
+static size_t dgrad_panel_floats(const HimConv2d* d) {
+  return (size_t)d->Cin * (use_fast(d->Cin, d->Cout) ? pad16(d->Cout) : d->Cout) * d->KH * d->KW;
+}
+// panel == nullptr: regroup the weights into the workspace on every call; build_only: write the panel to ws and return
 static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float* out, const float* bias, int act,
-                     float slope, void* ws, size_t ws_bytes, hipStream_t st) {
-  const size_t need = dgrad_ws_bytes(d);
+                     float slope, void* ws, size_t ws_bytes, hipStream_t st, const float* panel = nullptr,
+                     bool build_only = false) {
+  const size_t need = build_only ? dgrad_panel_floats(d) * sizeof(float) : dgrad_ws_bytes(d);
   if (!ws || ws_bytes < need) return fail(HIM_E_WORKSPACE, "dgrad needs %zu ws bytes, got %zu", need, ws_bytes);
-  float* Wt = (float*)ws;
+  float* Wt = panel ? (float*)panel : (float*)ws;
   const bool dfold = dfold_ok(d);
   const bool refl = d->pad_mode == HIM_PAD_REFLECT && !dfold;
   const bool fast = use_fast(d->Cin, d->Cout);
@@ -1863,7 +1876,7 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
     nw = off;
     g.fast = 1;
   }
-  float* dpad = Wt + ((nw + 63) / 64) * 64;
+  float* dpad = (float*)ws + ((nw + 63) / 64) * 64;
   if (fast && g.nphase == 1) {
     const int ks = dgrad_ksplit(d);
     if (ks > 1) {
@@ -1886,8 +1899,10 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
   g.DW = IW;
   g.act = refl ? HIM_ACT_NONE : act;
   g.slope = slope;
-  int rc;
-  if (fast) {
+  int rc = HIM_OK;
+  if (panel) {
+    // weights already regrouped by a build_only call
+  } else if (fast) {
     if (d->stride == 1 && d->KH * d->KW <= 49) {
       hipLaunchKernelGGL(wt_dgrad_kernel, dim3(cdiv(d->Cin, 16), pad16(d->Cout) / 16), dim3(256), 0, st, w, Wt, d->Cout,
                          d->Cin, pad16(d->Cout) / 16, d->KH * d->KW);
@@ -1901,7 +1916,7 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
     hipLaunchKernelGGL(wtrans_kernel, dim3(std::min<long long>(cdiv(nw, 256), 8192)), dim3(256), 0, st, wt);
     rc = check_launch("wtrans");
   }
-  if (rc) return rc;
+  if (rc || build_only) return rc;
   if (dfold) {
     hipLaunchKernelGGL(reflect_extend_kernel, dim3(cdiv((long long)(d->OH + 2) * (d->OW + 2), 256), d->B * d->Cout),
                        dim3(256), 0, st, gy, dpad, d->OH, d->OW);
@@ -1971,6 +1986,41 @@ int him_conv2d_bwd_data(const HimConv2d* d, const float* dy, const float* w, flo
   return run_dgrad(d, dy, w, dx, nullptr, HIM_ACT_NONE, 0.f, ws, ws_bytes, (hipStream_t)stream);
 }
 
+size_t him_conv2d_panel_bytes(const HimConv2d* d, int kind) {
+  if (!d || check_conv(d)) return 0;
+  return (kind == HIM_PANEL_FWD ? fprop_panel_floats(d) : dgrad_panel_floats(d)) * sizeof(float);
+}
+
+int him_conv2d_panel_build(const HimConv2d* d, int kind, const float* w, void* panel, size_t panel_bytes,
+                           void* stream) {
+  int rc = check_conv(d);
+  if (rc) return rc;
+  if (kind == HIM_PANEL_FWD) {
+    if (!fprop_panel_floats(d)) return fail(HIM_E_UNSUPPORTED, "this conv's forward reads the raw weights: no panel");
+    return run_fprop(d, nullptr, w, nullptr, nullptr, panel, panel_bytes, (hipStream_t)stream, nullptr, true);
+  }
+  if (kind != HIM_PANEL_BWD_DATA) return fail(HIM_E_INVALID, "panel kind %d", kind);
+  return run_dgrad(d, nullptr, w, nullptr, nullptr, HIM_ACT_NONE, 0.f, panel, panel_bytes, (hipStream_t)stream, nullptr,
+                   true);
+}
+
+int him_conv2d_fwd_panel(const HimConv2d* d, const float* x, const void* panel, const float* bias, float* y, void* ws,
+                         size_t ws_bytes, void* stream) {
+  int rc = check_conv(d);
+  if (rc) return rc;
+  if (!panel || !fprop_panel_floats(d)) return fail(HIM_E_INVALID, "conv fwd: no panel for this descriptor");
+  return run_fprop(d, x, nullptr, bias, y, ws, ws_bytes, (hipStream_t)stream, (const float*)panel);
+}
+
+int him_conv2d_bwd_data_panel(const HimConv2d* d, const float* dy, const void* panel, float* dx, void* ws,
+                              size_t ws_bytes, void* stream) {
+  int rc = check_conv(d);
+  if (rc) return rc;
+  if (!panel) return fail(HIM_E_INVALID, "conv bwd_data: null panel");
+  return run_dgrad(d, dy, nullptr, dx, nullptr, HIM_ACT_NONE, 0.f, ws, ws_bytes, (hipStream_t)stream,
+                   (const float*)panel);
+}
+
 size_t him_conv2d_bwd_weight_ws(const HimConv2d* d) {
   return d ? wgrad_ws_bytes(d->Cout, d->Cin, d->KH, d->KW, d->B * d->OH * d->OW, d->Cout) : 0;
 }
@@ -2020,6 +2070,40 @@ int him_deconv2d_bwd_data(const HimDeconv2d* t, const float* dy, const float* w,
   int rc = adjoint_of(t, &c);
   if (rc) return rc;
   return run_fprop(&c, dy, w, nullptr, dx, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// ConvTranspose2d: the forward IS the adjoint conv's data gradient and vice versa, so the panel kinds swap
+size_t him_deconv2d_panel_bytes(const HimDeconv2d* t, int kind) {
+  HimConv2d c;
+  if (adjoint_of(t, &c)) return 0;
+  return him_conv2d_panel_bytes(&c, kind == HIM_PANEL_FWD ? HIM_PANEL_BWD_DATA : HIM_PANEL_FWD);
+}
+
+int him_deconv2d_panel_build(const HimDeconv2d* t, int kind, const float* w, void* panel, size_t panel_bytes,
+                             void* stream) {
+  HimConv2d c;
+  int rc = adjoint_of(t, &c);
+  if (rc) return rc;
+  return him_conv2d_panel_build(&c, kind == HIM_PANEL_FWD ? HIM_PANEL_BWD_DATA : HIM_PANEL_FWD, w, panel, panel_bytes,
+                                stream);
+}
+
+int him_deconv2d_fwd_panel(const HimDeconv2d* t, const float* x, const void* panel, const float* bias, float* y,
+                           void* ws, size_t ws_bytes, void* stream) {
+  HimConv2d c;
+  int rc = adjoint_of(t, &c);
+  if (rc) return rc;
+  if (!panel) return fail(HIM_E_INVALID, "deconv fwd: null panel");
+  return run_dgrad(&c, x, nullptr, y, bias, t->act, t->slope, ws, ws_bytes, (hipStream_t)stream, (const float*)panel);
+}
+
+int him_deconv2d_bwd_data_panel(const HimDeconv2d* t, const float* dy, const void* panel, float* dx, void* ws,
+                                size_t ws_bytes, void* stream) {
+  HimConv2d c;
+  int rc = adjoint_of(t, &c);
+  if (rc) return rc;
+  if (!panel || !fprop_panel_floats(&c)) return fail(HIM_E_INVALID, "deconv bwd_data: no panel for this descriptor");
+  return run_fprop(&c, dy, nullptr, nullptr, dx, ws, ws_bytes, (hipStream_t)stream, (const float*)panel);
 }
 
 size_t him_deconv2d_bwd_weight_ws(const HimDeconv2d* t) {

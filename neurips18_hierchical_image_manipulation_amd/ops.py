@@ -151,6 +151,74 @@ def _conv_desc(x, w, stride, pad, pad_mode, act, slope):
     return HimConv2d(B, Cin, H, W, Cout, KH, KW, stride, pad, pad_mode, OH, OW, act, slope)
 
 
+# Weight panels: the MFMA kernels read the weights regrouped (include/him.h "Weight panels").  Weights change once
+# per optimizer step, so the panel of every nn.Parameter is cached on the parameter and rebuilt (a) by
+# FusedAdam.step() right after the update -- on the optimizer's stream, under the other network's backward -- or (b)
+# lazily when the parameter's version counter / storage moved (load_state_dict, torch optimizers).  Code that writes
+# weights behind torch's back (raw pointers, ``p.data.copy_``) must call ``invalidate_panels``.
+PANEL_FWD, PANEL_BWD_DATA = 0, 1
+_PANELS_ON = os.environ.get('HIM_NO_PANEL_CACHE') is None
+
+
+class _Panel(object):
+    __slots__ = ('buf', 'nbytes', 'desc', 'is_deconv', 'kind', 'token', 'event', 'stream_id')
+
+
+def _panel_token(w):
+    return (w._version, w.data_ptr(), getattr(w, '_him_gen', 0))
+
+
+def _build_panel(w, e):
+    fn = lib.him_deconv2d_panel_build if e.is_deconv else lib.him_conv2d_panel_build
+    fn(ctypes.byref(e.desc), e.kind, _p(w), _p(e.buf), e.nbytes, _stream())
+    e.token = _panel_token(w)
+    e.event = torch.cuda.Event()
+    e.event.record(torch.cuda.current_stream())
+    e.stream_id = _stream()
+
+
+def _panel(w, d, kind, is_deconv):
+    """Device pointer of the cached panel of parameter ``w`` for descriptor ``d`` (0: use the plain entry point)."""
+    if not _PANELS_ON or not isinstance(w, torch.nn.Parameter):
+        return 0
+    cache = w.__dict__.get('_him_panels')
+    if cache is None:
+        cache = w.__dict__['_him_panels'] = {}
+    key = (kind, d.stride)
+    e = cache.get(key)
+    if e is None:
+        e = cache[key] = _Panel()
+        e.kind, e.is_deconv = kind, is_deconv
+        e.desc = type(d).from_buffer_copy(d)
+        fn = lib.him_deconv2d_panel_bytes if is_deconv else lib.him_conv2d_panel_bytes
+        e.nbytes = int(fn(ctypes.byref(d), kind))
+        e.buf = torch.empty(e.nbytes // 4, dtype=torch.float32, device=w.device) if e.nbytes else None
+        e.token = None
+    if e.buf is None:
+        return 0
+    if e.token != _panel_token(w):
+        _build_panel(w, e)
+    if e.stream_id != _stream():
+        torch.cuda.current_stream().wait_event(e.event)
+    return e.buf.data_ptr()
+
+
+def refresh_panels(params):
+    """Rebuild the cached panels of ``params`` on the current stream (called by FusedAdam.step after the update)."""
+    for p in params:
+        p._him_gen = getattr(p, '_him_gen', 0) + 1
+        cache = p.__dict__.get('_him_panels')
+        if cache:
+            for e in cache.values():
+                if e.buf is not None:
+                    _build_panel(p, e)
+
+
+def invalidate_panels(params):
+    for p in params:
+        p._him_gen = getattr(p, '_him_gen', 0) + 1
+
+
 class _Conv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, pad, pad_mode, act, slope):
@@ -161,7 +229,11 @@ class _Conv2d(torch.autograd.Function):
         y = torch.empty((d.B, d.Cout, d.OH, d.OW), dtype=torch.float32, device=x.device)
         nb = lib.him_conv2d_fwd_ws(ctypes.byref(d))
         ws = _ws(nb, x)
-        lib.him_conv2d_fwd(ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), _p(ws), nb, _stream())
+        pan = _panel(w, d, PANEL_FWD, False)
+        if pan:
+            lib.him_conv2d_fwd_panel(ctypes.byref(d), _p(x), pan, _p(b), _p(y), _p(ws), nb, _stream())
+        else:
+            lib.him_conv2d_fwd(ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), _p(ws), nb, _stream())
         ctx.d = d
         ctx.x, ctx.w, ctx.b = x, w, b
         ctx.y = y if act != ACT_NONE else None
@@ -184,7 +256,11 @@ class _Conv2d(torch.autograd.Function):
             dx = torch.empty_like(x)
             nb = lib.him_conv2d_bwd_data_ws(ctypes.byref(d))
             ws = _ws(nb, x)
-            lib.him_conv2d_bwd_data(ctypes.byref(d), _p(dz), _p(w), _p(dx), _p(ws), nb, st)
+            pan = _panel(w, d, PANEL_BWD_DATA, False)
+            if pan:
+                lib.him_conv2d_bwd_data_panel(ctypes.byref(d), _p(dz), pan, _p(dx), _p(ws), nb, st)
+            else:
+                lib.him_conv2d_bwd_data(ctypes.byref(d), _p(dz), _p(w), _p(dx), _p(ws), nb, st)
         skip_w = id(w) in SKIP_WGRAD
         need_w = ctx.needs_input_grad[1] and not skip_w
         need_b = b is not None and ctx.needs_input_grad[2] and not skip_w
@@ -228,7 +304,11 @@ class _Deconv2d(torch.autograd.Function):
         y = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
         nb = lib.him_deconv2d_fwd_ws(ctypes.byref(d))
         ws = _ws(nb, x)
-        lib.him_deconv2d_fwd(ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), _p(ws), nb, _stream())
+        pan = _panel(w, d, PANEL_FWD, True)
+        if pan:
+            lib.him_deconv2d_fwd_panel(ctypes.byref(d), _p(x), pan, _p(b), _p(y), _p(ws), nb, _stream())
+        else:
+            lib.him_deconv2d_fwd(ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), _p(ws), nb, _stream())
         ctx.d = d
         ctx.x, ctx.w, ctx.b = x, w, b
         ctx.y = y if act != ACT_NONE else None
@@ -251,7 +331,11 @@ class _Deconv2d(torch.autograd.Function):
             dx = torch.empty_like(x)
             nb = lib.him_deconv2d_bwd_data_ws(ctypes.byref(d))
             ws = _ws(nb, x)
-            lib.him_deconv2d_bwd_data(ctypes.byref(d), _p(dz), _p(w), _p(dx), _p(ws), nb, st)
+            pan = _panel(w, d, PANEL_BWD_DATA, True)
+            if pan:
+                lib.him_deconv2d_bwd_data_panel(ctypes.byref(d), _p(dz), pan, _p(dx), _p(ws), nb, st)
+            else:
+                lib.him_deconv2d_bwd_data(ctypes.byref(d), _p(dz), _p(w), _p(dx), _p(ws), nb, st)
         need_w = ctx.needs_input_grad[1]
         need_b = b is not None and ctx.needs_input_grad[2]
         if need_w or need_b:

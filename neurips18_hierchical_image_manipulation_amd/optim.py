@@ -77,6 +77,8 @@ class FusedAdam(object):
         lib.him_adam_step(a.data.data_ptr(), a.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                           a.total, float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
                           self.step_count, _stream())
+        from .ops import refresh_panels
+        refresh_panels(a.params)               # regrouped weight panels of the conv kernels follow the update
 
     def load_moments(self, exp_avgs, exp_avg_sqs, step):
         """Adopt per-parameter Adam moments (e.g. from a torch.optim.Adam) -- used by checkpoint import and by the

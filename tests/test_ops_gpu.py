@@ -291,3 +291,37 @@ def test_spectral_norm_sigma_and_full_gradient(shape):
     assert_close('W/sigma', Wbar, Wbar_ref, rtol=1e-5)
     (gW,) = torch.autograd.grad(Wbar, Wd, gy.to(DEV))
     assert_close('d(W/sigma)/dW through both normalisations', gW, gW_ref, rtol=2e-5)
+
+
+def test_weight_panel_cache_matches_plain_path_and_tracks_updates():
+    """Cached weight panels (nn.Parameter weights) give bit-identical results to the per-launch regroup, and follow
+    weight updates made through torch (version counter) or announced with invalidate_panels."""
+    ops = _ops()
+    for kind in ('conv', 'deconv'):
+        x = _rand(2, 32, 12, 20, seed=1).to(DEV).requires_grad_(True)
+        if kind == 'conv':
+            w0 = _rand(48, 32, 3, 3, seed=2, scale=0.1).to(DEV)
+            run = lambda xx, ww: ops.conv2d(xx, ww, None, 1, 1, 'reflect', 'none')  # noqa: E731
+        else:
+            w0 = _rand(32, 48, 3, 3, seed=2, scale=0.1).to(DEV)
+            run = lambda xx, ww: ops.conv_transpose2d(xx, ww, None, 2, 1, 1, 'none')  # noqa: E731
+        plain_w = w0.clone().requires_grad_(True)            # plain tensor: regrouped on every launch
+        param_w = torch.nn.Parameter(w0.clone())             # Parameter: cached panels
+        y0 = run(x, plain_w)
+        gy = torch.randn_like(y0)
+        (gx0,) = torch.autograd.grad(y0, x, gy)
+        for _ in range(2):                                   # second round hits the cache
+            y1 = run(x, param_w)
+            (gx1,) = torch.autograd.grad(y1, x, gy)
+            assert torch.equal(y0, y1) and torch.equal(gx0, gx1)
+        assert len(param_w._him_panels) == 2
+        with torch.no_grad():
+            param_w.mul_(2.0)                                # version bump -> lazy rebuild
+        assert torch.equal(run(x, param_w), run(x, (w0 * 2.0)))
+        param_w.data.copy_(w0 * 3.0)                         # behind torch's back
+        ops.invalidate_panels([param_w])
+        y3 = run(x, param_w)
+        (gx3,) = torch.autograd.grad(y3, x, gy)
+        y3r = run(x, (w0 * 3.0).requires_grad_(True))
+        (gx3r,) = torch.autograd.grad(y3r, x, gy)
+        assert torch.equal(y3, y3r) and torch.equal(gx3, gx3r)
