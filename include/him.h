@@ -108,6 +108,13 @@ int him_deconv2d_bwd_weight(const HimDeconv2d* d, const float* x, const float* d
  * *_panel_bytes returns 0 when that kernel reads the raw weights (Cout <= 4 heads, Cin < 16 stems):
  * use the plain entry point.  Workspace sizes are those of the plain entry points.
  * -------------------------------------------------------------------------------------------*/
+/* 3x3 stride-1 pad-1 convs with Cin and Cout >= this many channels (default 512; env HIM_WINO_MIN_C,
+ * HIM_NO_WINOGRAD) run as Winograd F(2x2,3x3): transforms + ONE batched fp32-MFMA GEMM over the 16 transform
+ * positions (2.25x fewer multiplies; fp32 rounding differs from the direct form at the 1e-6 level).  The data and
+ * weight gradients of those layers use the same scheme.  Workspace / panel sizes follow the current setting: change
+ * it only between steps, then rebuild cached panels.  c <= 0 turns it off.  Returns the previous value. */
+int him_set_winograd_min_channels(int c);
+
 #define HIM_PANEL_FWD 0
 #define HIM_PANEL_BWD_DATA 1
 size_t him_conv2d_panel_bytes(const HimConv2d* d, int kind);

@@ -61,6 +61,8 @@ struct GConvP {
   int kno_finish;     // the caller sums the split-K slabs itself (reflection fold)
   float* small_part;  // tiny-M path: [nsplit][M][Ntot] partial sums when the channels are split over grid.y
   int small_nsplit;
+  int wbatch;         // fast path, batched weights (Winograd): image b reads the panel At + b*wbatch floats; needs
+                      // plane % BN == 0 so that a tile never straddles two images
   GPhase ph[4];
 };
 
@@ -97,14 +99,22 @@ __global__ __launch_bounds__(WM * WN * 64) void gconv_fast_kernel(const GConvP p
     const int total = nmt * nnt, L = blockIdx.x;
     const int q = total >> 3, r = total & 7, xcd = L & 7, slot = L >> 3;
     const int T = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    const int mt = T / nnt;
-    m0 = mt * BM;
-    n0 = (T - mt * nnt) * BN;
+    if (p.wbatch) {  // image-major: one XCD works through whole (panel, image) pairs
+      const int ntp = plane / BN, per = nmt * ntp;
+      const int img = T / per, rem = T - img * per;
+      const int mt = rem / ntp;
+      m0 = mt * BM;
+      n0 = img * plane + (rem - mt * ntp) * BN;
+    } else {
+      const int mt = T / nnt;
+      m0 = mt * BM;
+      n0 = (T - mt * nnt) * BN;
+    }
   }
   if (n0 >= Ntot) return;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const float* __restrict__ At = ph.At;
+  const float* __restrict__ At = ph.At + (p.wbatch ? (size_t)(n0 / plane) * p.wbatch : 0);
   const float* __restrict__ src = p.src;
   const int C2 = p.C2, C2p = ph.C2p, CB = C2p / BK;
   const int JW = ph.JW, JH = ph.JH;
@@ -989,6 +999,407 @@ __global__ __launch_bounds__(256) void reflect_extend_kernel(const float* __rest
   ext[(size_t)blockIdx.y * EH * EW + i] = v;
 }
 
+
+// ==============================================================================================
+// Winograd F(2x2, 3x3) for the wide 3x3 stride-1 layers (the 1024-channel ResnetBlock stack, VGG conv4/5):
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A      (Lavin & Gray 2016; 2.25x fewer multiplies than the direct form)
+// The 16 element-wise products are 16 independent dense contractions over the input channels, i.e. ONE batched GEMM
+//   Mo[pos][co][tile] = sum_ci U[pos][co][ci] * V[pos][ci][tile]
+// that runs on the same fp32-MFMA kernel as a 1x1 convolution over 16 "images" with per-image weight panels
+// (GConvP::wbatch).  The transforms are separate HBM-bound kernels (x4 expansion of the activations).
+// Data gradient: same machinery with the flipped/transposed filter (U'); for reflect padding it produces the padded
+// gradient (full correlation, offset 2) which reflect_fold_kernel folds.  Weight gradient:
+//   dU[pos][co][ci] = sum_tile dM[pos][co][tile] * V[pos][ci][tile],  dM = A dY A^T,  dg = G^T dU G
+// = one batched NT GEMM (wino_gemm_nt_kernel) + transforms.
+// Tile index t = (b*TY + ty)*TX + tx, padded to Tp (multiple of 128) so GEMM tiles never straddle a position slab.
+// ==============================================================================================
+struct WinoGeom {
+  int B, C, H, W;    // tensor being transformed / produced: [B][C][H][W]
+  int OH, OW;        // output grid the 2x2 tiles cover
+  int TY, TX, T, Tp;
+  int po;            // patch origin offset: input row = 2*ty - po + i   (1: pad-1 conv, 2: full correlation)
+};
+static WinoGeom wino_geom(int B, int C, int H, int W, int OH, int OW, int po) {
+  WinoGeom g;
+  g.B = B; g.C = C; g.H = H; g.W = W; g.OH = OH; g.OW = OW; g.po = po;
+  g.TY = (OH + 1) / 2; g.TX = (OW + 1) / 2;
+  g.T = B * g.TY * g.TX;
+  g.Tp = (g.T + 127) / 128 * 128;
+  return g;
+}
+
+// V[pos][c][t] = (B^T d B)[pos] of the 4x4 patch of x[b][c] at rows 2ty-po.., cols 2tx-po..; REFLECT: mirrored
+// indices (ReflectionPad2d(1)), else zeros outside.  grid (Tp/256, C)
+template <bool REFLECT>
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V,
+                                                         const WinoGeom g) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.y;
+  if (t >= g.Tp) return;
+  float d[4][4];
+  if (t < g.T) {
+    const int per = g.TY * g.TX;
+    const int b = t / per, r = t - b * per, ty = r / g.TX, tx = r - ty * g.TX;
+    const float* __restrict__ src = x + ((size_t)b * g.C + c) * g.H * g.W;
+    int ys[4], xs[4];
+    bool oky[4], okx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int iy = 2 * ty - g.po + i, ix = 2 * tx - g.po + i;
+      if (REFLECT) {
+        iy = iy < 0 ? -iy : iy;
+        iy = iy >= g.H ? 2 * (g.H - 1) - iy : iy;
+        ix = ix < 0 ? -ix : ix;
+        ix = ix >= g.W ? 2 * (g.W - 1) - ix : ix;
+      }
+      const int cy = min(max(iy, 0), g.H - 1), cx = min(max(ix, 0), g.W - 1);
+      oky[i] = REFLECT || cy == iy;
+      okx[i] = REFLECT || cx == ix;
+      ys[i] = cy * g.W;
+      xs[i] = cx;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float v = src[ys[i] + xs[j]];
+        d[i][j] = (oky[i] && okx[j]) ? v : 0.f;
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[i][j] = 0.f;
+  }
+  float tt[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    tt[0][j] = d[0][j] - d[2][j];
+    tt[1][j] = d[1][j] + d[2][j];
+    tt[2][j] = d[2][j] - d[1][j];
+    tt[3][j] = d[1][j] - d[3][j];
+  }
+  const size_t slab = (size_t)g.C * g.Tp;
+  float* __restrict__ o = V + (size_t)c * g.Tp + t;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    o[(size_t)(i * 4 + 0) * slab] = tt[i][0] - tt[i][2];
+    o[(size_t)(i * 4 + 1) * slab] = tt[i][1] + tt[i][2];
+    o[(size_t)(i * 4 + 2) * slab] = tt[i][2] - tt[i][1];
+    o[(size_t)(i * 4 + 3) * slab] = tt[i][1] - tt[i][3];
+  }
+}
+
+// y[b][c][2ty+i][2tx+j] = act((A^T Mo A)[i][j] + bias[c]);  Mo[pos][c][t].  grid (Tp/256, C)
+__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mo, float* __restrict__ y,
+                                                          const float* __restrict__ bias, const WinoGeom g, int act,
+                                                          float slope) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.y;
+  if (t >= g.T) return;
+  const size_t slab = (size_t)g.C * g.Tp;
+  const float* __restrict__ in = Mo + (size_t)c * g.Tp + t;
+  float m[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m[i][j] = in[(size_t)(i * 4 + j) * slab];
+  float r[2][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    r[0][j] = m[0][j] + m[1][j] + m[2][j];
+    r[1][j] = m[1][j] - m[2][j] - m[3][j];
+  }
+  const int per = g.TY * g.TX;
+  const int b = t / per, rr = t - b * per, ty = rr / g.TX, tx = rr - ty * g.TX;
+  const float bb = bias ? bias[c] : 0.f;
+  float* __restrict__ dst = y + ((size_t)b * g.C + c) * g.OH * g.OW;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int oy = 2 * ty + i;
+    if (oy >= g.OH) continue;
+    const float v0 = r[i][0] + r[i][1] + r[i][2], v1 = r[i][1] - r[i][2] - r[i][3];
+    const int ox = 2 * tx;
+    dst[oy * g.OW + ox] = apply_act(v0 + bb, act, slope);
+    if (ox + 1 < g.OW) dst[oy * g.OW + ox + 1] = apply_act(v1 + bb, act, slope);
+  }
+}
+
+// dM[pos][c][t] = (A dY A^T)[pos] of the 2x2 output-gradient tile (zeros outside the grid and in the padded columns)
+__global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ dy, float* __restrict__ dM,
+                                                      const WinoGeom g) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.y;
+  if (t >= g.Tp) return;
+  float e[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  if (t < g.T) {
+    const int per = g.TY * g.TX;
+    const int b = t / per, rr = t - b * per, ty = rr / g.TX, tx = rr - ty * g.TX;
+    const float* __restrict__ src = dy + ((size_t)b * g.C + c) * g.OH * g.OW;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int oy = 2 * ty + i, ox = 2 * tx + j;
+        if (oy < g.OH && ox < g.OW) e[i][j] = src[oy * g.OW + ox];
+      }
+  }
+  float q[4][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    q[0][j] = e[0][j];
+    q[1][j] = e[0][j] + e[1][j];
+    q[2][j] = e[0][j] - e[1][j];
+    q[3][j] = -e[1][j];
+  }
+  const size_t slab = (size_t)g.C * g.Tp;
+  float* __restrict__ o = dM + (size_t)c * g.Tp + t;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    o[(size_t)(i * 4 + 0) * slab] = q[i][0];
+    o[(size_t)(i * 4 + 1) * slab] = q[i][0] + q[i][1];
+    o[(size_t)(i * 4 + 2) * slab] = q[i][0] - q[i][1];
+    o[(size_t)(i * 4 + 3) * slab] = -q[i][1];
+  }
+}
+
+// U[pos][m][c] = (G g G^T)[pos].  FLIP = 0: g = w[m][c] (forward, m = Cout, c = Cin);
+// FLIP = 1: g = 180-degree rotation of w[c][m] (data gradient: m = Cin, c = Cout).  grid (ceil(Cc/256), Mm)
+template <int FLIP>
+__global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Mm,
+                                                          int Cc) {
+  const int c = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y;
+  if (c >= Cc) return;
+  const float* __restrict__ src = FLIP ? w + ((size_t)c * Mm + m) * 9 : w + ((size_t)m * Cc + c) * 9;
+  float g[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) g[i][j] = FLIP ? src[(2 - i) * 3 + (2 - j)] : src[i * 3 + j];
+  float sg[4][3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    sg[0][j] = g[0][j];
+    sg[1][j] = 0.5f * (g[0][j] + g[1][j] + g[2][j]);
+    sg[2][j] = 0.5f * (g[0][j] - g[1][j] + g[2][j]);
+    sg[3][j] = g[2][j];
+  }
+  const size_t slab = (size_t)Mm * Cc;
+  float* __restrict__ o = U + (size_t)m * Cc + c;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    o[(size_t)(i * 4 + 0) * slab] = sg[i][0];
+    o[(size_t)(i * 4 + 1) * slab] = 0.5f * (sg[i][0] + sg[i][1] + sg[i][2]);
+    o[(size_t)(i * 4 + 2) * slab] = 0.5f * (sg[i][0] - sg[i][1] + sg[i][2]);
+    o[(size_t)(i * 4 + 3) * slab] = sg[i][2];
+  }
+}
+
+// dw[m][c][3][3] (+)= G^T dU[.][m][c] G.  grid (ceil(C/256), M)
+__global__ __launch_bounds__(256) void wino_wgrad_out_kernel(const float* __restrict__ dU, float* __restrict__ dw,
+                                                             int M, int C, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y;
+  if (c >= C) return;
+  const size_t slab = (size_t)M * C;
+  const float* __restrict__ in = dU + (size_t)m * C + c;
+  float u[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) u[i][j] = in[(size_t)(i * 4 + j) * slab];
+  float e[3][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    e[0][j] = u[0][j] + 0.5f * (u[1][j] + u[2][j]);
+    e[1][j] = 0.5f * (u[1][j] - u[2][j]);
+    e[2][j] = 0.5f * (u[1][j] + u[2][j]) + u[3][j];
+  }
+  float* __restrict__ o = dw + ((size_t)m * C + c) * 9;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float g0 = e[i][0] + 0.5f * (e[i][1] + e[i][2]);
+    const float g1 = 0.5f * (e[i][1] - e[i][2]);
+    const float g2 = 0.5f * (e[i][1] + e[i][2]) + e[i][3];
+    if (accumulate) {
+      o[i * 3 + 0] += g0;
+      o[i * 3 + 1] += g1;
+      o[i * 3 + 2] += g2;
+    } else {
+      o[i * 3 + 0] = g0;
+      o[i * 3 + 1] = g1;
+      o[i * 3 + 2] = g2;
+    }
+  }
+}
+
+// Batched NT GEMM on fp32 MFMA: Cm[z][m][n] = sum_k A[z][m][k] * Bm[z][n][k]; M, N multiples of 128, K of 32.
+// 128x128 tile per 256-thread workgroup (2x2 waves x 2x2 MFMA tiles), BK = 32, both operand tiles are contiguous
+// float4 rows (k fastest), LDS [row][32+4] read with aligned ds_read_b128 (k <-> lane>>5 pairing as wgrad_fast).
+// 1-D grid, XCD-aware: each XCD owns whole batches (both operands of a batch stream through its L2 once).
+__global__ __launch_bounds__(256) void wino_gemm_nt_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                           float* __restrict__ Cm, int M, int N, int K) {
+  constexpr int BM = 128, BN = 128, BK = 32, LD = 36;
+  __shared__ __attribute__((aligned(16))) float sA[2][BM * LD];
+  __shared__ __attribute__((aligned(16))) float sB[2][BN * LD];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int z, m0, n0;
+  {
+    const int total = gridDim.x, L = blockIdx.x;
+    const int q = total >> 3, r = total & 7, xcd = L & 7, slot = L >> 3;
+    const int T = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    const int nmt = M / BM, nnt = N / BN, per = nmt * nnt;
+    z = T / per;
+    const int rem = T - z * per, mt = rem / nnt;
+    m0 = mt * BM;
+    n0 = (rem - mt * nnt) * BN;
+  }
+  const float* __restrict__ Ab = A + ((size_t)z * M + m0) * K;
+  const float* __restrict__ Bb = Bm + ((size_t)z * N + n0) * K;
+  const int row = t >> 3, kq = t & 7;  // thread -> rows row + 32 i, k quad kq
+  float4 ra[4], rb[4];
+  const int nk = K / BK;
+#define HIM_NT_LOAD(kt_)                                                                   \
+  {                                                                                        \
+    const size_t ko = (size_t)(kt_) * BK + kq * 4;                                         \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                        \
+      ra[i] = *(const float4*)(Ab + (size_t)(row + 32 * i) * K + ko);                      \
+      rb[i] = *(const float4*)(Bb + (size_t)(row + 32 * i) * K + ko);                      \
+    }                                                                                      \
+  }
+#define HIM_NT_STORE(buf_)                                                                 \
+  {                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                        \
+      *(float4*)&sA[buf_][(row + 32 * i) * LD + kq * 4] = ra[i];                           \
+      *(float4*)&sB[buf_][(row + 32 * i) * LD + kq * 4] = rb[i];                           \
+    }                                                                                      \
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int l31 = lane & 31, lh = lane >> 5;
+  HIM_NT_LOAD(0)
+  HIM_NT_STORE(0)
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    const float4* __restrict__ pa = (const float4*)&sA[buf][(wm * 64 + l31) * LD + lh * 16];
+    const float4* __restrict__ pb = (const float4*)&sB[buf][(wn * 64 + l31) * LD + lh * 16];
+    float4 af[2][4], bf[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        af[i][q] = pa[i * 32 * LD / 4 + q];
+        bf[i][q] = pb[i * 32 * LD / 4 + q];
+      }
+    if (kt + 1 < nk) HIM_NT_LOAD(kt + 1)
+#define HIM_NT_M(Q, CMP)                                                                                     \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] =    \
+      __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][Q].CMP, bf[j][Q].CMP, acc[i][j], 0, 0, 0);
+    HIM_NT_M(0, x) HIM_NT_M(0, y) HIM_NT_M(0, z) HIM_NT_M(0, w)
+    HIM_NT_M(1, x) HIM_NT_M(1, y) HIM_NT_M(1, z) HIM_NT_M(1, w)
+    HIM_NT_M(2, x) HIM_NT_M(2, y) HIM_NT_M(2, z) HIM_NT_M(2, w)
+    HIM_NT_M(3, x) HIM_NT_M(3, y) HIM_NT_M(3, z) HIM_NT_M(3, w)
+#undef HIM_NT_M
+    if (kt + 1 < nk) HIM_NT_STORE(buf ^ 1)
+    __syncthreads();
+  }
+#undef HIM_NT_LOAD
+#undef HIM_NT_STORE
+  float* __restrict__ out = Cm + ((size_t)z * M + m0) * N + n0;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = wn * 64 + j * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        out[(size_t)m * N + n] = acc[i][j][r];
+      }
+  }
+}
+
+
+// ---- Winograd host side -------------------------------------------------------------------------------------------
+static int g_wino_min_c = -2;  // -2: not initialised; <= 0: Winograd off
+static int wino_min_c() {
+  if (g_wino_min_c == -2) {
+    const char* e = getenv("HIM_WINO_MIN_C");
+    g_wino_min_c = getenv("HIM_NO_WINOGRAD") ? -1 : (e ? atoi(e) : 512);
+  }
+  return g_wino_min_c;
+}
+// wide 3x3 stride-1 pad-1 layers only: below ~512 channels the x4 transform traffic eats the 2.25x multiply saving
+static bool wino_shape_ok(int Cout, int Cin, int KH, int KW, int stride, int pad, int H, int W) {
+  const int mc = wino_min_c();
+  return mc > 0 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin >= mc && Cout >= mc && (Cin % 16) == 0 &&
+         (Cout % 16) == 0 && H >= 2 && W >= 2 && use_fast(Cout, Cin);
+}
+static bool wino_wgrad_ok(int M, int C, int KH, int KW, int stride, int pad, int H, int W) {
+  return wino_shape_ok(M, C, KH, KW, stride, pad, H, W) && (M % 128) == 0 && (C % 128) == 0;
+}
+static size_t wino_conv_floats(int B, int Csrc, int Mout, int OH, int OW) {
+  const WinoGeom g = wino_geom(B, Csrc, 1, 1, OH, OW, 1);
+  return (size_t)16 * (Csrc + Mout) * g.Tp;
+}
+static size_t wino_wgrad_floats(int B, int M, int C, int OH, int OW) {
+  const WinoGeom g = wino_geom(B, C, 1, 1, OH, OW, 1);
+  return (size_t)16 * (C + M) * g.Tp + (size_t)16 * M * C;
+}
+// dst[B][Mout][OH][OW] = act(winograd-conv(src[B][Csrc][H][W], U) + bias); ws holds V and Mo
+static int run_wino_conv(int B, int Csrc, int H, int W, int Mout, int OH, int OW, int po, bool reflect,
+                         const float* src, const float* U, const float* bias, int act, float slope, float* dst,
+                         float* ws, hipStream_t st) {
+  const WinoGeom gi = wino_geom(B, Csrc, H, W, OH, OW, po);
+  float* V = ws;
+  float* Mo = V + (size_t)16 * Csrc * gi.Tp;
+  const dim3 gin(cdiv(gi.Tp, 256), Csrc);
+  if (reflect) hipLaunchKernelGGL((wino_input_kernel<true>), gin, dim3(256), 0, st, src, V, gi);
+  else hipLaunchKernelGGL((wino_input_kernel<false>), gin, dim3(256), 0, st, src, V, gi);
+  int rc = check_launch("wino_input");
+  if (rc) return rc;
+  GConvP g;
+  memset(&g, 0, sizeof(g));
+  g.src = V;
+  g.dst = Mo;
+  g.M = Mout;
+  g.C2 = Csrc;
+  g.B = 16;
+  g.SH = 1;
+  g.SW = gi.Tp;
+  g.DH = 1;
+  g.DW = gi.Tp;
+  g.oys = g.oxs = g.sy = g.sx = g.dy = g.dx = 1;
+  g.pad_mode = HIM_PAD_ZERO;
+  g.act = HIM_ACT_NONE;
+  g.nphase = 1;
+  g.fast = 1;
+  g.wbatch = Mout * Csrc;
+  GPhase& P = g.ph[0];
+  P.A = U;
+  P.At = U;
+  P.C2p = Csrc;
+  P.K = Csrc;
+  P.JH = P.JW = 1;
+  P.fJHJW = make_fastdiv(1);
+  P.fJW = make_fastdiv(1);
+  P.NA = 1;
+  P.NC = gi.Tp;
+  rc = launch_gconv(g, st);
+  if (rc) return rc;
+  WinoGeom go = gi;
+  go.C = Mout;
+  hipLaunchKernelGGL(wino_output_kernel, dim3(cdiv(gi.Tp, 256), Mout), dim3(256), 0, st, (const float*)Mo, dst, bias, go,
+                     act, slope);
+  return check_launch("wino_output");
+}
+
 // ==============================================================================================
 // wgrad
 // ==============================================================================================
@@ -1507,9 +1918,10 @@ static int small_wgrad_slices(int C, int Kdim) {
   return s < 1 ? 1 : s;
 }
 static bool small_wgrad_ok(int M, int KH, int KW) { return M <= 4 && KH == KW && (KH == 7 || KH == 4 || KH == 3); }
-static size_t wgrad_slab_bytes(int M, int C, int KH, int KW, int Kdim) {
+static size_t wgrad_slab_bytes(int M, int C, int KH, int KW, int Kdim, size_t wino_floats = 0) {
   const int Np = C * KH * KW;
   size_t slabs;
+  if (wino_floats) return ((wino_floats * sizeof(float) + 255) / 256) * 256;
   if (small_wgrad_ok(M, KH, KW)) {
     slabs = (size_t)small_wgrad_slices(C, Kdim) * M * Np * sizeof(float);
   } else if (wgrad_fast_ok(M, C, 1, 4) && Kdim % 4 == 0) {  /* upper bound; the runner re-checks OH*OW */
@@ -1529,8 +1941,13 @@ static size_t wgrad_slab_bytes(int M, int C, int KH, int KW, int Kdim) {
   }
   return ((slabs + 255) / 256) * 256;
 }
-static size_t wgrad_ws_bytes(int M, int C, int KH, int KW, int Kdim, int biasC) {
-  return wgrad_slab_bytes(M, C, KH, KW, Kdim) + bias_ws_bytes(biasC);
+static size_t wgrad_ws_bytes(int M, int C, int KH, int KW, int Kdim, int biasC, size_t wino_floats = 0) {
+  return wgrad_slab_bytes(M, C, KH, KW, Kdim, wino_floats) + bias_ws_bytes(biasC);
+}
+static size_t conv_wino_wgrad_floats(const HimConv2d* d) {
+  return wino_wgrad_ok(d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad, d->H, d->W)
+             ? wino_wgrad_floats(d->B, d->Cout, d->Cin, d->OH, d->OW)
+             : 0;
 }
 
 // generic weight gradient: dW[M][C*KH*KW] from dy[B][M][OH][OW] and x[B][C][H][W]
@@ -1557,6 +1974,30 @@ static int run_wgrad(const float* dy, const float* x, float* dw, int M, int C, i
   p.fKK = make_fastdiv((uint32_t)(KH * KW));
   p.fKW = make_fastdiv((uint32_t)KW);
   p.fOW = make_fastdiv((uint32_t)OW);
+  if (wino_wgrad_ok(M, C, KH, KW, stride, pad, H, W) && OH == H && OW == W) {
+    // dU = dM x V^T per Winograd position (batched NT GEMM), then dw (+)= G^T dU G
+    const size_t need = wino_wgrad_floats(B, M, C, OH, OW) * sizeof(float);
+    if (ws_bytes < need || !ws) return fail(HIM_E_WORKSPACE, "wgrad needs %zu ws bytes, got %zu", need, ws_bytes);
+    const WinoGeom gx = wino_geom(B, C, H, W, OH, OW, 1);
+    WinoGeom gd = gx;
+    gd.C = M;
+    float* V = (float*)ws;
+    float* dM = V + (size_t)16 * C * gx.Tp;
+    float* dU = dM + (size_t)16 * M * gx.Tp;
+    const dim3 gin(cdiv(gx.Tp, 256), C);
+    if (pad_mode == HIM_PAD_REFLECT) hipLaunchKernelGGL((wino_input_kernel<true>), gin, dim3(256), 0, st, x, V, gx);
+    else hipLaunchKernelGGL((wino_input_kernel<false>), gin, dim3(256), 0, st, x, V, gx);
+    hipLaunchKernelGGL(wino_dy_kernel, dim3(cdiv(gx.Tp, 256), M), dim3(256), 0, st, dy, dM, gd);
+    int rcw = check_launch("wino_wgrad_transforms");
+    if (rcw) return rcw;
+    hipLaunchKernelGGL(wino_gemm_nt_kernel, dim3(16 * (M / 128) * (C / 128)), dim3(256), 0, st, (const float*)dM,
+                       (const float*)V, dU, M, C, gx.Tp);
+    rcw = check_launch("wino_gemm_nt");
+    if (rcw) return rcw;
+    hipLaunchKernelGGL(wino_wgrad_out_kernel, dim3(cdiv(C, 256), M), dim3(256), 0, st, (const float*)dU, dw, M, C,
+                       accumulate);
+    return check_launch("wino_wgrad_out");
+  }
   if (small_wgrad_ok(M, KH, KW)) {
     const int slices = small_wgrad_slices(C, p.Kdim);
     const size_t need = (size_t)slices * M * p.Np * sizeof(float);
@@ -1742,7 +2183,12 @@ static int fast_ksplit(int M, long long N, int nk) {
   }
   return best;
 }
+static bool wino_fwd_ok(const HimConv2d* d) {
+  return wino_shape_ok(d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad, d->H, d->W);
+}
 static size_t fprop_ws_bytes(const HimConv2d* d) {
+  if (wino_fwd_ok(d))
+    return ((size_t)16 * d->Cout * d->Cin + wino_conv_floats(d->B, d->Cin, d->Cout, d->OH, d->OW)) * sizeof(float) + 256;
   if (small_split_ok(d)) return (size_t)SMALL_NSPLIT * d->Cout * d->B * d->OH * d->OW * sizeof(float) + 256;
   if (!use_fast(d->Cout, d->Cin)) return 0;
   const int ks = fast_ksplit(d->Cout, (long long)d->B * d->OH * d->OW, d->KH * d->KW * (pad16(d->Cin) / 16));
@@ -1752,11 +2198,25 @@ static size_t fprop_ws_bytes(const HimConv2d* d) {
 // floats of the regrouped weight panel the forward kernel reads (0: it reads the raw weights)
 static size_t fprop_panel_floats(const HimConv2d* d) {
   if (small_split_ok(d) || d->Cout <= 4 || !use_fast(d->Cout, d->Cin)) return 0;
+  if (wino_fwd_ok(d)) return (size_t)16 * d->Cout * d->Cin;
   return (size_t)d->Cout * d->KH * d->KW * pad16(d->Cin);
 }
 // panel == nullptr: regroup the weights into the workspace on every call; build_only: write the panel to ws and return
 static int run_fprop(const HimConv2d* d, const float* x, const float* w, const float* bias, float* y, void* ws,
                      size_t ws_bytes, hipStream_t st, const float* panel = nullptr, bool build_only = false) {
+  if (wino_fwd_ok(d)) {
+    const size_t need = build_only ? fprop_panel_floats(d) * sizeof(float) : fprop_ws_bytes(d);
+    if (!ws || ws_bytes < need) return fail(HIM_E_WORKSPACE, "conv fwd needs %zu ws bytes, got %zu", need, ws_bytes);
+    float* U = (float*)ws;
+    if (!panel) {
+      hipLaunchKernelGGL((wino_weight_kernel<0>), dim3(cdiv(d->Cin, 256), d->Cout), dim3(256), 0, st, w, U, d->Cout,
+                         d->Cin);
+      int rc = check_launch("wino_weight");
+      if (rc || build_only) return rc;
+    }
+    return run_wino_conv(d->B, d->Cin, d->H, d->W, d->Cout, d->OH, d->OW, 1, d->pad_mode == HIM_PAD_REFLECT, x,
+                         panel ? panel : U, bias, d->act, d->slope, y, U + (size_t)16 * d->Cout * d->Cin, st);
+  }
   GConvP g;
   fill_fprop(g, d, x, w, bias, y);
   if (small_split_ok(d)) {
@@ -1814,6 +2274,15 @@ static bool dfold_ok(const HimConv2d* d) {
   return !off && d->pad_mode == HIM_PAD_REFLECT && d->pad == 1 && d->KH == 3 && d->KW == 3 && d->stride == 1 &&
          d->H >= 3 && d->W >= 3 && d->OH == d->H && d->OW == d->W && use_fast(d->Cin, d->Cout);
 }
+static bool wino_dgrad_ok(const HimConv2d* d) {
+  return wino_shape_ok(d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad, d->H, d->W) && d->OH == d->H && d->OW == d->W;
+}
+static size_t wino_dgrad_floats(const HimConv2d* d) {  // U' + V + Mo (+ padded gradient for reflect)
+  const bool refl = d->pad_mode == HIM_PAD_REFLECT;
+  const int GH = refl ? d->H + 2 : d->H, GW = refl ? d->W + 2 : d->W;
+  return (size_t)16 * d->Cin * d->Cout + wino_conv_floats(d->B, d->Cout, d->Cin, GH, GW) +
+         (refl ? (size_t)d->B * d->Cin * GH * GW : 0);
+}
 static int dgrad_ksplit(const HimConv2d* d) {
   if (d->stride != 1 || !use_fast(d->Cin, d->Cout)) return 1;
   const bool refl = d->pad_mode == HIM_PAD_REFLECT && !dfold_ok(d);
@@ -1821,6 +2290,7 @@ static int dgrad_ksplit(const HimConv2d* d) {
   return fast_ksplit(d->Cin, N, d->KH * d->KW * (pad16(d->Cout) / 16));
 }
 static size_t dgrad_ws_bytes(const HimConv2d* d) {
+  if (wino_dgrad_ok(d)) return wino_dgrad_floats(d) * sizeof(float) + 256;
   size_t n = (size_t)d->Cin * pad16(d->Cout) * d->KH * d->KW + 64;
   const size_t outn = (size_t)d->B * d->Cin * (d->H + 2 * d->pad) * (d->W + 2 * d->pad);
   if (dfold_ok(d)) n += (size_t)d->B * d->Cout * (d->OH + 2) * (d->OW + 2) + 64;
@@ -1830,6 +2300,7 @@ static size_t dgrad_ws_bytes(const HimConv2d* d) {
   return n * sizeof(float) + 256;
 }
 static size_t dgrad_panel_floats(const HimConv2d* d) {
+  if (wino_dgrad_ok(d)) return (size_t)16 * d->Cin * d->Cout;
   return (size_t)d->Cin * (use_fast(d->Cin, d->Cout) ? pad16(d->Cout) : d->Cout) * d->KH * d->KW;
 }
 // panel == nullptr: regroup the weights into the workspace on every call; build_only: write the panel to ws and return
@@ -1838,6 +2309,28 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
                      bool build_only = false) {
   const size_t need = build_only ? dgrad_panel_floats(d) * sizeof(float) : dgrad_ws_bytes(d);
   if (!ws || ws_bytes < need) return fail(HIM_E_WORKSPACE, "dgrad needs %zu ws bytes, got %zu", need, ws_bytes);
+  if (wino_dgrad_ok(d) && panel && (bias || act != HIM_ACT_NONE))
+    return fail(HIM_E_UNSUPPORTED, "dgrad: Winograd panel with a fused bias/activation epilogue");
+  if (wino_dgrad_ok(d) && (build_only || (!bias && act == HIM_ACT_NONE))) {
+    float* U = (float*)ws;
+    if (!panel) {
+      hipLaunchKernelGGL((wino_weight_kernel<1>), dim3(cdiv(d->Cout, 256), d->Cin), dim3(256), 0, st, w, U, d->Cin,
+                         d->Cout);
+      int rcu = check_launch("wino_weight");
+      if (rcu || build_only) return rcu;
+    }
+    const bool rf = d->pad_mode == HIM_PAD_REFLECT;
+    const int GH = rf ? d->H + 2 : d->H, GW = rf ? d->W + 2 : d->W;
+    float* wsv = U + (size_t)16 * d->Cin * d->Cout;
+    float* dpadw = wsv + wino_conv_floats(d->B, d->Cout, d->Cin, GH, GW);
+    // reflect: full correlation (offset 2) -> padded gradient -> fold; zero pad: the plain pad-1 correlation
+    int rcw = run_wino_conv(d->B, d->Cout, d->OH, d->OW, d->Cin, GH, GW, rf ? 2 : 1, false, gy, panel ? panel : U,
+                            nullptr, HIM_ACT_NONE, 0.f, rf ? dpadw : out, wsv, st);
+    if (rcw || !rf) return rcw;
+    hipLaunchKernelGGL(reflect_fold_kernel, dim3(cdiv((long long)d->H * d->W, 256), d->B * d->Cin), dim3(256), 0, st,
+                       (const float*)dpadw, out, d->B * d->Cin, d->H, d->W, 1, 1, (size_t)0);
+    return check_launch("reflect_fold");
+  }
   float* Wt = panel ? (float*)panel : (float*)ws;
   const bool dfold = dfold_ok(d);
   const bool refl = d->pad_mode == HIM_PAD_REFLECT && !dfold;
@@ -1968,6 +2461,12 @@ using namespace him;
 
 extern "C" {
 
+int him_set_winograd_min_channels(int c) {
+  const int prev = wino_min_c();
+  g_wino_min_c = c > 0 ? c : -1;
+  return prev;
+}
+
 size_t him_conv2d_fwd_ws(const HimConv2d* d) { return d ? fprop_ws_bytes(d) : 0; }
 
 int him_conv2d_fwd(const HimConv2d* d, const float* x, const float* w, const float* bias, float* y, void* ws,
@@ -2022,7 +2521,7 @@ int him_conv2d_bwd_data_panel(const HimConv2d* d, const float* dy, const void* p
 }
 
 size_t him_conv2d_bwd_weight_ws(const HimConv2d* d) {
-  return d ? wgrad_ws_bytes(d->Cout, d->Cin, d->KH, d->KW, d->B * d->OH * d->OW, d->Cout) : 0;
+  return d ? wgrad_ws_bytes(d->Cout, d->Cin, d->KH, d->KW, d->B * d->OH * d->OW, d->Cout, conv_wino_wgrad_floats(d)) : 0;
 }
 
 int him_conv2d_bwd_weight(const HimConv2d* d, const float* x, const float* dy, float* dw, float* dbias,
@@ -2035,7 +2534,7 @@ int him_conv2d_bwd_weight(const HimConv2d* d, const float* x, const float* dy, f
     if (rc) return rc;
   }
   if (dbias) {
-    const size_t off = wgrad_slab_bytes(d->Cout, d->Cin, d->KH, d->KW, d->B * d->OH * d->OW);
+    const size_t off = wgrad_slab_bytes(d->Cout, d->Cin, d->KH, d->KW, d->B * d->OH * d->OW, conv_wino_wgrad_floats(d));
     if (ws_bytes < off) return fail(HIM_E_WORKSPACE, "bwd_weight ws too small");
     rc = run_bias_grad(dy, dbias, d->B, d->Cout, d->OH * d->OW, accumulate, (char*)ws + off, ws_bytes - off,
                        (hipStream_t)stream);

@@ -165,10 +165,14 @@ class _Panel(object):
 
 
 def _panel_token(w):
-    return (w._version, w.data_ptr(), getattr(w, '_him_gen', 0))
+    return (w._version, w.data_ptr(), getattr(w, '_him_gen', 0), _WINO_GEN)
 
 
 def _build_panel(w, e):
+    nb = int((lib.him_deconv2d_panel_bytes if e.is_deconv else lib.him_conv2d_panel_bytes)(ctypes.byref(e.desc), e.kind))
+    if nb != e.nbytes:                       # the Winograd threshold moved: different panel layout
+        e.nbytes = nb
+        e.buf = torch.empty(max(nb // 4, 1), dtype=torch.float32, device=w.device)
     fn = lib.him_deconv2d_panel_build if e.is_deconv else lib.him_conv2d_panel_build
     fn(ctypes.byref(e.desc), e.kind, _p(w), _p(e.buf), e.nbytes, _stream())
     e.token = _panel_token(w)
@@ -217,6 +221,18 @@ def refresh_panels(params):
 def invalidate_panels(params):
     for p in params:
         p._him_gen = getattr(p, '_him_gen', 0) + 1
+
+
+def set_winograd_min_channels(c):
+    """3x3 stride-1 convs with >= c channels on both sides run as Winograd F(2x2,3x3) (c <= 0: off).  Cached panels
+    are keyed by the setting.  Returns the previous value."""
+    global _WINO_GEN
+    prev = int(lib.him_set_winograd_min_channels(int(c)))
+    _WINO_GEN += 1
+    return prev - (1 << 32) if prev >= (1 << 31) else prev
+
+
+_WINO_GEN = 0
 
 
 class _Conv2d(torch.autograd.Function):

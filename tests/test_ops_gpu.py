@@ -325,3 +325,43 @@ def test_weight_panel_cache_matches_plain_path_and_tracks_updates():
         y3r = run(x, (w0 * 3.0).requires_grad_(True))
         (gx3r,) = torch.autograd.grad(y3r, x, gy)
         assert torch.equal(y3, y3r) and torch.equal(gx3, gx3r)
+
+
+WINO_CASES = [
+    # B, Cin, H, W, Cout, pad_mode   (threshold forced down to 16 channels so small shapes take the Winograd path)
+    (2, 32, 16, 32, 32, 'reflect'),      # ResnetBlock shape family
+    (2, 32, 16, 32, 48, 'zero'),         # VGG-style zero padding
+    (1, 48, 9, 13, 32, 'reflect'),       # odd H and W: partial 2x2 tiles on both edges
+    (3, 16, 2, 2, 16, 'reflect'),        # a single tile per image
+    (1, 128, 6, 10, 128, 'reflect'),     # 128-multiple channels: Winograd weight gradient (batched NT GEMM)
+    (2, 128, 8, 8, 256, 'zero'),         # Winograd weight gradient, rectangular
+]
+
+
+@pytest.mark.parametrize('case', WINO_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_winograd_conv3x3_fwd_bwd(case):
+    """Winograd F(2x2,3x3) forward / data gradient / weight gradient against the fp32 torch reference of the SAME op
+    (tolerance 2e-5 of max|ref|: the transform-domain rounding is a few ulps above the direct form)."""
+    ops = _ops()
+    B, Cin, H, W, Cout, pm = case
+    prev = ops.set_winograd_min_channels(16)
+    try:
+        x = _rand(B, Cin, H, W, seed=1).requires_grad_(True)
+        w = _rand(Cout, Cin, 3, 3, seed=2, scale=(Cin * 9) ** -0.5).requires_grad_(True)
+        b = _rand(Cout, seed=3, scale=0.1).requires_grad_(True)
+        y_ref = _ref_conv(x, w, b, 1, 1, pm, 'relu')
+        gy = _rand(*y_ref.shape, seed=4)
+        gx_ref, gw_ref, gb_ref = torch.autograd.grad(y_ref, (x, w, b), gy)
+        xd, bd = (t.detach().to(DEV).requires_grad_(True) for t in (x, b))
+        for as_param in (False, True):           # plain tensor: per-launch weight transform; Parameter: cached panel
+            wd = w.detach().to(DEV).requires_grad_(True)
+            if as_param:
+                wd = torch.nn.Parameter(wd.detach())
+            y = ops.conv2d(xd, wd, bd, 1, 1, pm, 'relu', 0.2)
+            assert_close('wino fwd', y, y_ref, rtol=2e-5)
+            gx, gw, gb = torch.autograd.grad(y, (xd, wd, bd), gy.to(DEV))
+            assert_close('wino dgrad', gx, gx_ref, rtol=2e-5)
+            assert_close('wino wgrad', gw, gw_ref, rtol=2e-5)
+            assert_close('wino bgrad', gb, gb_ref, rtol=2e-5)
+    finally:
+        ops.set_winograd_min_channels(prev)
