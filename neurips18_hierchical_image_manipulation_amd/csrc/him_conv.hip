@@ -77,14 +77,14 @@ struct GConvP {
 // PM: 0 zero padding, 1 reflection gather (forward of a reflect-padded conv), 2 = PAD_DFOLD: data gradient of a
 // reflect-pad-1 3x3 stride-1 conv read from the border-extended gradient built by reflect_extend_kernel (below).
 template <int WM, int WN, int TM, int TN, int PM, bool CLAMPC>
-__global__ __launch_bounds__(WM * WN * 64) void gconv_fast_kernel(const GConvP p) {
+__global__ __launch_bounds__(WM * WN * 64, (TN == 4 ? 2 : 1)) void gconv_fast_kernel(const GConvP p) {
   constexpr int NT = WM * WN * 64;  // 4 waves (one per SIMD) or 8 waves (two per SIMD: they cover each other's LDS/barrier bubbles)
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 16, LD = 20;
   constexpr int A_V4 = BM * BK / 4 / NT;  // float4 loads per thread for the weight tile
   constexpr int AROWS = NT / 4;           // weight-tile rows covered per pass
   constexpr int KPT = BK * BN / NT;       // consecutive channels per thread in the gathered tile (8 or 4)
   static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
-  static_assert((A_V4 == 1 || A_V4 == 2) && (KPT == 4 || KPT == 8), "tile shape");
+  static_assert((A_V4 == 1 || A_V4 == 2) && (KPT == 4 || KPT == 8 || KPT == 16), "tile shape");
   __shared__ __attribute__((aligned(16))) float sA[2][BM * LD];
   __shared__ __attribute__((aligned(16))) float sB[2][BN * LD];
 
@@ -827,7 +827,15 @@ static int launch_gconv(const GConvP& p, hipStream_t st) {
     } else {
       const long long tiles128 = (long long)cdiv(maxN, 128) * cdiv(p.M, 128) * p.nphase;
       const bool big = tile_override >= 0 ? tile_override == 1 : (tiles128 >= 512 || (tiles128 >= 200 && tiles128 <= 256));
-      if (tile_override == 2) {
+      const long long plane0 = (long long)p.ph[0].NA * p.ph[0].NC;
+      const long long tiles256 = (maxN / 256) * cdiv(p.M, 128);
+      if (tile_override == 3 && p.wbatch && ks == 1 && p.nphase == 1 && plane0 % 256 == 0 && tiles256 % 512 == 0) {
+        // experiment (HIM_GCONV_TILE=3): 128x256 tiles for the batched Winograd GEMM, two workgroups per CU.  Alone it
+        // matches / beats the 128x128 tiling (weight-gradient GEMM 0.53 -> 0.42 ms) but its 232 VGPRs + 60 KB LDS stop
+        // it from sharing a CU with the other stream's kernels: the full step fell from 98 to 69 images/s.
+        dim3 grid((unsigned)tiles256, 1, 1);
+        launch_fast_cfg<2, 2, 2, 4>(p, grid, st);
+      } else if (tile_override == 2) {
         dim3 grid(cdiv(maxN, 128) * cdiv(p.M, 128), ks, p.nphase);
         launch_fast_cfg<2, 4, 2, 1>(p, grid, st);  // 8 waves per 128x128 tile (measured: lockstep, no better than 4)
       } else if (big || ks > 1) {
@@ -1010,7 +1018,7 @@ __global__ __launch_bounds__(256) void reflect_extend_kernel(const float* __rest
 // Data gradient: same machinery with the flipped/transposed filter (U'); for reflect padding it produces the padded
 // gradient (full correlation, offset 2) which reflect_fold_kernel folds.  Weight gradient:
 //   dU[pos][co][ci] = sum_tile dM[pos][co][tile] * V[pos][ci][tile],  dM = A dY A^T,  dg = G^T dU G
-// = one batched NT GEMM (wino_gemm_nt_kernel) + transforms.
+// = the same batched GEMM with the tiles as reduction index (dM is the row-major panel, V is produced transposed).
 // Tile index t = (b*TY + ty)*TX + tx, padded to Tp (multiple of 128) so GEMM tiles never straddle a position slab.
 // ==============================================================================================
 struct WinoGeom {
@@ -1081,6 +1089,69 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
   }
   const size_t slab = (size_t)g.C * g.Tp;
   float* __restrict__ o = V + (size_t)c * g.Tp + t;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    o[(size_t)(i * 4 + 0) * slab] = tt[i][0] - tt[i][2];
+    o[(size_t)(i * 4 + 1) * slab] = tt[i][1] + tt[i][2];
+    o[(size_t)(i * 4 + 2) * slab] = tt[i][2] - tt[i][1];
+    o[(size_t)(i * 4 + 3) * slab] = tt[i][1] - tt[i][3];
+  }
+}
+
+// Same transform, TRANSPOSED output Vt[pos][t][c] (c fastest) -- the column operand of the weight-gradient GEMM, whose
+// reduction runs over the tiles t.  Threads run along c so the stores are coalesced; the 16 patch loads of a thread
+// are 2 KB apart across lanes but come from the L2-resident activation.  grid (ceil(C/256), Tp)
+template <bool REFLECT>
+__global__ __launch_bounds__(256) void wino_input_t_kernel(const float* __restrict__ x, float* __restrict__ Vt,
+                                                           const WinoGeom g) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int t = blockIdx.y;
+  if (c >= g.C) return;
+  float d[4][4];
+  if (t < g.T) {
+    const int per = g.TY * g.TX;
+    const int b = t / per, r = t - b * per, ty = r / g.TX, tx = r - ty * g.TX;
+    const float* __restrict__ src = x + ((size_t)b * g.C + c) * g.H * g.W;
+    int ys[4], xs[4];
+    bool oky[4], okx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int iy = 2 * ty - g.po + i, ix = 2 * tx - g.po + i;
+      if (REFLECT) {
+        iy = iy < 0 ? -iy : iy;
+        iy = iy >= g.H ? 2 * (g.H - 1) - iy : iy;
+        ix = ix < 0 ? -ix : ix;
+        ix = ix >= g.W ? 2 * (g.W - 1) - ix : ix;
+      }
+      const int cy = min(max(iy, 0), g.H - 1), cx = min(max(ix, 0), g.W - 1);
+      oky[i] = REFLECT || cy == iy;
+      okx[i] = REFLECT || cx == ix;
+      ys[i] = cy * g.W;
+      xs[i] = cx;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float v = src[ys[i] + xs[j]];
+        d[i][j] = (oky[i] && okx[j]) ? v : 0.f;
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[i][j] = 0.f;
+  }
+  float tt[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    tt[0][j] = d[0][j] - d[2][j];
+    tt[1][j] = d[1][j] + d[2][j];
+    tt[2][j] = d[2][j] - d[1][j];
+    tt[3][j] = d[1][j] - d[3][j];
+  }
+  const size_t slab = (size_t)g.C * g.Tp;
+  float* __restrict__ o = Vt + (size_t)t * g.C + c;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     o[(size_t)(i * 4 + 0) * slab] = tt[i][0] - tt[i][2];
@@ -1232,100 +1303,6 @@ __global__ __launch_bounds__(256) void wino_wgrad_out_kernel(const float* __rest
   }
 }
 
-// Batched NT GEMM on fp32 MFMA: Cm[z][m][n] = sum_k A[z][m][k] * Bm[z][n][k]; M, N multiples of 128, K of 32.
-// 128x128 tile per 256-thread workgroup (2x2 waves x 2x2 MFMA tiles), BK = 32, both operand tiles are contiguous
-// float4 rows (k fastest), LDS [row][32+4] read with aligned ds_read_b128 (k <-> lane>>5 pairing as wgrad_fast).
-// 1-D grid, XCD-aware: each XCD owns whole batches (both operands of a batch stream through its L2 once).
-__global__ __launch_bounds__(256) void wino_gemm_nt_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
-                                                           float* __restrict__ Cm, int M, int N, int K) {
-  constexpr int BM = 128, BN = 128, BK = 32, LD = 36;
-  __shared__ __attribute__((aligned(16))) float sA[2][BM * LD];
-  __shared__ __attribute__((aligned(16))) float sB[2][BN * LD];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  int z, m0, n0;
-  {
-    const int total = gridDim.x, L = blockIdx.x;
-    const int q = total >> 3, r = total & 7, xcd = L & 7, slot = L >> 3;
-    const int T = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    const int nmt = M / BM, nnt = N / BN, per = nmt * nnt;
-    z = T / per;
-    const int rem = T - z * per, mt = rem / nnt;
-    m0 = mt * BM;
-    n0 = (rem - mt * nnt) * BN;
-  }
-  const float* __restrict__ Ab = A + ((size_t)z * M + m0) * K;
-  const float* __restrict__ Bb = Bm + ((size_t)z * N + n0) * K;
-  const int row = t >> 3, kq = t & 7;  // thread -> rows row + 32 i, k quad kq
-  float4 ra[4], rb[4];
-  const int nk = K / BK;
-#define HIM_NT_LOAD(kt_)                                                                   \
-  {                                                                                        \
-    const size_t ko = (size_t)(kt_) * BK + kq * 4;                                         \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                        \
-      ra[i] = *(const float4*)(Ab + (size_t)(row + 32 * i) * K + ko);                      \
-      rb[i] = *(const float4*)(Bb + (size_t)(row + 32 * i) * K + ko);                      \
-    }                                                                                      \
-  }
-#define HIM_NT_STORE(buf_)                                                                 \
-  {                                                                                        \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                        \
-      *(float4*)&sA[buf_][(row + 32 * i) * LD + kq * 4] = ra[i];                           \
-      *(float4*)&sB[buf_][(row + 32 * i) * LD + kq * 4] = rb[i];                           \
-    }                                                                                      \
-  }
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  const int l31 = lane & 31, lh = lane >> 5;
-  HIM_NT_LOAD(0)
-  HIM_NT_STORE(0)
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    const float4* __restrict__ pa = (const float4*)&sA[buf][(wm * 64 + l31) * LD + lh * 16];
-    const float4* __restrict__ pb = (const float4*)&sB[buf][(wn * 64 + l31) * LD + lh * 16];
-    float4 af[2][4], bf[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        af[i][q] = pa[i * 32 * LD / 4 + q];
-        bf[i][q] = pb[i * 32 * LD / 4 + q];
-      }
-    if (kt + 1 < nk) HIM_NT_LOAD(kt + 1)
-#define HIM_NT_M(Q, CMP)                                                                                     \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] =    \
-      __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][Q].CMP, bf[j][Q].CMP, acc[i][j], 0, 0, 0);
-    HIM_NT_M(0, x) HIM_NT_M(0, y) HIM_NT_M(0, z) HIM_NT_M(0, w)
-    HIM_NT_M(1, x) HIM_NT_M(1, y) HIM_NT_M(1, z) HIM_NT_M(1, w)
-    HIM_NT_M(2, x) HIM_NT_M(2, y) HIM_NT_M(2, z) HIM_NT_M(2, w)
-    HIM_NT_M(3, x) HIM_NT_M(3, y) HIM_NT_M(3, z) HIM_NT_M(3, w)
-#undef HIM_NT_M
-    if (kt + 1 < nk) HIM_NT_STORE(buf ^ 1)
-    __syncthreads();
-  }
-#undef HIM_NT_LOAD
-#undef HIM_NT_STORE
-  float* __restrict__ out = Cm + ((size_t)z * M + m0) * N + n0;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = wn * 64 + j * 32 + l31;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        out[(size_t)m * N + n] = acc[i][j][r];
-      }
-  }
-}
-
-
 // ---- Winograd host side -------------------------------------------------------------------------------------------
 static int g_wino_min_c = -2;  // -2: not initialised; <= 0: Winograd off
 static int wino_min_c() {
@@ -1352,6 +1329,38 @@ static size_t wino_wgrad_floats(int B, int M, int C, int OH, int OW) {
   const WinoGeom g = wino_geom(B, C, 1, 1, OH, OW, 1);
   return (size_t)16 * (C + M) * g.Tp + (size_t)16 * M * C;
 }
+// Cm[z][m][n] = sum_k A[z][m][k] * Bm[z][k][n] for the 16 transform positions z, on the fast MFMA conv kernel: a 1x1
+// convolution over 16 "images" [K][1][N] with per-image weight panels.  K % 16 == 0, N % 128 == 0.
+static int wino_batched_gemm(const float* A, const float* Bm, float* Cm, int M, int K, int N, hipStream_t st) {
+  GConvP g;
+  memset(&g, 0, sizeof(g));
+  g.src = Bm;
+  g.dst = Cm;
+  g.M = M;
+  g.C2 = K;
+  g.B = 16;
+  g.SH = 1;
+  g.SW = N;
+  g.DH = 1;
+  g.DW = N;
+  g.oys = g.oxs = g.sy = g.sx = g.dy = g.dx = 1;
+  g.pad_mode = HIM_PAD_ZERO;
+  g.act = HIM_ACT_NONE;
+  g.nphase = 1;
+  g.fast = 1;
+  g.wbatch = M * K;
+  GPhase& P = g.ph[0];
+  P.A = A;
+  P.At = A;
+  P.C2p = K;
+  P.K = K;
+  P.JH = P.JW = 1;
+  P.fJHJW = make_fastdiv(1);
+  P.fJW = make_fastdiv(1);
+  P.NA = 1;
+  P.NC = N;
+  return launch_gconv(g, st);
+}
 // dst[B][Mout][OH][OW] = act(winograd-conv(src[B][Csrc][H][W], U) + bias); ws holds V and Mo
 static int run_wino_conv(int B, int Csrc, int H, int W, int Mout, int OH, int OW, int po, bool reflect,
                          const float* src, const float* U, const float* bias, int act, float slope, float* dst,
@@ -1364,34 +1373,7 @@ static int run_wino_conv(int B, int Csrc, int H, int W, int Mout, int OH, int OW
   else hipLaunchKernelGGL((wino_input_kernel<false>), gin, dim3(256), 0, st, src, V, gi);
   int rc = check_launch("wino_input");
   if (rc) return rc;
-  GConvP g;
-  memset(&g, 0, sizeof(g));
-  g.src = V;
-  g.dst = Mo;
-  g.M = Mout;
-  g.C2 = Csrc;
-  g.B = 16;
-  g.SH = 1;
-  g.SW = gi.Tp;
-  g.DH = 1;
-  g.DW = gi.Tp;
-  g.oys = g.oxs = g.sy = g.sx = g.dy = g.dx = 1;
-  g.pad_mode = HIM_PAD_ZERO;
-  g.act = HIM_ACT_NONE;
-  g.nphase = 1;
-  g.fast = 1;
-  g.wbatch = Mout * Csrc;
-  GPhase& P = g.ph[0];
-  P.A = U;
-  P.At = U;
-  P.C2p = Csrc;
-  P.K = Csrc;
-  P.JH = P.JW = 1;
-  P.fJHJW = make_fastdiv(1);
-  P.fJW = make_fastdiv(1);
-  P.NA = 1;
-  P.NC = gi.Tp;
-  rc = launch_gconv(g, st);
+  rc = wino_batched_gemm(U, V, Mo, Mout, Csrc, gi.Tp, st);
   if (rc) return rc;
   WinoGeom go = gi;
   go.C = Mout;
@@ -1981,18 +1963,16 @@ static int run_wgrad(const float* dy, const float* x, float* dw, int M, int C, i
     const WinoGeom gx = wino_geom(B, C, H, W, OH, OW, 1);
     WinoGeom gd = gx;
     gd.C = M;
-    float* V = (float*)ws;
-    float* dM = V + (size_t)16 * C * gx.Tp;
-    float* dU = dM + (size_t)16 * M * gx.Tp;
-    const dim3 gin(cdiv(gx.Tp, 256), C);
-    if (pad_mode == HIM_PAD_REFLECT) hipLaunchKernelGGL((wino_input_kernel<true>), gin, dim3(256), 0, st, x, V, gx);
-    else hipLaunchKernelGGL((wino_input_kernel<false>), gin, dim3(256), 0, st, x, V, gx);
+    float* Vt = (float*)ws;                          // [16][Tp][C]
+    float* dM = Vt + (size_t)16 * C * gx.Tp;         // [16][M][Tp]
+    float* dU = dM + (size_t)16 * M * gx.Tp;         // [16][M][C]
+    const dim3 gin(cdiv(C, 256), gx.Tp);
+    if (pad_mode == HIM_PAD_REFLECT) hipLaunchKernelGGL((wino_input_t_kernel<true>), gin, dim3(256), 0, st, x, Vt, gx);
+    else hipLaunchKernelGGL((wino_input_t_kernel<false>), gin, dim3(256), 0, st, x, Vt, gx);
     hipLaunchKernelGGL(wino_dy_kernel, dim3(cdiv(gx.Tp, 256), M), dim3(256), 0, st, dy, dM, gd);
     int rcw = check_launch("wino_wgrad_transforms");
     if (rcw) return rcw;
-    hipLaunchKernelGGL(wino_gemm_nt_kernel, dim3(16 * (M / 128) * (C / 128)), dim3(256), 0, st, (const float*)dM,
-                       (const float*)V, dU, M, C, gx.Tp);
-    rcw = check_launch("wino_gemm_nt");
+    rcw = wino_batched_gemm(dM, Vt, dU, M, gx.Tp, C, st);
     if (rcw) return rcw;
     hipLaunchKernelGGL(wino_wgrad_out_kernel, dim3(cdiv(C, 256), M), dim3(256), 0, st, (const float*)dU, dw, M, C,
                        accumulate);
