@@ -43,38 +43,61 @@ def _event_ms(fn, iters):
 
 
 def dominant_kernel_roofline(device):
-    """ResnetBlock conv: refpad(1) + conv3x3 1024->1024 on (8,1024,16,32): GEMM M=1024, N=4096, K=9216 =
-    77.31 GFLOP per launch; 18 of them = 70.6 % of the generator's forward FLOPs (and the same GEMM again in every
-    data/weight gradient).  MFMA-bound (algorithmic intensity ~1090 FLOP/B >> the fp32 ridge of ~25).
-    Timed with HIP events on the launch stream; the time includes the split-K finish kernel that belongs to the
-    launch (so `achieved` is a lower bound for the MFMA kernel itself); the weight panel is cached as in training.
+    """The launch that carries most of the step's matrix work: stage 2 of the Winograd F(2x2,3x3) ResnetBlock conv
+    (refpad(1) + conv3x3 1024->1024 on (8,1024,16,32)) = ONE batched fp32-MFMA GEMM over the 16 transform positions,
+    [16] x (1024 x 1024) x (1024 x 1024 tiles) = 34.36 GFLOP EXECUTED per launch (the direct form of the same conv is
+    77.31 GFLOP: Winograd does 2.25x fewer multiplies).  18 forward + 18 data-gradient + 18 weight-gradient launches of
+    this shape per step.  `achieved` = executed FLOP / average launch time, HIP events on the launch stream around
+    him_winograd_gemm (exactly the kernel the conv launches); MFMA-bound: algorithmic bytes = the three 67.1 MB
+    operands read/written once = 201 MB, intensity 171 FLOP/B >> the fp32 ridge of ~25.
     `traffic` = HBM-side bytes per launch from the committed PMC passes (profiles/r01_pmc_dominant_kernel.json:
-    FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE), null if that file is absent."""
+    FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE), null if that file is absent.
+    `conv_launch` times the WHOLE conv (input transform + GEMM + output transform, cached weight panel) and states its
+    rate in direct-form-equivalent FLOP, for comparison with a non-Winograd implementation."""
     from neurips18_hierchical_image_manipulation_amd import ops
-    x = torch.randn(BS, 1024, 16, 32, device=device)
-    # a Parameter, as in the trainer: its regrouped weight panel is cached (rebuilt once per optimizer step)
-    w = torch.nn.Parameter(torch.randn(1024, 1024, 3, 3, device=device) * 0.02, requires_grad=False)
-    b = torch.zeros(1024, device=device)
-    with torch.no_grad():
-        fn = lambda: ops.conv2d(x, w, b, 1, 1, 'reflect', 'none')  # noqa: E731
-        for _ in range(3):
-            fn()
-        ms = _event_ms(fn, 20)
-    flops = 2.0 * 1024 * (BS * 16 * 32) * (1024 * 9)
+    from neurips18_hierchical_image_manipulation_amd._cabi import lib
+    M = K = N = 1024
+    a = torch.randn(16, M, K, device=device) * 0.02
+    b = torch.randn(16, K, N, device=device)
+    c = torch.empty(16, M, N, device=device)
+    st = torch.cuda.current_stream().cuda_stream
+    gemm = lambda: lib.him_winograd_gemm(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, K, N, st)  # noqa: E731
+    for _ in range(3):
+        gemm()
+    ms = _event_ms(gemm, 20)
+    flops = 2.0 * 16 * M * K * N
     ach = flops / (ms * 1e-3) / 1e12
+    # the whole conv launch, as the trainer runs it (Parameter weight: cached Winograd panel)
+    x = torch.randn(BS, 1024, 16, 32, device=device)
+    w = torch.nn.Parameter(torch.randn(1024, 1024, 3, 3, device=device) * 0.02, requires_grad=False)
+    bias = torch.zeros(1024, device=device)
+    with torch.no_grad():
+        conv = lambda: ops.conv2d(x, w, bias, 1, 1, 'reflect', 'none')  # noqa: E731
+        for _ in range(3):
+            conv()
+        cms = _event_ms(conv, 20)
+    direct = 2.0 * 1024 * (BS * 16 * 32) * (1024 * 9)
     traffic = None
     pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_dominant_kernel.json')
     if os.path.isfile(pmc):
         with open(pmc) as f:
             traffic = int(json.load(f)['traffic_bytes_corrected'])
-    return dict(bound='mfma', kernel='gconv_fast_kernel<2,2,2,2,PM=1(reflect),false> (ResnetBlock conv3x3 1024->1024 @16x32, bs 8)',
+    return dict(bound='mfma',
+                kernel='gconv_fast_kernel<2,2,2,2,0,false> as the batched Winograd GEMM [16]x(1024x1024)x(1024x1024) '
+                       '(ResnetBlock conv3x3 1024->1024 @16x32, bs 8)',
                 achieved=round(ach, 2), peak=PEAK_F32_MFMA, unit='TFLOP/s', frac=round(ach / PEAK_F32_MFMA, 4),
-                traffic=traffic, traffic_unit='bytes/launch (PMC, corrected)', algorithmic_bytes=71303168,
-                flop_per_launch=flops, avg_launch_ms=round(ms, 4))
+                traffic=traffic, traffic_unit='bytes/launch (PMC, corrected)', algorithmic_bytes=3 * 16 * M * N * 4,
+                flop_per_launch=flops, avg_launch_ms=round(ms, 4),
+                conv_launch=dict(ms=round(cms, 4), direct_form_gflop=round(direct / 1e9, 2),
+                                 direct_form_equivalent_tflops=round(direct / (cms * 1e-3) / 1e12, 1),
+                                 executed_tflops=round(flops / (cms * 1e-3) / 1e12, 1)))
 
 
 def g_forward_roofline(model, batch):
-    """The 'fused G-conv forward' the north star prices: whole GlobalGenerator forward at C2 = 1.970 TFLOP."""
+    """The 'fused G-conv forward' the north star prices: whole GlobalGenerator forward at C2.  SURVEY 8(d) counts it in
+    direct-form FLOP (1.970 TFLOP per bs-8 batch); the 18 ResnetBlock convs run as Winograd and execute 34.36 instead of
+    77.31 GFLOP each, i.e. 1.197 TFLOP are actually issued to the matrix pipe.  Both rates are reported; the roofline
+    fraction is the EXECUTED one."""
     with torch.no_grad():
         model.encode_input(batch['label'], batch['inst'], batch['image'], None, mask_in=batch['mask_in'])
         buf, _, _, mask = model._enc
@@ -82,8 +105,15 @@ def g_forward_roofline(model, batch):
         for _ in range(2):
             fn()
         ms = _event_ms(fn, 5)
-    tf = G_FWD_GFLOP_PER_IMG * BS / 1e3 / (ms * 1e-3)
-    return dict(ms=round(ms, 3), tflops=round(tf, 2), frac_of_f32_mfma_peak=round(tf / PEAK_F32_MFMA, 4))
+    direct = G_FWD_GFLOP_PER_IMG * BS / 1e3
+    from neurips18_hierchical_image_manipulation_amd import ops
+    wino = ops.set_winograd_min_channels(0)
+    ops.set_winograd_min_channels(wino)
+    executed = direct - (18 * (77.309 - 34.360) / 1e3 if 0 < wino <= 1024 else 0.0)
+    return dict(ms=round(ms, 3), tflops_direct_form_equivalent=round(direct / (ms * 1e-3), 2),
+                tflops_executed=round(executed / (ms * 1e-3), 2),
+                frac_of_f32_mfma_peak=round(executed / (ms * 1e-3) / PEAK_F32_MFMA, 4),
+                frac_direct_form_equivalent=round(direct / (ms * 1e-3) / PEAK_F32_MFMA, 4))
 
 
 def cpu_baseline():

@@ -115,6 +115,11 @@ int him_deconv2d_bwd_weight(const HimDeconv2d* d, const float* x, const float* d
  * it only between steps, then rebuild cached panels.  c <= 0 turns it off.  Returns the previous value. */
 int him_set_winograd_min_channels(int c);
 
+/* Stage 2 of the Winograd convolution on its own: c[z][m][n] = sum_k a[z][m][k] * b[z][k][n] for the 16 transform
+ * positions z (a: [16][M][K] weight/gradient panels, b: [16][K][N], c: [16][M][N]; K % 16 == 0, N % 128 == 0).
+ * This is the launch the roofline in bench.py is measured on (fp32 MFMA, 2*16*M*K*N executed FLOP). */
+int him_winograd_gemm(const float* a, const float* b, float* c, int M, int K, int N, void* stream);
+
 #define HIM_PANEL_FWD 0
 #define HIM_PANEL_BWD_DATA 1
 size_t him_conv2d_panel_bytes(const HimConv2d* d, int kind);

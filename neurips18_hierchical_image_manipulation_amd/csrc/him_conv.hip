@@ -2447,6 +2447,14 @@ int him_set_winograd_min_channels(int c) {
   return prev;
 }
 
+int him_winograd_gemm(const float* a, const float* b, float* c, int M, int K, int N, void* stream) {
+  if (!a || !b || !c || M <= 4 || K < 16 || (K % 16) || N <= 0 || (N % 128))
+    return fail(HIM_E_INVALID, "winograd gemm: need M > 4, K %% 16 == 0, N %% 128 == 0 (got %d, %d, %d)", M, K, N);
+  if ((long long)16 * K * N >= (1ll << 31) || (long long)16 * M * N >= (1ll << 31))
+    return fail(HIM_E_UNSUPPORTED, "winograd gemm: operand larger than 2^31 elements");
+  return wino_batched_gemm(a, b, c, M, K, N, (hipStream_t)stream);
+}
+
 size_t him_conv2d_fwd_ws(const HimConv2d* d) { return d ? fprop_ws_bytes(d) : 0; }
 
 int him_conv2d_fwd(const HimConv2d* d, const float* x, const float* w, const float* bias, float* y, void* ws,
