@@ -14,8 +14,10 @@ from neurips18_hierchical_image_manipulation_amd._cabi import lib
 
 
 def main():
-    M = K = N = 1024
+    M = K = 1024
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 15
+    N = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+    K = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
     a = torch.randn(16, M, K, device='cuda') * 0.02
     b = torch.randn(16, K, N, device='cuda')
     c = torch.empty(16, M, N, device='cuda')
