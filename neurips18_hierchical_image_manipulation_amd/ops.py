@@ -252,7 +252,9 @@ class _Conv2d(torch.autograd.Function):
             lib.him_conv2d_fwd(ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), _p(ws), nb, _stream())
         ctx.d = d
         ctx.x, ctx.w, ctx.b = x, w, b
-        ctx.y = y if act != ACT_NONE else None
+        # the OUTPUT must go through save_for_backward: a plain ctx attribute closes a tensor -> grad_fn -> ctx -> tensor
+        # cycle through C++ that no collector sees, and with it the whole upstream graph of every step leaks
+        ctx.save_for_backward(y if act != ACT_NONE else None)
         return y
 
     @staticmethod
@@ -264,7 +266,7 @@ class _Conv2d(torch.autograd.Function):
         st = _stream()
         if d.act != ACT_NONE:
             dz = torch.empty_like(dy)
-            lib.him_act_bwd(_p(ctx.y), _p(dy), _p(dz), dy.numel(), d.act, d.slope, st)
+            lib.him_act_bwd(_p(ctx.saved_tensors[0]), _p(dy), _p(dz), dy.numel(), d.act, d.slope, st)
         else:
             dz = dy
         dx = dw = db = None
@@ -327,7 +329,9 @@ class _Deconv2d(torch.autograd.Function):
             lib.him_deconv2d_fwd(ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), _p(ws), nb, _stream())
         ctx.d = d
         ctx.x, ctx.w, ctx.b = x, w, b
-        ctx.y = y if act != ACT_NONE else None
+        # the OUTPUT must go through save_for_backward: a plain ctx attribute closes a tensor -> grad_fn -> ctx -> tensor
+        # cycle through C++ that no collector sees, and with it the whole upstream graph of every step leaks
+        ctx.save_for_backward(y if act != ACT_NONE else None)
         return y
 
     @staticmethod
@@ -339,7 +343,7 @@ class _Deconv2d(torch.autograd.Function):
         st = _stream()
         if d.act != ACT_NONE:
             dz = torch.empty_like(dy)
-            lib.him_act_bwd(_p(ctx.y), _p(dy), _p(dz), dy.numel(), d.act, d.slope, st)
+            lib.him_act_bwd(_p(ctx.saved_tensors[0]), _p(dy), _p(dz), dy.numel(), d.act, d.slope, st)
         else:
             dz = dy
         dx = dw = db = None
@@ -712,7 +716,8 @@ class _SNSigma(torch.autograd.Function):
         nb = lib.him_sn_ws(rows, cols)
         ws = _ws(nb, W)
         lib.him_sn_power_iter_fwd(_p(W2), _p(u), rows, cols, _p(v), _p(u_new), _p(sigma), _p(ws), nb, _stream())
-        ctx.W, ctx.u, ctx.v, ctx.u_new, ctx.sigma = W2, u, v, u_new, sigma
+        ctx.W, ctx.u, ctx.v = W2, u, v
+        ctx.save_for_backward(u_new, sigma)    # outputs: never as plain ctx attributes (uncollectable cycle)
         ctx.shape = W.shape
         ctx.mark_non_differentiable(u_new)
         return sigma, u_new
@@ -727,7 +732,8 @@ class _SNSigma(torch.autograd.Function):
         dW = torch.empty_like(W2)
         nb = lib.him_sn_ws(rows, cols)
         ws = _ws(nb, W2)
-        lib.him_sn_power_iter_bwd(_p(W2), _p(ctx.u), _p(ctx.v), _p(ctx.u_new), _p(ctx.sigma), _p(g), rows, cols,
+        u_new, sigma = ctx.saved_tensors
+        lib.him_sn_power_iter_bwd(_p(W2), _p(ctx.u), _p(ctx.v), _p(u_new), _p(sigma), _p(g), rows, cols,
                                   _p(dW), 0, _p(ws), nb, _stream())
         return dW.view(ctx.shape), None
 
