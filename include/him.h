@@ -95,6 +95,23 @@ int him_deconv2d_bwd_weight(const HimDeconv2d* d, const float* x, const float* d
                             int accumulate, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * One-hot stems: conv over [one-hot(label) | dense channels] evaluated from the label ids.  `label` is the
+ * (B,1,H,W) float id map (data/segmentation_dataset.py:82), channels [0, n_onehot) of x are its one-hot encoding
+ * (him_onehot; reference encode_input models/pix2pixHD_condImg_model.py:150-155) and are never read; channels
+ * [n_onehot, Cin) are ordinary dense inputs.  Replaces nn.Conv2d(input_nc, ngf, 7) of models/Pix2Pix_NET.py:74-76
+ * (GlobalGenerator stem) and :137-140 (two-stream label encoder stem).  stride 1, odd square kernel, pad = K/2
+ * (zero or reflect), Cout % 16 == 0; *_ws returns 0 when the descriptor is not eligible (use him_conv2d_*).
+ * No data gradient: the stem input is data.
+ * -------------------------------------------------------------------------------------------*/
+size_t him_conv2d_onehot_fwd_ws(const HimConv2d* d, int n_onehot);
+int him_conv2d_onehot_fwd(const HimConv2d* d, const float* label, int n_onehot, const float* x, const float* w,
+                          const float* bias, float* y, void* ws, size_t ws_bytes, void* stream);
+size_t him_conv2d_onehot_bwd_weight_ws(const HimConv2d* d, int n_onehot);
+int him_conv2d_onehot_bwd_weight(const HimConv2d* d, const float* label, int n_onehot, const float* x,
+                                 const float* dy, float* dw, float* dbias, int accumulate, void* ws, size_t ws_bytes,
+                                 void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Weight panels.  The MFMA kernels read the weights regrouped (forward: [Cout][Cin/16][KH][KW][16]; data
  * gradient: the transpose, per stride phase).  The plain entry points above rebuild that panel inside the
  * workspace on EVERY launch (75 MB of HBM traffic for a 1024x1024x3x3 ResnetBlock conv); weights only change

@@ -47,6 +47,10 @@ _SIGS = {
     'him_deconv2d_bwd_weight_ws': (c_size_t, [_DECONV]),
     'him_deconv2d_bwd_weight': (c_int, [_DECONV, P, P, P, P, c_int, P, c_size_t, P]),
     'him_set_winograd_min_channels': (C.c_uint, [c_int]),   # returns the previous value (not an error code)
+    'him_conv2d_onehot_fwd_ws': (c_size_t, [_CONV, c_int]),
+    'him_conv2d_onehot_fwd': (c_int, [_CONV, P, c_int, P, P, P, P, P, c_size_t, P]),
+    'him_conv2d_onehot_bwd_weight_ws': (c_size_t, [_CONV, c_int]),
+    'him_conv2d_onehot_bwd_weight': (c_int, [_CONV, P, c_int, P, P, P, P, c_int, P, c_size_t, P]),
     'him_winograd_gemm': (c_int, [P, P, P, c_int, c_int, c_int, P]),
     'him_conv2d_panel_bytes': (c_size_t, [_CONV, c_int]),
     'him_conv2d_panel_build': (c_int, [_CONV, c_int, P, P, c_size_t, P]),

@@ -2410,6 +2410,330 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
   return rc;
 }
 
+
+// ==============================================================================================
+// One-hot stems.  The first conv of the generators (conv7x7 38->64 / 49->64 at full resolution: 12.7 % of the
+// generator's direct-form FLOPs, twice that with its weight gradient) reads [one-hot(label) | dense channels]
+// (reference encode_input, models/pix2pixHD_condImg_model.py:144-174 + the cat at :204).  For the one-hot channels the
+// convolution is a table lookup -- exactly ONE of the label_nc products per (pixel, tap) is non-zero and it is 1.0*w:
+//   y[co][p]      = bias[co] + sum_t W[co][label(p+t)][t]                   (+ the dense channels' ordinary conv)
+//   dW[co][c][t] += sum_{p : label(p+t) = c} dy[co][p]                      (a class-segmented sum of dy)
+// Same sums as the dense form up to fp32 summation order; the label ids replace 35/38 of the MFMA work by LDS
+// lookups / wave reductions.  Labels are the (B,1,H,W) float id maps of the data set; ids outside [0, NC) select
+// nothing (the one-hot column is all zero, as in him_onehot).
+// ==============================================================================================
+struct OneHotP {
+  const float* label;  // [B][H][W] ids as floats
+  int B, H, W, NC, KS, pad, reflect, Cout;
+  int npix;            // B*H*W
+};
+
+// Wt[(t*NC + c)*Cout + co] = w[(co*C + c)*KK + t]
+__global__ void onehot_table_kernel(const float* __restrict__ w, float* __restrict__ Wt, int Cout, int C, int NC, int KK) {
+  const int total = KK * NC * Cout;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int co = i % Cout, r = i / Cout, c = r % NC, t = r / NC;
+    Wt[i] = w[((size_t)co * C + c) * KK + t];
+  }
+}
+
+__device__ __forceinline__ int onehot_label_at(const OneHotP& p, const float* __restrict__ lab, int y, int x) {
+  // returns the class id at (y, x) of the padded image, or -1 (no contribution)
+  bool ok = true;
+  if (p.reflect) {
+    y = y < 0 ? -y : y;
+    y = y >= p.H ? 2 * (p.H - 1) - y : y;
+    x = x < 0 ? -x : x;
+    x = x >= p.W ? 2 * (p.W - 1) - x : x;
+  } else {
+    ok = y >= 0 && y < p.H && x >= 0 && x < p.W;
+  }
+  y = min(max(y, 0), p.H - 1);
+  x = min(max(x, 0), p.W - 1);
+  const int id = (int)lab[y * p.W + x];
+  return (ok && id >= 0 && id < p.NC) ? id : -1;
+}
+
+// y[b][co0+j][p] (+)= sum_t Wt[t][label(p+t)][co0+j], j < 16; then the activation.  The 16-channel slice of the table
+// lives in LDS ([t][c][16], up to 154 KB); workgroups are persistent over pixel tiles.  All KS*KS label loads of a pixel
+// are issued before the first lookup (one resident workgroup per CU: nothing else would cover their latency).
+// grid (nblk, Cout/16)
+template <int KS>
+__global__ __launch_bounds__(1024) void onehot_conv_fwd_kernel(const OneHotP p, const float* __restrict__ Wt,
+                                                              const float* __restrict__ bias, float* __restrict__ y,
+                                                              int add_to_y, int act, float slope) {
+  extern __shared__ __attribute__((aligned(16))) float tab[];
+  constexpr int KK = KS * KS;
+  const int co0 = blockIdx.y * 16;
+  for (int i = threadIdx.x; i < KK * p.NC * 4; i += 1024) {
+    const int e = i >> 2, q = i & 3;
+    *(float4*)&tab[e * 16 + q * 4] = *(const float4*)&Wt[(size_t)e * p.Cout + co0 + q * 4];
+  }
+  __syncthreads();
+  const int HW = p.H * p.W;
+  for (int base = blockIdx.x * 1024; base < p.npix; base += gridDim.x * 1024) {
+    const int n = base + threadIdx.x;
+    if (n >= p.npix) continue;
+    const int b = n / HW, r = n - b * HW, yy = r / p.W, xx = r - yy * p.W;
+    const float* __restrict__ lab = p.label + (size_t)b * HW;
+    float* __restrict__ out = y + ((size_t)b * p.Cout + co0) * HW + r;
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = add_to_y ? out[(size_t)j * HW] : (bias ? bias[co0 + j] : 0.f);
+    int cls[KS], nxt[KS];  // one tap row of labels in flight ahead of the lookups of the current row
+#pragma unroll
+    for (int tw = 0; tw < KS; ++tw) cls[tw] = onehot_label_at(p, lab, yy - p.pad, xx + tw - p.pad);
+#pragma unroll 1
+    for (int th = 0; th < KS; ++th) {
+#pragma unroll
+      for (int tw = 0; tw < KS; ++tw) nxt[tw] = onehot_label_at(p, lab, yy + min(th + 1, KS - 1) - p.pad, xx + tw - p.pad);
+#pragma unroll
+      for (int tw = 0; tw < KS; ++tw) {
+      const int c = cls[tw];
+      const int t = th * KS + tw;
+      const float4* __restrict__ e = (const float4*)&tab[(t * p.NC + max(c, 0)) * 16];
+      const float4 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3];
+      const float m = c >= 0 ? 1.f : 0.f;
+      acc[0] = fmaf(m, e0.x, acc[0]); acc[1] = fmaf(m, e0.y, acc[1]); acc[2] = fmaf(m, e0.z, acc[2]); acc[3] = fmaf(m, e0.w, acc[3]);
+      acc[4] = fmaf(m, e1.x, acc[4]); acc[5] = fmaf(m, e1.y, acc[5]); acc[6] = fmaf(m, e1.z, acc[6]); acc[7] = fmaf(m, e1.w, acc[7]);
+      acc[8] = fmaf(m, e2.x, acc[8]); acc[9] = fmaf(m, e2.y, acc[9]); acc[10] = fmaf(m, e2.z, acc[10]); acc[11] = fmaf(m, e2.w, acc[11]);
+      acc[12] = fmaf(m, e3.x, acc[12]); acc[13] = fmaf(m, e3.y, acc[13]); acc[14] = fmaf(m, e3.z, acc[14]); acc[15] = fmaf(m, e3.w, acc[15]);
+      }
+#pragma unroll
+      for (int tw = 0; tw < KS; ++tw) cls[tw] = nxt[tw];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) out[(size_t)j * HW] = apply_act(acc[j], act, slope);
+  }
+}
+
+// part[blk][t][c][co0 + 4*wave + j] = sum over this block's padded positions q with class(q) = c of dy[co][q - t].
+// Lane-private accumulation: the 64 lanes of a wave are 64 consecutive columns qx of the PADDED image and walk down a
+// strip of rows; a lane keeps the KSxKS window of dy around its position in registers (one new row of KS loads per
+// step, coalesced across the lanes) and adds it to KSxKS private accumulators per output channel -- all positions it
+// visits while its class stays the same share those accumulators (label maps are piecewise constant).  On a class
+// change the lane flushes them into its wave's PRIVATE LDS table with ds_add_f32; 8 waves x 2 output channels (the two
+// channels ride in one v_pk_add_f32; 4 per wave needed 450 registers and spent its time moving AGPRs).
+// grid (pixel-blocks = B * nsx * nyc, Cout/16); dynamic LDS = 16 * KK*NC floats.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// sum over each DPP row (16 lanes) -- the row total ends up in lanes 15, 31, 47, 63
+__device__ __forceinline__ float row_sum_dpp(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));  // row_shr:1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));  // row_shr:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));  // row_shr:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));  // row_shr:8
+  return v;
+}
+
+template <int KS>
+__global__ __launch_bounds__(512) void onehot_wgrad_kernel(const OneHotP p, const float* __restrict__ dy,
+                                                           float* __restrict__ part, int nsx, int nyc, int rows_per) {
+  extern __shared__ __attribute__((aligned(16))) float tab[];
+  constexpr int KK = KS * KS, CPW = 2;  // 2 channels per wave (one v_pk_add_f32), 8 waves = the workgroup's 16 channels
+  const int pad = p.pad, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int co0 = blockIdx.y * 16 + wave * CPW;
+  float* __restrict__ mytab = tab + (size_t)wave * KK * p.NC * CPW;
+  for (int i = lane; i < KK * p.NC * CPW; i += 64) mytab[i] = 0.f;
+  const int H = p.H, W = p.W, HW = H * W;
+  int blk = blockIdx.x;
+  const int yc = blk % nyc;
+  blk /= nyc;
+  const int sx = blk % nsx, b = blk / nsx;
+  // strips start 16 columns left of the image so that the 16-lane DPP rows sit on multiples of 16 in image
+  // coordinates (label regions of real maps and of the synthetic 16x16 blocks then rarely split a row)
+  const int qx = sx * 64 - 16 + lane;
+  const bool lane_on = qx >= -pad && qx < W + pad;
+  const int qy0 = -pad + yc * rows_per, qy1 = min(qy0 + rows_per, H + pad);
+  const float* __restrict__ g = dy + ((size_t)b * p.Cout + co0) * HW;
+  const float* __restrict__ lab = p.label + (size_t)b * HW;
+  // class of padded position (qy, qx): the one-hot image is what gets padded (reflect: mirrored ids; zero: nothing)
+  int lx = qx;
+  bool okx = lane_on;
+  if (p.reflect) {
+    lx = lx < 0 ? -lx : lx;
+    lx = lx >= W ? 2 * (W - 1) - lx : lx;
+  } else {
+    okx = okx && qx >= 0 && qx < W;
+  }
+  lx = min(max(lx, 0), W - 1);
+  int pxs[KS];
+  bool pok[KS];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    const int px = qx - pad + k;
+    pok[k] = lane_on && px >= 0 && px < W;
+    pxs[k] = min(max(px, 0), W - 1);
+  }
+  f32x2 win[KS][KS], acc[KK];
+#pragma unroll
+  for (int t = 0; t < KK; ++t) acc[t] = f32x2{0.f, 0.f};
+  // window rows for the first position: logical slot r holds dy row (qy0 - pad + r)
+#pragma unroll
+  for (int r = 0; r < KS; ++r) {
+    const int py = qy0 - pad + r;
+    const bool oky = py >= 0 && py < H;
+    const int row = min(max(py, 0), H - 1) * W;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      const f32x2 v = f32x2{g[row + pxs[k]], g[(size_t)HW + row + pxs[k]]};
+      win[r][k] = (oky && pok[k]) ? v : f32x2{0.f, 0.f};
+    }
+  }
+#define HIM_OH_CLASS(QY, OUT)                                             \
+  {                                                                       \
+    int ly = (QY);                                                        \
+    bool ok = okx;                                                        \
+    if (p.reflect) {                                                      \
+      ly = ly < 0 ? -ly : ly;                                             \
+      ly = ly >= H ? 2 * (H - 1) - ly : ly;                               \
+    } else {                                                              \
+      ok = ok && (QY) >= 0 && (QY) < H;                                   \
+    }                                                                     \
+    ly = min(max(ly, 0), H - 1);                                          \
+    const int id = (int)lab[ly * W + lx];                                 \
+    OUT = (ok && id >= 0 && id < p.NC) ? id : -1;                         \
+  }
+  // Flush of the private sums.  Fast path (the usual one: label regions are wider than 16 pixels and every lane of the
+  // wave changes class on the same row): all 16 lanes of each DPP row leave the same class -> one DPP row sum per
+  // accumulator and a single ds_add_f32 lane per row; otherwise every flushing lane adds its own sums.
+#define HIM_OH_FLUSH(FLUSHING)                                                                               \
+  {                                                                                                          \
+    int rc = cur; /* class of the row = max over its 16 lanes (lanes without a class carry -1 and zero sums) */ \
+    rc = max(rc, __builtin_amdgcn_update_dpp(-1, rc, 0x111, 0xf, 0xf, false));                               \
+    rc = max(rc, __builtin_amdgcn_update_dpp(-1, rc, 0x112, 0xf, 0xf, false));                               \
+    rc = max(rc, __builtin_amdgcn_update_dpp(-1, rc, 0x114, 0xf, 0xf, false));                               \
+    rc = max(rc, __builtin_amdgcn_update_dpp(-1, rc, 0x118, 0xf, 0xf, false));                               \
+    rc = __shfl(rc, lane | 15);                                                                              \
+    const bool rowu = __ballot((FLUSHING) && (cur < 0 || cur == rc)) == ~0ull;                               \
+    if (rowu) {                                                                                              \
+      _Pragma("unroll") for (int t = 0; t < KK; ++t) {                                                       \
+        const float s0 = row_sum_dpp(cur < 0 ? 0.f : acc[t].x), s1 = row_sum_dpp(cur < 0 ? 0.f : acc[t].y);  \
+        if ((lane & 15) == 15 && rc >= 0) {                                                                  \
+          __hip_atomic_fetch_add(&mytab[(t * p.NC + rc) * CPW], s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     \
+          __hip_atomic_fetch_add(&mytab[(t * p.NC + rc) * CPW + 1], s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+        }                                                                                                    \
+      }                                                                                                      \
+    } else if ((FLUSHING) && cur >= 0) {                                                                     \
+      _Pragma("unroll") for (int t = 0; t < KK; ++t) {                                                       \
+        __hip_atomic_fetch_add(&mytab[(t * p.NC + cur) * CPW], acc[t].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     \
+        __hip_atomic_fetch_add(&mytab[(t * p.NC + cur) * CPW + 1], acc[t].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+      }                                                                                                      \
+    }                                                                                                        \
+  }
+  int cur = -1, cnext;
+  HIM_OH_CLASS(qy0, cnext)
+  for (int qyb = qy0; qyb < qy1; qyb += KS) {
+#pragma unroll
+    for (int ph = 0; ph < KS; ++ph) {
+      const int qy = qyb + ph;
+      if (qy < qy1) {
+        // issue the loads of the row that enters the window at the NEXT position and the next position's class
+        const int pyn = qy + 1 + pad;
+        const bool okn = pyn >= 0 && pyn < H;
+        const int rown = min(max(pyn, 0), H - 1) * W;
+        f32x2 nxt[KS];
+#pragma unroll
+        for (int k = 0; k < KS; ++k) nxt[k] = f32x2{g[rown + pxs[k]], g[(size_t)HW + rown + pxs[k]]};
+        const int c = cnext;
+        HIM_OH_CLASS(qy + 1, cnext)
+        const bool chg = c != cur;
+        if (__ballot(chg)) {  // wave-uniform: some lane leaves its class
+          HIM_OH_FLUSH(chg)
+          if (chg) {
+#pragma unroll
+            for (int t = 0; t < KK; ++t) acc[t] = f32x2{0.f, 0.f};
+            cur = c;
+          }
+        }
+        // acc[th][tw] += dy[q - t] = window row (KS-1-th), column (KS-1-tw); physical row slot = (logical + ph) % KS
+#pragma unroll
+        for (int th = 0; th < KS; ++th)
+#pragma unroll
+          for (int tw = 0; tw < KS; ++tw) acc[th * KS + tw] += win[(KS - 1 - th + ph) % KS][KS - 1 - tw];
+        // the retired row slot (logical 0 = physical ph) receives the new row
+#pragma unroll
+        for (int k = 0; k < KS; ++k) win[ph][k] = (okn && pok[k]) ? nxt[k] : f32x2{0.f, 0.f};
+      }
+    }
+  }
+  HIM_OH_FLUSH(true)
+#undef HIM_OH_CLASS
+#undef HIM_OH_FLUSH
+  __syncthreads();
+  // wave-private table -> part[blk][t][c][Cout] (the CPW channels of this wave)
+  float* __restrict__ dst = part + (size_t)blockIdx.x * KK * p.NC * p.Cout;
+  for (int i = lane; i < KK * p.NC * CPW; i += 64) dst[(size_t)(i / CPW) * p.Cout + co0 + (i % CPW)] = mytab[i];
+}
+
+// dw[co][c][t] (+)= sum_blk part[blk][t][c][co]   (fixed order), c < NC
+__global__ void onehot_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nblk, int Cout,
+                                           int C, int NC, int KK, int accumulate) {
+  const int total = KK * NC * Cout;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int z = 0; z < nblk; ++z) s += part[(size_t)z * total + i];
+    const int co = i % Cout, r = i / Cout, c = r % NC, t = r / NC;
+    float* o = dw + ((size_t)co * C + c) * KK + t;
+    *o = accumulate ? *o + s : s;
+  }
+}
+
+// out[co][c - NC][t] <-> full[co][c][t] for the dense channels c >= NC (dir 0: gather weights; 1: scatter(-add) grads)
+__global__ void onehot_dense_w_kernel(float* __restrict__ full, float* __restrict__ dense, int Cout, int C, int NC, int KK,
+                                      int dir, int accumulate) {
+  const int Cd = C - NC, total = Cout * Cd * KK;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int t = i % KK, r = i / KK, c = r % Cd, co = r / Cd;
+    float* f = full + ((size_t)co * C + NC + c) * KK + t;
+    if (dir == 0) dense[i] = *f;
+    else *f = accumulate ? *f + dense[i] : dense[i];
+  }
+}
+
+static void onehot_wgrad_geom(const HimConv2d* d, int* nsx, int* nyc, int* rows_per) {
+  *nsx = cdiv(d->W + d->pad + 16, 64);  // strips start at column -16
+  *rows_per = 66;
+  *nyc = cdiv(d->H + 2 * d->pad, *rows_per);
+}
+static int onehot_wgrad_blocks(const HimConv2d* d) {
+  int nsx, nyc, rp;
+  onehot_wgrad_geom(d, &nsx, &nyc, &rp);
+  return d->B * nsx * nyc;
+}
+static bool onehot_ok(const HimConv2d* d, int NC) {
+  return d->stride == 1 && d->KH == d->KW && (d->KH == 3 || d->KH == 5 || d->KH == 7) && d->pad == d->KH / 2 && NC >= 2 &&
+         NC <= d->Cin &&
+         (d->Cout % 16) == 0 && (size_t)d->KH * d->KW * NC * 16 * sizeof(float) <= 160 * 1024 && d->OH == d->H &&
+         d->OW == d->W;
+}
+static HimConv2d onehot_dense_desc(const HimConv2d* d, int NC) {
+  HimConv2d dd = *d;
+  dd.Cin = d->Cin - NC;
+  dd.act = HIM_ACT_NONE;
+  return dd;
+}
+// layout of the workspace: [Wt table][dense x copy][dense w copy][dense conv ws]
+static size_t onehot_fwd_ws_bytes(const HimConv2d* d, int NC) {
+  const int Cd = d->Cin - NC, KK = d->KH * d->KW;
+  size_t n = ((size_t)KK * NC * d->Cout + 63) / 64 * 64;
+  if (Cd > 0) {
+    const HimConv2d dd = onehot_dense_desc(d, NC);
+    n += ((size_t)d->B * Cd * d->H * d->W + 63) / 64 * 64 + ((size_t)d->Cout * Cd * KK + 63) / 64 * 64;
+    return n * sizeof(float) + fprop_ws_bytes(&dd) + 256;
+  }
+  return n * sizeof(float) + 256;
+}
+static size_t onehot_wgrad_ws_bytes(const HimConv2d* d, int NC) {
+  const int Cd = d->Cin - NC, KK = d->KH * d->KW;
+  size_t n = (size_t)onehot_wgrad_blocks(d) * KK * NC * d->Cout + 64;
+  if (Cd > 0) {
+    n += ((size_t)d->B * Cd * d->H * d->W + 63) / 64 * 64 + ((size_t)d->Cout * Cd * KK + 63) / 64 * 64;
+    return n * sizeof(float) + wgrad_slab_bytes(d->Cout, Cd, d->KH, d->KW, d->B * d->OH * d->OW) + 256;
+  }
+  return n * sizeof(float) + 256;
+}
+
 static int adjoint_of(const HimDeconv2d* t, HimConv2d* c) {
   if (!t) return fail(HIM_E_INVALID, "null descriptor");
   const int oh = (t->H - 1) * t->stride - 2 * t->pad + t->KH + t->out_pad;
@@ -2526,6 +2850,116 @@ int him_conv2d_bwd_weight(const HimConv2d* d, const float* x, const float* dy, f
     if (ws_bytes < off) return fail(HIM_E_WORKSPACE, "bwd_weight ws too small");
     rc = run_bias_grad(dy, dbias, d->B, d->Cout, d->OH * d->OW, accumulate, (char*)ws + off, ws_bytes - off,
                        (hipStream_t)stream);
+  }
+  return rc;
+}
+
+
+size_t him_conv2d_onehot_fwd_ws(const HimConv2d* d, int n_onehot) {
+  return (d && !check_conv(d) && onehot_ok(d, n_onehot)) ? onehot_fwd_ws_bytes(d, n_onehot) : 0;
+}
+
+int him_conv2d_onehot_fwd(const HimConv2d* d, const float* label, int n_onehot, const float* x, const float* w,
+                          const float* bias, float* y, void* ws, size_t ws_bytes, void* stream) {
+  int rc = check_conv(d);
+  if (rc) return rc;
+  if (!onehot_ok(d, n_onehot)) return fail(HIM_E_UNSUPPORTED, "onehot conv: needs stride 1, odd square kernel, same padding, Cout %% 16 == 0");
+  if (!ws || ws_bytes < onehot_fwd_ws_bytes(d, n_onehot)) return fail(HIM_E_WORKSPACE, "onehot conv fwd: ws too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int NC = n_onehot, Cd = d->Cin - NC, KK = d->KH * d->KW, HW = d->H * d->W;
+  float* Wt = (float*)ws;
+  float* xd = Wt + ((size_t)KK * NC * d->Cout + 63) / 64 * 64;
+  hipLaunchKernelGGL(onehot_table_kernel, dim3(cdiv((long long)KK * NC * d->Cout, 256)), dim3(256), 0, st, w, Wt, d->Cout,
+                     d->Cin, NC, KK);
+  if (Cd > 0) {  // dense channels: the ordinary conv on contiguous copies (bias folded in here)
+    float* wd = xd + ((size_t)d->B * Cd * HW + 63) / 64 * 64;
+    float* cws = wd + ((size_t)d->Cout * Cd * KK + 63) / 64 * 64;
+    rc = him_copy_channels(x, d->Cin, NC, xd, Cd, 0, Cd, d->B, HW, nullptr, 0, 0, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(onehot_dense_w_kernel, dim3(cdiv((long long)d->Cout * Cd * KK, 256)), dim3(256), 0, st,
+                       (float*)w, wd, d->Cout, d->Cin, NC, KK, 0, 0);
+    const HimConv2d dd = onehot_dense_desc(d, NC);
+    rc = run_fprop(&dd, xd, wd, bias, y, cws, fprop_ws_bytes(&dd), st);
+    if (rc) return rc;
+  }
+  OneHotP p;
+  p.label = label;
+  p.B = d->B; p.H = d->H; p.W = d->W; p.NC = NC; p.KS = d->KH; p.pad = d->pad;
+  p.reflect = d->pad_mode == HIM_PAD_REFLECT;
+  p.Cout = d->Cout;
+  p.npix = d->B * HW;
+  const size_t lds = (size_t)KK * NC * 16 * sizeof(float);
+  const dim3 grid(std::min(cdiv(p.npix, 1024), 64), d->Cout / 16);
+#define HIM_OH_FWD(KSv)                                                                                              \
+  {                                                                                                                  \
+    hipFuncSetAttribute((const void*)onehot_conv_fwd_kernel<KSv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((onehot_conv_fwd_kernel<KSv>), grid, dim3(1024), lds, st, p, (const float*)Wt, bias, y,        \
+                       Cd > 0 ? 1 : 0, d->act, d->slope);                                                            \
+  }
+  if (d->KH == 7) HIM_OH_FWD(7)
+  else if (d->KH == 5) HIM_OH_FWD(5)
+  else HIM_OH_FWD(3)
+#undef HIM_OH_FWD
+  return check_launch("onehot_conv_fwd");
+}
+
+size_t him_conv2d_onehot_bwd_weight_ws(const HimConv2d* d, int n_onehot) {
+  return (d && !check_conv(d) && onehot_ok(d, n_onehot)) ? onehot_wgrad_ws_bytes(d, n_onehot) + bias_ws_bytes(d->Cout) : 0;
+}
+
+int him_conv2d_onehot_bwd_weight(const HimConv2d* d, const float* label, int n_onehot, const float* x, const float* dy,
+                                 float* dw, float* dbias, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+  int rc = check_conv(d);
+  if (rc) return rc;
+  if (!onehot_ok(d, n_onehot)) return fail(HIM_E_UNSUPPORTED, "onehot conv: unsupported descriptor");
+  if (!ws || ws_bytes < him_conv2d_onehot_bwd_weight_ws(d, n_onehot))
+    return fail(HIM_E_WORKSPACE, "onehot conv bwd_weight: ws too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int NC = n_onehot, Cd = d->Cin - NC, KK = d->KH * d->KW, HW = d->H * d->W;
+  float* part = (float*)ws;
+  float* xd = part + (size_t)onehot_wgrad_blocks(d) * KK * NC * d->Cout + 64;
+  OneHotP p;
+  p.label = label;
+  p.B = d->B; p.H = d->H; p.W = d->W; p.NC = NC; p.KS = d->KH; p.pad = d->pad;
+  p.reflect = d->pad_mode == HIM_PAD_REFLECT;
+  p.Cout = d->Cout;
+  p.npix = d->B * HW;
+  if (dw) {
+    int nsx, nyc, rows_per;
+    onehot_wgrad_geom(d, &nsx, &nyc, &rows_per);
+    const int nblk = d->B * nsx * nyc;
+    const size_t lds = (size_t)4 * KK * NC * 4 * sizeof(float);
+#define HIM_OH_WG(KSv)                                                                                              \
+  {                                                                                                                 \
+    hipFuncSetAttribute((const void*)onehot_wgrad_kernel<KSv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((onehot_wgrad_kernel<KSv>), dim3(nblk, d->Cout / 16), dim3(512), lds, st, p, dy, part, nsx, nyc, \
+                       rows_per);                                                                                   \
+  }
+    if (d->KH == 7) HIM_OH_WG(7)
+    else if (d->KH == 5) HIM_OH_WG(5)
+    else HIM_OH_WG(3)
+#undef HIM_OH_WG
+    hipLaunchKernelGGL(onehot_wgrad_reduce_kernel, dim3(cdiv((long long)KK * NC * d->Cout, 256)), dim3(256), 0, st,
+                       (const float*)part, dw, nblk, d->Cout, d->Cin, NC, KK, accumulate);
+    rc = check_launch("onehot_wgrad");
+    if (rc) return rc;
+    if (Cd > 0) {
+      float* dwd = xd + ((size_t)d->B * Cd * HW + 63) / 64 * 64;
+      float* wws = dwd + ((size_t)d->Cout * Cd * KK + 63) / 64 * 64;
+      rc = him_copy_channels(x, d->Cin, NC, xd, Cd, 0, Cd, d->B, HW, nullptr, 0, 0, stream);
+      if (rc) return rc;
+      rc = run_wgrad(dy, xd, dwd, d->Cout, Cd, d->B, d->H, d->W, d->OH, d->OW, d->KH, d->KW, d->stride, d->pad,
+                     d->pad_mode, 0, wws, wgrad_slab_bytes(d->Cout, Cd, d->KH, d->KW, d->B * d->OH * d->OW), st);
+      if (rc) return rc;
+      hipLaunchKernelGGL(onehot_dense_w_kernel, dim3(cdiv((long long)d->Cout * Cd * KK, 256)), dim3(256), 0, st, dw, dwd,
+                         d->Cout, d->Cin, NC, KK, 1, accumulate);
+      rc = check_launch("onehot_dense_w");
+      if (rc) return rc;
+    }
+  }
+  if (dbias) {
+    const size_t off = onehot_wgrad_ws_bytes(d, NC);
+    rc = run_bias_grad(dy, dbias, d->B, d->Cout, d->OH * d->OW, accumulate, (char*)ws + off, ws_bytes - off, st);
   }
   return rc;
 }

@@ -300,8 +300,80 @@ class _Conv2d(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None
 
 
+class _OneHotConv2d(torch.autograd.Function):
+    """conv2d over [one-hot(label) | dense channels] evaluated from the label ids (include/him.h "One-hot stems")."""
+
+    @staticmethod
+    def forward(ctx, x, label, n_onehot, w, b, pad, pad_mode, act, slope):
+        ctx.set_materialize_grads(False)
+        x, label = x.contiguous(), label.contiguous()
+        _chk(x, label, w, b)
+        d = _conv_desc(x, w, 1, pad, pad_mode, act, slope)
+        y = torch.empty((d.B, d.Cout, d.OH, d.OW), dtype=torch.float32, device=x.device)
+        nb = lib.him_conv2d_onehot_fwd_ws(ctypes.byref(d), n_onehot)
+        ws = _ws(nb, x)
+        lib.him_conv2d_onehot_fwd(ctypes.byref(d), _p(label), n_onehot, _p(x), _p(w), _p(b), _p(y), _p(ws), nb, _stream())
+        ctx.d, ctx.n_onehot = d, n_onehot
+        ctx.x, ctx.label, ctx.w, ctx.b = x, label, w, b
+        ctx.save_for_backward(y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if dy is None:
+            return (None,) * 9
+        if ctx.needs_input_grad[0]:
+            raise HimError('one-hot stem conv has no data gradient (its input is data)')
+        d, x, label, w, b = ctx.d, ctx.x, ctx.label, ctx.w, ctx.b
+        dy = dy.contiguous()
+        st = _stream()
+        if d.act != ACT_NONE:
+            dz = torch.empty_like(dy)
+            lib.him_act_bwd(_p(ctx.saved_tensors[0]), _p(dy), _p(dz), dy.numel(), d.act, d.slope, st)
+        else:
+            dz = dy
+        dw = db = None
+        skip_w = id(w) in SKIP_WGRAD
+        need_w = ctx.needs_input_grad[3] and not skip_w
+        need_b = b is not None and ctx.needs_input_grad[4] and not skip_w
+        if need_w or need_b:
+            nb = lib.him_conv2d_onehot_bwd_weight_ws(ctypes.byref(d), ctx.n_onehot)
+            if need_w and _direct(w) and (not need_b or _direct(b)):
+                with _wgrad_stream(x, dz, label):
+                    ws = _ws(nb, x)
+                    lib.him_conv2d_onehot_bwd_weight(ctypes.byref(d), _p(label), ctx.n_onehot, _p(x), _p(dz), _p(w.grad),
+                                                     _p(b.grad) if need_b else 0, 1, _p(ws), nb, _stream())
+                    _notify(w)
+                    if need_b:
+                        _notify(b)
+            else:
+                ws = _ws(nb, x)
+                dw = torch.empty_like(w) if need_w else None
+                db = torch.empty_like(b) if need_b else None
+                lib.him_conv2d_onehot_bwd_weight(ctypes.byref(d), _p(label), ctx.n_onehot, _p(x), _p(dz), _p(dw), _p(db), 0,
+                                                 _p(ws), nb, st)
+        return None, None, None, dw, db, None, None, None, None
+
+
+_ONEHOT_ON = os.environ.get('HIM_NO_ONEHOT_STEM') is None
+
+
+def mark_onehot(x, label, n_onehot):
+    """Declare that channels [0, n_onehot) of ``x`` are the one-hot encoding of the id map ``label`` (B,1,H,W): the
+    first convolution applied to ``x`` may then be evaluated from the ids (``_OneHotConv2d``)."""
+    x._him_onehot = (label, int(n_onehot))
+    return x
+
+
 def conv2d(x, w, b=None, stride=1, pad=0, pad_mode='zero', act='none', slope=0.2):
     """act(conv2d(pad(x), w) + b); pad_mode 'reflect' == nn.ReflectionPad2d(pad) + Conv2d(padding=0)."""
+    oh = getattr(x, '_him_onehot', None) if _ONEHOT_ON else None
+    if oh is not None and stride == 1 and not x.requires_grad:
+        label, n_onehot = oh
+        pm = PAD_REFLECT if pad_mode == 'reflect' else PAD_ZERO
+        d = _conv_desc(x, w, 1, pad, pm, ACTS[act], float(slope))
+        if lib.him_conv2d_onehot_fwd_ws(ctypes.byref(d), n_onehot):
+            return _OneHotConv2d.apply(x, label, n_onehot, w, b, pad, pm, ACTS[act], float(slope))
     return _Conv2d.apply(x, w, b, stride, pad, PAD_REFLECT if pad_mode == 'reflect' else PAD_ZERO, ACTS[act],
                          float(slope))
 
@@ -616,6 +688,8 @@ def encode_channels(label, inst, image, mask_in, label_nc, use_edges, extra_afte
     c += 3
     if color_emb is not None:
         lib.him_tile_embed(_p(color_emb), _p(mask_in), _p(buf), B, Ctot, c, hw, st)
+    if label_nc:
+        mark_onehot(buf, label, label_nc)
     return buf, n_label, n_cond
 
 
@@ -625,6 +699,9 @@ def slice_channels(x, c0, n):
     B, Cn, H, W = x.shape
     out = torch.empty((B, n, H, W), dtype=torch.float32, device=x.device)
     lib.him_copy_channels(_p(x), Cn, c0, _p(out), n, 0, n, B, H * W, 0, 0, 0, _stream())
+    oh = getattr(x, '_him_onehot', None)
+    if oh is not None and c0 == 0 and n >= oh[1]:      # a slice that still starts with the whole one-hot block
+        mark_onehot(out, oh[0], oh[1])
     return out
 
 

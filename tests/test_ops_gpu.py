@@ -365,3 +365,49 @@ def test_winograd_conv3x3_fwd_bwd(case):
             assert_close('wino bgrad', gb, gb_ref, rtol=2e-5)
     finally:
         ops.set_winograd_min_channels(prev)
+
+
+ONEHOT_CASES = [
+    # B, NC, Cdense, H, W, Cout, k, pad_mode
+    (2, 35, 3, 24, 40, 64, 7, 'reflect'),     # GlobalGenerator stem (one-hot 35 + cond image 3)
+    (2, 49, 0, 20, 24, 32, 7, 'reflect'),     # two-stream label encoder stem, largest table (49 x 49 x 16 floats)
+    (1, 35, 4, 17, 23, 16, 3, 'zero'),        # zero padding, odd sizes, one-hot + edge + image
+    (3, 5, 2, 9, 70, 16, 5, 'reflect'),       # rows longer than a wave: several class groups per wave
+]
+
+
+@pytest.mark.parametrize('case', ONEHOT_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_onehot_stem_conv_matches_dense_conv(case):
+    """The label-id evaluation of conv([one-hot | dense]) against the fp32 torch conv on the materialised one-hot
+    tensor: forward, weight and bias gradients; run-to-run deterministic.  Includes ids outside [0, NC)."""
+    ops = _ops()
+    B, NC, Cd, H, W, Cout, k, pm = case
+    g = torch.Generator().manual_seed(11)
+    # piecewise-constant label map with a few isolated pixels and one out-of-range id
+    coarse = torch.randint(0, NC, (B, 1, (H + 3) // 4, (W + 3) // 4), generator=g)
+    label = coarse.repeat_interleave(4, 2).repeat_interleave(4, 3)[:, :, :H, :W].clone()
+    label[:, :, 1::5, 2::7] = torch.randint(0, NC, label[:, :, 1::5, 2::7].shape, generator=g)
+    label[0, 0, 0, 0] = NC                      # invalid id: all-zero one-hot column
+    label = label.float()
+    onehot = torch.zeros(B, NC, H, W)
+    valid = (label >= 0) & (label < NC)
+    onehot.scatter_(1, label.clamp(0, NC - 1).long(), valid.float())
+    dense = _rand(B, Cd, H, W, seed=5) if Cd else torch.zeros(B, 0, H, W)
+    x = torch.cat([onehot, dense], 1)
+    w = _rand(Cout, NC + Cd, k, k, seed=2, scale=0.05).requires_grad_(True)
+    b = _rand(Cout, seed=3, scale=0.1).requires_grad_(True)
+    y_ref = _ref_conv(x, w, b, 1, k // 2, pm, 'none')
+    gy = _rand(*y_ref.shape, seed=4)
+    gw_ref, gb_ref = torch.autograd.grad(y_ref, (w, b), gy)
+
+    xd = ops.mark_onehot(x.to(DEV), label.to(DEV), NC)
+    wd, bd = (t.detach().to(DEV).requires_grad_(True) for t in (w, b))
+    y = ops.conv2d(xd, wd, bd, 1, k // 2, pm, 'none')
+    assert y.grad_fn.__class__.__name__.startswith('_OneHotConv2d')
+    assert_close('onehot conv fwd', y, y_ref, rtol=2e-5)
+    gw, gb = torch.autograd.grad(y, (wd, bd), gy.to(DEV))
+    assert_close('onehot conv wgrad', gw, gw_ref, rtol=2e-5)
+    assert_close('onehot conv bgrad', gb, gb_ref, rtol=2e-5)
+    y2 = ops.conv2d(xd, wd, bd, 1, k // 2, pm, 'none')
+    gw2, _ = torch.autograd.grad(y2, (wd, bd), gy.to(DEV))
+    assert torch.equal(y, y2) and torch.equal(gw, gw2), 'one-hot stem must be run-to-run deterministic'
