@@ -1893,6 +1893,124 @@ static void wgrad_tile(int M, int* BM, int* BN) {
   *BM = M <= 32 ? 32 : (M <= 64 ? 64 : 128);
 }
 
+
+// sum over the 64 lanes of a wave with DPP row shifts + row broadcasts (full-rate VALU, no LDS crossbar); the total
+// ends up in lane 63
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));  // row_shr:1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));  // row_shr:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));  // row_shr:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));  // row_shr:8
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, true));  // row_bcast:15
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, true));  // row_bcast:31
+  return v;
+}
+
+// Tiny-M weight gradient for "same" odd kernels (the G tanh head conv7x7 64->3): sliding-window, lane-private.
+// One wave = one input channel; its 64 lanes are 64 consecutive output columns and walk down a strip of rows keeping
+// the KSxKS window of x around their pixel in registers (ONE new row of KS loads per step instead of KS*KS gathers),
+// MM*KS*KS private FMA accumulators, a DPP wave reduction once per workgroup.  part[slot][m][c*KK + t].
+// grid (slots, ceil(C/4)); workgroups are persistent over the (image, column strip, row chunk) tasks.
+template <int MM, int KS, bool REFLECT>
+__global__ __launch_bounds__(256) void wgrad_small_win_kernel(const WGradP p, int nsx, int nyc, int rows_per, int ntasks) {
+  constexpr int KK = KS * KS;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c = blockIdx.y * 4 + wave;
+  if (c >= p.C) return;
+  const int H = p.H, W = p.W, HW = H * W, pad = p.pad;
+  float acc[MM][KK];
+#pragma unroll
+  for (int m = 0; m < MM; ++m)
+#pragma unroll
+    for (int t = 0; t < KK; ++t) acc[m][t] = 0.f;
+  for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
+    int q = task;
+    const int yc = q % nyc;
+    q /= nyc;
+    const int sx = q % nsx, b = q / nsx;
+    const int px = sx * 64 + lane;
+    const bool lane_on = px < W;
+    const int y0 = yc * rows_per, y1 = min(y0 + rows_per, H);
+    const float* __restrict__ xc = p.x + ((size_t)b * p.C + c) * HW;
+    const float* __restrict__ g = p.dy + (size_t)b * p.M * HW + min(px, W - 1);
+    int cx[KS];
+    bool okc[KS];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      int ix = px - pad + k;
+      bool ok = lane_on;
+      if (REFLECT) {
+        ix = ix < 0 ? -ix : ix;
+        ix = ix >= W ? 2 * (W - 1) - ix : ix;
+      } else {
+        ok = ok && ix >= 0 && ix < W;
+      }
+      cx[k] = min(max(ix, 0), W - 1);
+      okc[k] = ok;
+    }
+    float win[KS][KS];
+#define HIM_SW_ROW(PY, DST)                                                            \
+  {                                                                                    \
+    int iy = (PY);                                                                     \
+    bool oky = true;                                                                   \
+    if (REFLECT) {                                                                     \
+      iy = iy < 0 ? -iy : iy;                                                          \
+      iy = iy >= H ? 2 * (H - 1) - iy : iy;                                            \
+    } else {                                                                           \
+      oky = iy >= 0 && iy < H;                                                         \
+    }                                                                                  \
+    const float* __restrict__ rp = xc + min(max(iy, 0), H - 1) * W;                    \
+    _Pragma("unroll") for (int k = 0; k < KS; ++k) {                                   \
+      const float v = rp[cx[k]];                                                       \
+      DST[k] = (oky && okc[k]) ? v : 0.f;                                              \
+    }                                                                                  \
+  }
+#pragma unroll
+    for (int r = 0; r < KS; ++r) HIM_SW_ROW(y0 - pad + r, win[r])
+    for (int pyb = y0; pyb < y1; pyb += KS) {
+#pragma unroll
+      for (int ph = 0; ph < KS; ++ph) {
+        const int py = pyb + ph;
+        if (py < y1) {
+          float nxt[KS], gv[MM];
+          HIM_SW_ROW(py + 1 + pad, nxt)
+#pragma unroll
+          for (int m = 0; m < MM; ++m) {
+            const float v = g[(size_t)m * HW + py * W];
+            gv[m] = lane_on ? v : 0.f;
+          }
+          // x row (py - pad + th) sits in logical slot th = physical (th + ph) % KS
+#pragma unroll
+          for (int th = 0; th < KS; ++th)
+#pragma unroll
+            for (int tw = 0; tw < KS; ++tw)
+#pragma unroll
+              for (int m = 0; m < MM; ++m) acc[m][th * KS + tw] = fmaf(gv[m], win[(th + ph) % KS][tw], acc[m][th * KS + tw]);
+#pragma unroll
+          for (int k = 0; k < KS; ++k) win[ph][k] = nxt[k];
+        }
+      }
+    }
+#undef HIM_SW_ROW
+  }
+  float* __restrict__ out = p.out + (size_t)blockIdx.x * p.M * p.Np + (size_t)c * KK;
+#pragma unroll
+  for (int m = 0; m < MM; ++m)
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+      const float sm = wave_sum_dpp(acc[m][t]);
+      if (lane == 63) out[(size_t)m * p.Np + t] = sm;
+    }
+}
+
+static const int SMALL_WIN_SLOTS = 256;
+static bool small_win_ok(int M, int KH, int KW, int stride, int pad, int H, int W, int OH, int OW) {
+  static int off = -1;
+  if (off < 0) off = getenv("HIM_NO_SMALL_WIN") ? 1 : 0;
+  return !off && M <= 4 && KH == KW && (KH == 3 || KH == 5 || KH == 7) && stride == 1 && pad == KH / 2 && OH == H && OW == W &&
+         H > pad && W > pad;
+}
+
 static int small_wgrad_slices(int C, int Kdim) {
   int s = (2048 + C - 1) / C;
   const int maxs = cdiv(Kdim, 256 * 8);
@@ -1904,8 +2022,8 @@ static size_t wgrad_slab_bytes(int M, int C, int KH, int KW, int Kdim, size_t wi
   const int Np = C * KH * KW;
   size_t slabs;
   if (wino_floats) return ((wino_floats * sizeof(float) + 255) / 256) * 256;
-  if (small_wgrad_ok(M, KH, KW)) {
-    slabs = (size_t)small_wgrad_slices(C, Kdim) * M * Np * sizeof(float);
+  if (small_wgrad_ok(M, KH, KW) || (M <= 4 && KH == KW && KH == 5)) {
+    slabs = (size_t)std::max(small_wgrad_slices(C, Kdim), SMALL_WIN_SLOTS) * M * Np * sizeof(float);
   } else if (wgrad_fast_ok(M, C, 1, 4) && Kdim % 4 == 0) {  /* upper bound; the runner re-checks OH*OW */
     int BM, BN, sp;
     wgrad_fast_cfg(M, C, Kdim, KH * KW, &BM, &BN, &sp);
@@ -1977,6 +2095,30 @@ static int run_wgrad(const float* dy, const float* x, float* dw, int M, int C, i
     hipLaunchKernelGGL(wino_wgrad_out_kernel, dim3(cdiv(C, 256), M), dim3(256), 0, st, (const float*)dU, dw, M, C,
                        accumulate);
     return check_launch("wino_wgrad_out");
+  }
+  if (small_win_ok(M, KH, KW, stride, pad, H, W, OH, OW)) {
+    const int nsx = cdiv(W, 64), rows_per = 64, nyc = cdiv(H, rows_per), ntasks = B * nsx * nyc;
+    const int slots = std::min(ntasks, SMALL_WIN_SLOTS);
+    const size_t need = (size_t)slots * M * p.Np * sizeof(float);
+    if (ws_bytes < need || !ws) return fail(HIM_E_WORKSPACE, "wgrad needs %zu ws bytes, got %zu", need, ws_bytes);
+    p.out = (float*)ws;
+    const dim3 grid(slots, cdiv(C, 4)), block(256);
+    const bool refl = pad_mode == HIM_PAD_REFLECT;
+#define HIM_SWK(MMv, KSv)                                                                                         \
+  if (M == MMv && KH == KSv) {                                                                                    \
+    if (refl) hipLaunchKernelGGL((wgrad_small_win_kernel<MMv, KSv, true>), grid, block, 0, st, p, nsx, nyc, rows_per, ntasks); \
+    else hipLaunchKernelGGL((wgrad_small_win_kernel<MMv, KSv, false>), grid, block, 0, st, p, nsx, nyc, rows_per, ntasks);     \
+  }
+    HIM_SWK(1, 3) HIM_SWK(2, 3) HIM_SWK(3, 3) HIM_SWK(4, 3)
+    HIM_SWK(1, 5) HIM_SWK(2, 5) HIM_SWK(3, 5) HIM_SWK(4, 5)
+    HIM_SWK(1, 7) HIM_SWK(2, 7) HIM_SWK(3, 7) HIM_SWK(4, 7)
+#undef HIM_SWK
+    int rc0 = check_launch("wgrad_small_win");
+    if (rc0) return rc0;
+    const long long n = (long long)M * p.Np;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(std::min<long long>(cdiv(n, 256), 4096)), dim3(256), 0, st,
+                       (const float*)ws, dw, n, slots, accumulate);
+    return check_launch("slab_reduce");
   }
   if (small_wgrad_ok(M, KH, KW)) {
     const int slices = small_wgrad_slices(C, p.Kdim);

@@ -54,6 +54,8 @@ CONV_CASES = [
     (2, 20, 4, 5, 24, 3, 1, 1, 'reflect', 'none'),       # folded reflect dgrad, channel tails (Cout 24)
     (1, 32, 2, 4, 16, 3, 1, 1, 'reflect', 'none'),       # H = 2: padded-gradient + fold fallback
     (2, 256, 16, 32, 256, 3, 1, 1, 'reflect', 'none'),   # folded reflect dgrad under split-K
+    (2, 20, 9, 70, 2, 3, 1, 1, 'zero', 'none'),          # tiny-M sliding-window wgrad, zero pad, W > one wave
+    (1, 12, 70, 9, 4, 5, 1, 2, 'reflect', 'none'),       # tiny-M sliding-window wgrad 5x5, H > one row chunk
 ]
 
 
