@@ -95,9 +95,9 @@ def dominant_kernel_roofline(device):
 
 def g_forward_roofline(model, batch):
     """The 'fused G-conv forward' the north star prices: whole GlobalGenerator forward at C2.  SURVEY 8(d) counts it in
-    direct-form FLOP (1.970 TFLOP per bs-8 batch); the 18 ResnetBlock convs run as Winograd and execute 34.36 instead of
-    77.31 GFLOP each, i.e. 1.197 TFLOP are actually issued to the matrix pipe.  Both rates are reported; the roofline
-    fraction is the EXECUTED one."""
+    direct-form FLOP (1.970 TFLOP per bs-8 batch); the 18 ResnetBlock convs run as Winograd (34.36 instead of 77.31 GFLOP
+    each) and the stem's 35 one-hot input channels are table lookups, i.e. 0.967 TFLOP are actually issued to the matrix
+    pipe.  Both rates are reported; the roofline fraction is the EXECUTED one."""
     with torch.no_grad():
         model.encode_input(batch['label'], batch['inst'], batch['image'], None, mask_in=batch['mask_in'])
         buf, _, _, mask = model._enc
@@ -109,7 +109,11 @@ def g_forward_roofline(model, batch):
     from neurips18_hierchical_image_manipulation_amd import ops
     wino = ops.set_winograd_min_channels(0)
     ops.set_winograd_min_channels(wino)
-    executed = direct - (18 * (77.309 - 34.360) / 1e3 if 0 < wino <= 1024 else 0.0)
+    executed = direct
+    if 0 < wino <= 1024:            # 18 ResnetBlock convs: 34.36 instead of 77.31 GFLOP each
+        executed -= 18 * (77.309 - 34.360) / 1e3
+    if ops._ONEHOT_ON:              # stem conv7x7 38->64: the 35 one-hot channels are LDS lookups, 3 dense ones stay
+        executed -= 2.0 * 64 * 35 * 49 * (BS * H * W) / 1e12
     return dict(ms=round(ms, 3), tflops_direct_form_equivalent=round(direct / (ms * 1e-3), 2),
                 tflops_executed=round(executed / (ms * 1e-3), 2),
                 frac_of_f32_mfma_peak=round(executed / (ms * 1e-3) / PEAK_F32_MFMA, 4),
