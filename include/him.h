@@ -36,6 +36,7 @@ extern "C" {
 #define HIM_ACT_RELU 1  /* nn.ReLU        (models/Pix2Pix_NET.py:70) */
 #define HIM_ACT_LRELU 2 /* nn.LeakyReLU(0.2) (models/Discriminator_NET.py:73) */
 #define HIM_ACT_TANH 3  /* nn.Tanh        (models/Pix2Pix_NET.py:91) */
+#define HIM_ACT_SIGMOID 4 /* nn.Sigmoid    (models/MaskTwoStreamConvSwitch_NET.py:22,206: object-mask head) */
 
 #define HIM_PAD_ZERO 0    /* Conv2d(padding=p) */
 #define HIM_PAD_REFLECT 1 /* nn.ReflectionPad2d(p) followed by Conv2d(padding=0) */
@@ -93,6 +94,41 @@ int him_deconv2d_bwd_data(const HimDeconv2d* d, const float* dy, const float* w,
 size_t him_deconv2d_bwd_weight_ws(const HimDeconv2d* d);
 int him_deconv2d_bwd_weight(const HimDeconv2d* d, const float* x, const float* dy, float* dw, float* dbias,
                             int accumulate, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * box2mask building blocks (second hot path, SURVEY 8 row a18: models/MaskTwoStreamConvSwitch_NET.py,
+ * models/layer_util.py:128-250 ConvResnetBlock / DeconvResnetBlock, models/mask_losses.py).
+ *   batchnorm: nn.BatchNorm2d(affine=True) of get_norm_layer('batch') (layer_util.py:19-21), training mode = batch
+ *     statistics + running-statistics update (momentum, unbiased variance), eval mode = running statistics; fused with
+ *     the activation behind it and an optional residual add.  gamma/beta may be NULL (affine=False).
+ *     bwd: dgamma/dbeta (+)= when accumulate != 0; dx may be NULL.
+ *   act_fwd: stand-alone nn.ReLU / LeakyReLU / Tanh / Sigmoid (the blocks start with an activation).
+ *   upsample2: nn.Upsample(scale_factor=2, mode='bilinear') (layer_util.py:189,206); align_corners selects the
+ *     torch >= 0.4 default (0) or the torch 0.3.1 behaviour (1).
+ *   logsoftmax: nn.LogSoftmax(dim=1) over the channel axis (MaskTwoStreamConvSwitch_NET.py:21,196).
+ *   masked_nll: MaskReconLoss = NLLLoss2d(ignore_index) with the positions where mask < 0.5 ignored
+ *     (mask_losses.py:12-27); out2 = {loss, #valid positions}.   bce_mean: nn.BCELoss() (TwoStreamAE_mask.py:53).
+ * -------------------------------------------------------------------------------------------*/
+size_t him_batchnorm_ws(int C);
+int him_batchnorm_fwd(const float* x, const float* residual, const float* gamma, const float* beta, float* run_mean,
+                      float* run_var, float* y, float* save_mean, float* save_rstd, int B, int C, int hw, float eps,
+                      float momentum, int training, int act, float slope, void* ws, size_t ws_bytes, void* stream);
+int him_batchnorm_bwd(const float* x, const float* gamma, const float* beta, const float* save_mean,
+                      const float* save_rstd, const float* dy, float* dx, float* dgamma, float* dbeta, int B, int C,
+                      int hw, int training, int act, float slope, int accumulate, void* ws, size_t ws_bytes,
+                      void* stream);
+int him_act_fwd(const float* x, float* y, size_t n, int act, float slope, void* stream);
+int him_upsample2_fwd(const float* x, float* y, int planes, int H, int W, int align_corners, void* stream);
+int him_upsample2_bwd(const float* dy, float* dx, int planes, int H, int W, int align_corners, void* stream);
+int him_logsoftmax_fwd(const float* x, float* y, int B, int C, int hw, void* stream);
+int him_logsoftmax_bwd(const float* y, const float* dy, float* dx, int B, int C, int hw, void* stream);
+size_t him_mask_loss_ws(void);
+int him_masked_nll_fwd(const float* logp, const float* label, const float* mask, float* out2, int B, int C, int hw,
+                       void* ws, size_t ws_bytes, void* stream);
+int him_masked_nll_bwd(const float* label, const float* mask, const float* g, const float* count, float* dlogp, int B,
+                       int C, int hw, void* stream);
+int him_bce_mean_fwd(const float* p, const float* t, size_t n, float* out, void* ws, size_t ws_bytes, void* stream);
+int him_bce_mean_bwd(const float* p, const float* t, size_t n, const float* g, float* dp, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * One-hot stems: conv over [one-hot(label) | dense channels] evaluated from the label ids.  `label` is the

@@ -23,7 +23,7 @@ class HimDeconv2d(C.Structure):
                                      'OH', 'OW', 'act')] + [('slope', c_float)]
 
 
-ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 PAD_ZERO, PAD_REFLECT = 0, 1
 
 P = c_void_p
@@ -60,6 +60,21 @@ _SIGS = {
     'him_deconv2d_panel_build': (c_int, [_DECONV, c_int, P, P, c_size_t, P]),
     'him_deconv2d_fwd_panel': (c_int, [_DECONV, P, P, P, P, P, c_size_t, P]),
     'him_deconv2d_bwd_data_panel': (c_int, [_DECONV, P, P, P, P, c_size_t, P]),
+    'him_batchnorm_ws': (c_size_t, [c_int]),
+    'him_batchnorm_fwd': (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, c_int, c_int, c_float,
+                                  P, c_size_t, P]),
+    'him_batchnorm_bwd': (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P,
+                                  c_size_t, P]),
+    'him_act_fwd': (c_int, [P, P, c_size_t, c_int, c_float, P]),
+    'him_upsample2_fwd': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    'him_upsample2_bwd': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    'him_logsoftmax_fwd': (c_int, [P, P, c_int, c_int, c_int, P]),
+    'him_logsoftmax_bwd': (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    'him_mask_loss_ws': (c_size_t, []),
+    'him_masked_nll_fwd': (c_int, [P, P, P, P, c_int, c_int, c_int, P, c_size_t, P]),
+    'him_masked_nll_bwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
+    'him_bce_mean_fwd': (c_int, [P, P, c_size_t, P, P, c_size_t, P]),
+    'him_bce_mean_bwd': (c_int, [P, P, c_size_t, P, P, P]),
     'him_instnorm_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_float, c_int, c_float, P]),
     'him_instnorm_bwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_float, P]),
     'him_act_bwd': (c_int, [P, P, P, c_size_t, c_int, c_float, P]),

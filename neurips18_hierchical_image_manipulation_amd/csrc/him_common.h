@@ -48,6 +48,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     case HIM_ACT_RELU: return v > 0.f ? v : 0.f;
     case HIM_ACT_LRELU: return v > 0.f ? v : v * slope;
     case HIM_ACT_TANH: return tanhf(v);
+    case HIM_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
     default: return v;
   }
 }

@@ -3034,7 +3034,7 @@ int him_conv2d_onehot_fwd(const HimConv2d* d, const float* label, int n_onehot, 
   const dim3 grid(std::min(cdiv(p.npix, 1024), 64), d->Cout / 16);
 #define HIM_OH_FWD(KSv)                                                                                              \
   {                                                                                                                  \
-    hipFuncSetAttribute((const void*)onehot_conv_fwd_kernel<KSv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    (void)hipFuncSetAttribute((const void*)onehot_conv_fwd_kernel<KSv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL((onehot_conv_fwd_kernel<KSv>), grid, dim3(1024), lds, st, p, (const float*)Wt, bias, y,        \
                        Cd > 0 ? 1 : 0, d->act, d->slope);                                                            \
   }
@@ -3073,7 +3073,7 @@ int him_conv2d_onehot_bwd_weight(const HimConv2d* d, const float* label, int n_o
     const size_t lds = (size_t)4 * KK * NC * 4 * sizeof(float);
 #define HIM_OH_WG(KSv)                                                                                              \
   {                                                                                                                 \
-    hipFuncSetAttribute((const void*)onehot_wgrad_kernel<KSv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    (void)hipFuncSetAttribute((const void*)onehot_wgrad_kernel<KSv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL((onehot_wgrad_kernel<KSv>), dim3(nblk, d->Cout / 16), dim3(512), lds, st, p, dy, part, nsx, nyc, \
                        rows_per);                                                                                   \
   }

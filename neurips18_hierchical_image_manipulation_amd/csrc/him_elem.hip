@@ -22,6 +22,7 @@ __global__ void act_bwd_kernel(const float* __restrict__ y, const float* __restr
     if (act == HIM_ACT_RELU) d = yy > 0.f ? g : 0.f;
     else if (act == HIM_ACT_LRELU) d = yy > 0.f ? g : g * slope;
     else if (act == HIM_ACT_TANH) d = g * (1.f - yy * yy);
+    else if (act == HIM_ACT_SIGMOID) d = g * yy * (1.f - yy);
     else d = g;
     dz[i] = d;
   }

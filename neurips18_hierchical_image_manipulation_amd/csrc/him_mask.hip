@@ -1,0 +1,458 @@
+// Building blocks of the box2mask generator (reference models/MaskTwoStreamConvSwitch_NET.py, models/layer_util.py
+// ConvResnetBlock / DeconvResnetBlock, models/mask_losses.py): BatchNorm2d (training and eval mode), stand-alone
+// activations, bilinear x2 upsampling, channel log-softmax, masked NLL and BCE losses.  All HBM-bound: coalesced NCHW
+// streams, per-channel statistics by two-stage fixed-order reductions (no atomics, run-to-run deterministic).
+#include <algorithm>
+
+#include "him_common.h"
+
+namespace him {
+
+static inline dim3 gs_grid(long long n, int per_block = 256) {
+  long long b = (n + per_block - 1) / per_block;
+  if (b > 256 * 8 * 4) b = 256 * 8 * 4;
+  if (b < 1) b = 1;
+  return dim3((unsigned)b);
+}
+#define GS_LOOP(i, n) \
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)(n); i += (long long)gridDim.x * blockDim.x)
+
+static const int BN_SLICES = 32;  // partial sums per channel (over contiguous runs of the B*HW positions)
+
+__device__ __forceinline__ float act_grad_from_z(float z, int act, float slope) {
+  if (act == HIM_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  if (act == HIM_ACT_LRELU) return z > 0.f ? 1.f : slope;
+  if (act == HIM_ACT_TANH) {
+    const float t = tanhf(z);
+    return 1.f - t * t;
+  }
+  if (act == HIM_ACT_SIGMOID) {
+    const float s = 1.f / (1.f + expf(-z));
+    return s * (1.f - s);
+  }
+  return 1.f;
+}
+
+// ---- BatchNorm2d ------------------------------------------------------------------------------------------------
+// partial[(c*S + s)*2 + {0,1}] = sum, sum of squares of (x - shift_c) over slice s of channel c; shift_c = x[0][c][0]
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, float* __restrict__ partial, int B, int C,
+                                                       int hw) {
+  __shared__ float sh[8];
+  const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
+  const long long n = (long long)B * hw;
+  const long long lo = n * s / S, hi = n * (s + 1) / S;
+  const float shift = x[(size_t)c * hw];
+  float a = 0.f, q = 0.f;
+  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+    const int b = (int)(i / hw), r = (int)(i - (long long)b * hw);
+    const float d = x[((size_t)b * C + c) * hw + r] - shift;
+    a += d;
+    q += d * d;
+  }
+  a = block_sum_256(a, sh);
+  q = block_sum_256(q, sh);
+  if (threadIdx.x == 0) {
+    partial[((size_t)c * S + s) * 2] = a;
+    partial[((size_t)c * S + s) * 2 + 1] = q;
+  }
+}
+
+// mean / rstd of the batch (training) or from the running statistics (eval); training also updates the running
+// statistics the way torch does (momentum m, unbiased variance)
+__global__ void bn_finalize_kernel(const float* __restrict__ x, const float* __restrict__ partial, float* __restrict__ mean,
+                                   float* __restrict__ rstd, float* __restrict__ run_mean, float* __restrict__ run_var,
+                                   int B, int C, int hw, int S, float eps, float momentum, int training) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  if (!training) {
+    mean[c] = run_mean[c];
+    rstd[c] = 1.f / sqrtf(run_var[c] + eps);
+    return;
+  }
+  float a = 0.f, q = 0.f;
+  for (int s = 0; s < S; ++s) {
+    a += partial[((size_t)c * S + s) * 2];
+    q += partial[((size_t)c * S + s) * 2 + 1];
+  }
+  const float n = (float)B * (float)hw;
+  const float ms = a / n;
+  const float mu = x[(size_t)c * hw] + ms;
+  const float var = fmaxf(q / n - ms * ms, 0.f);
+  mean[c] = mu;
+  rstd[c] = 1.f / sqrtf(var + eps);
+  if (run_mean) {
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mu;
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * (n / fmaxf(n - 1.f, 1.f));
+  }
+}
+
+// y = act((x - mean)*rstd*gamma + beta) (+ residual)
+__global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ residual, float* __restrict__ y,
+                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                const float* __restrict__ gamma, const float* __restrict__ beta, long long n, int C, int hw,
+                                int act, float slope) {
+  GS_LOOP(i, n) {
+    const int c = (int)((i / hw) % C);
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    float v = apply_act((x[i] - mean[c]) * rstd[c] * g + b, act, slope);
+    if (residual) v += residual[i];
+    y[i] = v;
+  }
+}
+
+// partial sums of dz and dz*xhat per channel slice, dz = dy * act'(z)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ partial, int B, int C, int hw, int act,
+                                                            float slope) {
+  __shared__ float sh[8];
+  const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
+  const long long n = (long long)B * hw;
+  const long long lo = n * s / S, hi = n * (s + 1) / S;
+  const float mu = mean[c], rs = rstd[c], g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+  float a = 0.f, q = 0.f;
+  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+    const int b = (int)(i / hw), r = (int)(i - (long long)b * hw);
+    const size_t idx = ((size_t)b * C + c) * hw + r;
+    const float xh = (x[idx] - mu) * rs;
+    const float dz = dy[idx] * act_grad_from_z(xh * g + bt, act, slope);
+    a += dz;
+    q += dz * xh;
+  }
+  a = block_sum_256(a, sh);
+  q = block_sum_256(q, sh);
+  if (threadIdx.x == 0) {
+    partial[((size_t)c * S + s) * 2] = a;
+    partial[((size_t)c * S + s) * 2 + 1] = q;
+  }
+}
+
+// sums[c*2+{0,1}] = total dz, total dz*xhat; dgamma/dbeta (+)=
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, float* __restrict__ sums, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, int C, int S, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, q = 0.f;
+  for (int s = 0; s < S; ++s) {
+    a += partial[((size_t)c * S + s) * 2];
+    q += partial[((size_t)c * S + s) * 2 + 1];
+  }
+  sums[c * 2] = a;
+  sums[c * 2 + 1] = q;
+  if (dgamma) dgamma[c] = accumulate ? dgamma[c] + q : q;
+  if (dbeta) dbeta[c] = accumulate ? dbeta[c] + a : a;
+}
+
+// training: dx = gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat)); eval: dx = gamma*rstd*dz
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ sums, long long n, int C, int hw, float inv_n, int act,
+                                    float slope, int training) {
+  GS_LOOP(i, n) {
+    const int c = (int)((i / hw) % C);
+    const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f, rs = rstd[c];
+    const float xh = (x[i] - mean[c]) * rs;
+    const float dz = dy[i] * act_grad_from_z(xh * g + bt, act, slope);
+    dx[i] = training ? g * rs * (dz - sums[c * 2] * inv_n - xh * sums[c * 2 + 1] * inv_n) : g * rs * dz;
+  }
+}
+
+// ---- stand-alone activation ------------------------------------------------------------------------------------
+__global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, int act, float slope) {
+  GS_LOOP(i, n) y[i] = apply_act(x[i], act, slope);
+}
+
+// ---- bilinear x2 upsampling (nn.Upsample(scale_factor=2, mode='bilinear')) -------------------------------------
+__device__ __forceinline__ void bilinear_src(int o, int in_size, int out_size, int align, int* i0, int* i1, float* w1) {
+  float src;
+  if (align) {
+    src = out_size > 1 ? (float)o * (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
+  } else {
+    src = ((float)o + 0.5f) * ((float)in_size / (float)out_size) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+  }
+  const int a = min((int)src, in_size - 1);
+  *i0 = a;
+  *i1 = min(a + 1, in_size - 1);
+  *w1 = src - (float)a;
+}
+
+__global__ void upsample2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int planes, int H, int W, int align) {
+  const int OH = 2 * H, OW = 2 * W;
+  const long long n = (long long)planes * OH * OW;
+  GS_LOOP(i, n) {
+    const int ox = (int)(i % OW), oy = (int)((i / OW) % OH);
+    const long long pl = i / ((long long)OW * OH);
+    int y0, y1, x0, x1;
+    float wy, wx;
+    bilinear_src(oy, H, OH, align, &y0, &y1, &wy);
+    bilinear_src(ox, W, OW, align, &x0, &x1, &wx);
+    const float* __restrict__ p = x + pl * H * W;
+    const float top = p[y0 * W + x0] * (1.f - wx) + p[y0 * W + x1] * wx;
+    const float bot = p[y1 * W + x0] * (1.f - wx) + p[y1 * W + x1] * wx;
+    y[i] = top * (1.f - wy) + bot * wy;
+  }
+}
+
+// gather form of the adjoint: every input pixel sums the weights with which the (at most 6 x 6) nearby output pixels
+// read it -- no atomics, fixed order
+__global__ void upsample2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int planes, int H, int W,
+                                     int align) {
+  const int OH = 2 * H, OW = 2 * W;
+  const long long n = (long long)planes * H * W;
+  GS_LOOP(i, n) {
+    const int ix = (int)(i % W), iy = (int)((i / W) % H);
+    const long long pl = i / ((long long)W * H);
+    const float* __restrict__ g = dy + pl * OH * OW;
+    float wys[6], wxs[6];
+    int oys[6], oxs[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int oy = 2 * iy - 2 + k, ox = 2 * ix - 2 + k;
+      int a0, a1;
+      float w1;
+      float wy = 0.f, wx = 0.f;
+      if (oy >= 0 && oy < OH) {
+        bilinear_src(oy, H, OH, align, &a0, &a1, &w1);
+        wy = (a0 == iy ? 1.f - w1 : 0.f) + (a1 == iy ? w1 : 0.f);
+      }
+      if (ox >= 0 && ox < OW) {
+        bilinear_src(ox, W, OW, align, &a0, &a1, &w1);
+        wx = (a0 == ix ? 1.f - w1 : 0.f) + (a1 == ix ? w1 : 0.f);
+      }
+      wys[k] = wy;
+      wxs[k] = wx;
+      oys[k] = min(max(oy, 0), OH - 1);
+      oxs[k] = min(max(ox, 0), OW - 1);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      if (wys[a] == 0.f) continue;
+      float r = 0.f;
+#pragma unroll
+      for (int b = 0; b < 6; ++b) r += wxs[b] * g[oys[a] * OW + oxs[b]];
+      s += wys[a] * r;
+    }
+    dx[i] = s;
+  }
+}
+
+// ---- log-softmax over the channel axis (nn.LogSoftmax(dim=1)) ----------------------------------------------------
+__global__ void logsoftmax_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C, int hw) {
+  const long long n = (long long)B * hw;
+  GS_LOOP(i, n) {
+    const int b = (int)(i / hw), r = (int)(i - (long long)b * hw);
+    const float* __restrict__ p = x + (size_t)b * C * hw + r;
+    float m = p[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, p[(size_t)c * hw]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(p[(size_t)c * hw] - m);
+    const float lse = m + logf(s);
+    float* __restrict__ o = y + (size_t)b * C * hw + r;
+    for (int c = 0; c < C; ++c) o[(size_t)c * hw] = p[(size_t)c * hw] - lse;
+  }
+}
+// dx = dy - exp(y) * sum_c dy
+__global__ void logsoftmax_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dx, int B,
+                                      int C, int hw) {
+  const long long n = (long long)B * hw;
+  GS_LOOP(i, n) {
+    const int b = (int)(i / hw), r = (int)(i - (long long)b * hw);
+    const size_t base = (size_t)b * C * hw + r;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += dy[base + (size_t)c * hw];
+    for (int c = 0; c < C; ++c) dx[base + (size_t)c * hw] = dy[base + (size_t)c * hw] - expf(y[base + (size_t)c * hw]) * s;
+  }
+}
+
+// ---- losses ------------------------------------------------------------------------------------------------------
+// MaskReconLoss (models/mask_losses.py:12-27): NLLLoss2d(ignore_index) with the positions where mask < 0.5 ignored:
+// loss = -sum_{valid} logp[label] / #valid.  Stage 1: per-block (sum, count); stage 2 below.
+__global__ __launch_bounds__(256) void masked_nll_stage1(const float* __restrict__ logp, const float* __restrict__ label,
+                                                         const float* __restrict__ mask, float* __restrict__ partial, int B,
+                                                         int C, int hw) {
+  __shared__ float sh[8];
+  const long long n = (long long)B * hw;
+  float a = 0.f, cnt = 0.f;
+  GS_LOOP(i, n) {
+    const int b = (int)(i / hw), r = (int)(i - (long long)b * hw);
+    const int id = (int)label[i];
+    if (mask[i] >= 0.5f && id >= 0 && id < C) {
+      a -= logp[((size_t)b * C + id) * hw + r];
+      cnt += 1.f;
+    }
+  }
+  a = block_sum_256(a, sh);
+  cnt = block_sum_256(cnt, sh);
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x * 2] = a;
+    partial[blockIdx.x * 2 + 1] = cnt;
+  }
+}
+__global__ __launch_bounds__(256) void masked_nll_stage2(const float* __restrict__ partial, int nb, float* __restrict__ out) {
+  __shared__ float sh[8];
+  float a = 0.f, cnt = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) {
+    a += partial[i * 2];
+    cnt += partial[i * 2 + 1];
+  }
+  a = block_sum_256(a, sh);
+  cnt = block_sum_256(cnt, sh);
+  if (threadIdx.x == 0) {
+    out[0] = a / cnt;   // 0/0 = nan when nothing is valid, as torch
+    out[1] = cnt;
+  }
+}
+// dlogp[b][c][r] = -(g / count) at c = label for valid positions, 0 elsewhere
+__global__ void masked_nll_bwd_kernel(const float* __restrict__ label, const float* __restrict__ mask,
+                                      const float* __restrict__ g, const float* __restrict__ cnt, float* __restrict__ dlogp,
+                                      int B, int C, int hw) {
+  const long long n = (long long)B * C * hw;
+  const float scale = -g[0] / cnt[0];
+  GS_LOOP(i, n) {
+    const int r = (int)(i % hw), c = (int)((i / hw) % C), b = (int)(i / ((long long)hw * C));
+    const size_t pi = (size_t)b * hw + r;
+    const int id = (int)label[pi];
+    dlogp[i] = (mask[pi] >= 0.5f && id == c) ? scale : 0.f;
+  }
+}
+
+// nn.BCELoss (mean): -(t*max(log p, -100) + (1-t)*max(log(1-p), -100))
+__global__ __launch_bounds__(256) void bce_stage1(const float* __restrict__ p, const float* __restrict__ t,
+                                                  float* __restrict__ partial, size_t n) {
+  __shared__ float sh[8];
+  float a = 0.f;
+  GS_LOOP(i, n) {
+    const float pp = p[i], tt = t[i];
+    a -= tt * fmaxf(logf(pp), -100.f) + (1.f - tt) * fmaxf(logf(1.f - pp), -100.f);
+  }
+  a = block_sum_256(a, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = a;
+}
+__global__ __launch_bounds__(256) void sum_stage2(const float* __restrict__ partial, int nb, float scale, float* __restrict__ out) {
+  __shared__ float sh[8];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) a += partial[i];
+  a = block_sum_256(a, sh);
+  if (threadIdx.x == 0) out[0] = a * scale;
+}
+// dp = g/n * (p - t) / max(p*(1-p), 1e-12)   (torch's binary_cross_entropy_backward)
+__global__ void bce_bwd_kernel(const float* __restrict__ p, const float* __restrict__ t, const float* __restrict__ g,
+                               float* __restrict__ dp, size_t n, float inv_n) {
+  const float s = g[0] * inv_n;
+  GS_LOOP(i, n) {
+    const float pp = p[i];
+    dp[i] = s * (pp - t[i]) / fmaxf(pp * (1.f - pp), 1e-12f);
+  }
+}
+
+}  // namespace him
+
+using namespace him;
+#define ST ((hipStream_t)stream)
+
+extern "C" {
+
+size_t him_batchnorm_ws(int C) { return ((size_t)C * BN_SLICES * 2 + (size_t)C * 2) * sizeof(float) + 256; }
+
+int him_batchnorm_fwd(const float* x, const float* residual, const float* gamma, const float* beta, float* run_mean,
+                      float* run_var, float* y, float* save_mean, float* save_rstd, int B, int C, int hw, float eps,
+                      float momentum, int training, int act, float slope, void* ws, size_t ws_bytes, void* stream) {
+  if (B <= 0 || C <= 0 || hw <= 0) return fail(HIM_E_INVALID, "batchnorm: B=%d C=%d hw=%d", B, C, hw);
+  if (!training && (!run_mean || !run_var)) return fail(HIM_E_INVALID, "batchnorm: eval mode needs running statistics");
+  if (!ws || ws_bytes < him_batchnorm_ws(C)) return fail(HIM_E_WORKSPACE, "batchnorm: ws too small");
+  float* partial = (float*)ws;
+  if (training) hipLaunchKernelGGL(bn_stats_kernel, dim3(C, BN_SLICES), dim3(256), 0, ST, x, partial, B, C, hw);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, ST, x, (const float*)partial, save_mean, save_rstd,
+                     run_mean, run_var, B, C, hw, BN_SLICES, eps, momentum, training);
+  const long long n = (long long)B * C * hw;
+  hipLaunchKernelGGL(bn_apply_kernel, gs_grid(n), dim3(256), 0, ST, x, residual, y, (const float*)save_mean,
+                     (const float*)save_rstd, gamma, beta, n, C, hw, act, slope);
+  return check_launch("batchnorm_fwd");
+}
+
+int him_batchnorm_bwd(const float* x, const float* gamma, const float* beta, const float* save_mean, const float* save_rstd,
+                      const float* dy, float* dx, float* dgamma, float* dbeta, int B, int C, int hw, int training, int act,
+                      float slope, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+  if (B <= 0 || C <= 0 || hw <= 0) return fail(HIM_E_INVALID, "batchnorm: B=%d C=%d hw=%d", B, C, hw);
+  if (!ws || ws_bytes < him_batchnorm_ws(C)) return fail(HIM_E_WORKSPACE, "batchnorm: ws too small");
+  float* partial = (float*)ws;
+  float* sums = partial + (size_t)C * BN_SLICES * 2;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, BN_SLICES), dim3(256), 0, ST, x, dy, save_mean, save_rstd, gamma, beta,
+                     partial, B, C, hw, act, slope);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, ST, (const float*)partial, sums, dgamma, dbeta, C,
+                     BN_SLICES, accumulate);
+  if (dx) {
+    const long long n = (long long)B * C * hw;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, gs_grid(n), dim3(256), 0, ST, x, dy, dx, save_mean, save_rstd, gamma, beta,
+                       (const float*)sums, n, C, hw, 1.f / ((float)B * (float)hw), act, slope, training);
+  }
+  return check_launch("batchnorm_bwd");
+}
+
+int him_act_fwd(const float* x, float* y, size_t n, int act, float slope, void* stream) {
+  if (!n) return HIM_OK;
+  hipLaunchKernelGGL(act_fwd_kernel, gs_grid(n), dim3(256), 0, ST, x, y, n, act, slope);
+  return check_launch("act_fwd");
+}
+
+int him_upsample2_fwd(const float* x, float* y, int planes, int H, int W, int align_corners, void* stream) {
+  if (planes <= 0 || H <= 0 || W <= 0) return fail(HIM_E_INVALID, "upsample: planes=%d H=%d W=%d", planes, H, W);
+  hipLaunchKernelGGL(upsample2_fwd_kernel, gs_grid((long long)planes * 4 * H * W), dim3(256), 0, ST, x, y, planes, H, W,
+                     align_corners);
+  return check_launch("upsample2_fwd");
+}
+int him_upsample2_bwd(const float* dy, float* dx, int planes, int H, int W, int align_corners, void* stream) {
+  if (planes <= 0 || H <= 0 || W <= 0) return fail(HIM_E_INVALID, "upsample: planes=%d H=%d W=%d", planes, H, W);
+  hipLaunchKernelGGL(upsample2_bwd_kernel, gs_grid((long long)planes * H * W), dim3(256), 0, ST, dy, dx, planes, H, W,
+                     align_corners);
+  return check_launch("upsample2_bwd");
+}
+
+int him_logsoftmax_fwd(const float* x, float* y, int B, int C, int hw, void* stream) {
+  if (B <= 0 || C <= 0 || hw <= 0) return fail(HIM_E_INVALID, "logsoftmax: B=%d C=%d hw=%d", B, C, hw);
+  hipLaunchKernelGGL(logsoftmax_fwd_kernel, gs_grid((long long)B * hw), dim3(256), 0, ST, x, y, B, C, hw);
+  return check_launch("logsoftmax_fwd");
+}
+int him_logsoftmax_bwd(const float* y, const float* dy, float* dx, int B, int C, int hw, void* stream) {
+  if (B <= 0 || C <= 0 || hw <= 0) return fail(HIM_E_INVALID, "logsoftmax: B=%d C=%d hw=%d", B, C, hw);
+  hipLaunchKernelGGL(logsoftmax_bwd_kernel, gs_grid((long long)B * hw), dim3(256), 0, ST, y, dy, dx, B, C, hw);
+  return check_launch("logsoftmax_bwd");
+}
+
+static const int LOSS_BLOCKS = 1024;
+size_t him_mask_loss_ws(void) { return (size_t)LOSS_BLOCKS * 2 * sizeof(float) + 256; }
+
+int him_masked_nll_fwd(const float* logp, const float* label, const float* mask, float* out2, int B, int C, int hw, void* ws,
+                       size_t ws_bytes, void* stream) {
+  if (!ws || ws_bytes < him_mask_loss_ws()) return fail(HIM_E_WORKSPACE, "masked_nll: ws too small");
+  const int nb = (int)std::min<long long>(cdiv((long long)B * hw, 256), LOSS_BLOCKS);
+  hipLaunchKernelGGL(masked_nll_stage1, dim3(nb), dim3(256), 0, ST, logp, label, mask, (float*)ws, B, C, hw);
+  hipLaunchKernelGGL(masked_nll_stage2, dim3(1), dim3(256), 0, ST, (const float*)ws, nb, out2);
+  return check_launch("masked_nll_fwd");
+}
+int him_masked_nll_bwd(const float* label, const float* mask, const float* g, const float* count, float* dlogp, int B, int C,
+                       int hw, void* stream) {
+  hipLaunchKernelGGL(masked_nll_bwd_kernel, gs_grid((long long)B * C * hw), dim3(256), 0, ST, label, mask, g, count, dlogp, B,
+                     C, hw);
+  return check_launch("masked_nll_bwd");
+}
+
+int him_bce_mean_fwd(const float* p, const float* t, size_t n, float* out, void* ws, size_t ws_bytes, void* stream) {
+  if (!n) return fail(HIM_E_INVALID, "bce: empty input");
+  if (!ws || ws_bytes < him_mask_loss_ws()) return fail(HIM_E_WORKSPACE, "bce: ws too small");
+  const int nb = (int)std::min<long long>(cdiv((long long)n, 256), LOSS_BLOCKS);
+  hipLaunchKernelGGL(bce_stage1, dim3(nb), dim3(256), 0, ST, p, t, (float*)ws, n);
+  hipLaunchKernelGGL(sum_stage2, dim3(1), dim3(256), 0, ST, (const float*)ws, nb, (float)(1.0 / (double)n), out);
+  return check_launch("bce_mean_fwd");
+}
+int him_bce_mean_bwd(const float* p, const float* t, size_t n, const float* g, float* dp, void* stream) {
+  if (!n) return HIM_OK;
+  hipLaunchKernelGGL(bce_bwd_kernel, gs_grid(n), dim3(256), 0, ST, p, t, g, dp, n, (float)(1.0 / (double)n));
+  return check_launch("bce_mean_bwd");
+}
+
+}  // extern "C"

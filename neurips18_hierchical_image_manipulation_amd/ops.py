@@ -14,10 +14,10 @@ import os
 
 import torch
 
-from ._cabi import (lib, HimConv2d, HimDeconv2d, ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, PAD_ZERO,
+from ._cabi import (lib, HimConv2d, HimDeconv2d, ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID, PAD_ZERO,
                     PAD_REFLECT, HimError)
 
-ACTS = {'none': ACT_NONE, 'relu': ACT_RELU, 'lrelu': ACT_LRELU, 'tanh': ACT_TANH}
+ACTS = {'none': ACT_NONE, 'relu': ACT_RELU, 'lrelu': ACT_LRELU, 'tanh': ACT_TANH, 'sigmoid': ACT_SIGMOID}
 
 
 def _stream():
@@ -492,6 +492,212 @@ class _InstNorm(torch.autograd.Function):
 def instance_norm(x, residual=None, act='none', slope=0.2, eps=1e-5):
     """act(InstanceNorm2d(affine=False)(x)) [+ residual]."""
     return _InstNorm.apply(x, residual, ACTS[act], float(slope), float(eps))
+
+
+# ------------------------------------------------------------------------------------------------
+# box2mask building blocks: BatchNorm2d, stand-alone activation, bilinear x2, channel log-softmax, mask losses
+# ------------------------------------------------------------------------------------------------
+class _BatchNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, run_mean, run_var, training, momentum, eps, act, slope):
+        ctx.set_materialize_grads(False)
+        x = x.contiguous()
+        if residual is not None:
+            residual = residual.contiguous()
+        _chk(x, residual, gamma, beta, run_mean, run_var)
+        B, Cn, H, W = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(Cn, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        nb = lib.him_batchnorm_ws(Cn)
+        ws = _ws(nb, x)
+        lib.him_batchnorm_fwd(_p(x), _p(residual), _p(gamma), _p(beta), _p(run_mean), _p(run_var), _p(y), _p(mean),
+                              _p(rstd), B, Cn, H * W, eps, momentum, 1 if training else 0, act, slope, _p(ws), nb, _stream())
+        ctx.x, ctx.gamma, ctx.beta, ctx.mean, ctx.rstd = x, gamma, beta, mean, rstd
+        ctx.cfg = (B, Cn, H * W, bool(training), act, slope)
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if dy is None:
+            return (None,) * 11
+        dy = dy.contiguous()
+        B, Cn, hw, training, act, slope = ctx.cfg
+        x, gamma, beta = ctx.x, ctx.gamma, ctx.beta
+        need_x = ctx.needs_input_grad[0]
+        need_g = gamma is not None and ctx.needs_input_grad[2]
+        need_b = beta is not None and ctx.needs_input_grad[3]
+        dx = torch.empty_like(x) if need_x else None
+        nb = lib.him_batchnorm_ws(Cn)
+        ws = _ws(nb, x)
+        direct = need_g and need_b and _direct(gamma) and _direct(beta)
+        if direct:
+            dg, db = gamma.grad, beta.grad
+        else:
+            dg = torch.empty_like(gamma) if need_g else None
+            db = torch.empty_like(beta) if need_b else None
+        lib.him_batchnorm_bwd(_p(x), _p(gamma), _p(beta), _p(ctx.mean), _p(ctx.rstd), _p(dy), _p(dx), _p(dg), _p(db), B, Cn,
+                              hw, 1 if training else 0, act, slope, 1 if direct else 0, _p(ws), nb, _stream())
+        if direct:
+            _notify(gamma)
+            _notify(beta)
+            dg = db = None
+        dres = dy if (ctx.has_res and ctx.needs_input_grad[1]) else None
+        return dx, dres, dg, db, None, None, None, None, None, None, None
+
+
+def batch_norm(x, gamma, beta, run_mean, run_var, training=True, momentum=0.1, eps=1e-5, act='none', slope=0.2,
+               residual=None):
+    """act(BatchNorm2d(x)) [+ residual]; training mode updates run_mean / run_var in place (torch semantics)."""
+    return _BatchNorm.apply(x, residual, gamma, beta, run_mean, run_var, bool(training), float(momentum), float(eps),
+                            ACTS[act], float(slope))
+
+
+class _Act(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act, slope):
+        ctx.set_materialize_grads(False)
+        x = x.contiguous()
+        _chk(x)
+        y = torch.empty_like(x)
+        lib.him_act_fwd(_p(x), _p(y), x.numel(), act, slope, _stream())
+        ctx.cfg = (act, slope)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if dy is None:
+            return None, None, None
+        dy = dy.contiguous()
+        (y,) = ctx.saved_tensors
+        dz = torch.empty_like(dy)
+        lib.him_act_bwd(_p(y), _p(dy), _p(dz), dy.numel(), ctx.cfg[0], ctx.cfg[1], _stream())
+        return dz, None, None
+
+
+def activation(x, act, slope=0.2):
+    """stand-alone nn.ReLU / LeakyReLU / Tanh / Sigmoid (out of place)."""
+    return _Act.apply(x, ACTS[act], float(slope))
+
+
+class _Upsample2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, align):
+        ctx.set_materialize_grads(False)
+        x = x.contiguous()
+        _chk(x)
+        B, Cn, H, W = x.shape
+        y = torch.empty((B, Cn, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+        lib.him_upsample2_fwd(_p(x), _p(y), B * Cn, H, W, align, _stream())
+        ctx.cfg = (B * Cn, H, W, align)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if dy is None:
+            return None, None
+        dy = dy.contiguous()
+        planes, H, W, align = ctx.cfg
+        dx = torch.empty((dy.shape[0], dy.shape[1], H, W), dtype=torch.float32, device=dy.device)
+        lib.him_upsample2_bwd(_p(dy), _p(dx), planes, H, W, align, _stream())
+        return dx, None
+
+
+def upsample_bilinear2(x, align_corners=False):
+    """nn.Upsample(scale_factor=2, mode='bilinear')."""
+    return _Upsample2.apply(x, 1 if align_corners else 0)
+
+
+class _LogSoftmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.set_materialize_grads(False)
+        x = x.contiguous()
+        _chk(x)
+        B, Cn, H, W = x.shape
+        y = torch.empty_like(x)
+        lib.him_logsoftmax_fwd(_p(x), _p(y), B, Cn, H * W, _stream())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if dy is None:
+            return None
+        dy = dy.contiguous()
+        (y,) = ctx.saved_tensors
+        B, Cn, H, W = y.shape
+        dx = torch.empty_like(y)
+        lib.him_logsoftmax_bwd(_p(y), _p(dy), _p(dx), B, Cn, H * W, _stream())
+        return dx
+
+
+def log_softmax_channels(x):
+    """nn.LogSoftmax(dim=1) on a (B,C,H,W) tensor."""
+    return _LogSoftmax.apply(x)
+
+
+class _MaskedNLL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logp, label, mask):
+        ctx.set_materialize_grads(False)
+        logp, label, mask = logp.contiguous(), label.contiguous(), mask.contiguous()
+        _chk(logp, label, mask)
+        B, Cn, H, W = logp.shape
+        out2 = torch.empty(2, dtype=torch.float32, device=logp.device)
+        nb = lib.him_mask_loss_ws()
+        ws = _ws(nb, logp)
+        lib.him_masked_nll_fwd(_p(logp), _p(label), _p(mask), _p(out2), B, Cn, H * W, _p(ws), nb, _stream())
+        ctx.label, ctx.mask, ctx.count, ctx.shape = label, mask, out2[1:2], (B, Cn, H, W)
+        return out2[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None
+        B, Cn, H, W = ctx.shape
+        g = g.contiguous()
+        d = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+        lib.him_masked_nll_bwd(_p(ctx.label), _p(ctx.mask), _p(g), _p(ctx.count), _p(d), B, Cn, H * W, _stream())
+        return d, None, None
+
+
+def masked_nll(logp, label, mask):
+    """MaskReconLoss: NLLLoss2d(ignore_index) of log-probabilities (B,C,H,W) against the id map ``label`` (B,1,H,W or
+    B,H,W, ids as floats) with the positions where ``mask`` < 0.5 ignored; mean over the valid positions."""
+    return _MaskedNLL.apply(logp, label.detach(), mask.detach())
+
+
+class _BCEMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, t):
+        ctx.set_materialize_grads(False)
+        p, t = p.contiguous(), t.contiguous()
+        _chk(p, t)
+        if p.shape != t.shape:
+            raise HimError('bce: shape mismatch %s vs %s' % (tuple(p.shape), tuple(t.shape)))
+        out = torch.empty((), dtype=torch.float32, device=p.device)
+        nb = lib.him_mask_loss_ws()
+        ws = _ws(nb, p)
+        lib.him_bce_mean_fwd(_p(p), _p(t), p.numel(), _p(out), _p(ws), nb, _stream())
+        ctx.p, ctx.t = p, t
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None
+        g = g.contiguous()
+        dp = torch.empty_like(ctx.p)
+        lib.him_bce_mean_bwd(_p(ctx.p), _p(ctx.t), ctx.p.numel(), _p(g), _p(dp), _stream())
+        return dp, None
+
+
+def bce_mean(p, t):
+    """nn.BCELoss()(p, t.detach())."""
+    return _BCEMean.apply(p, t.detach())
 
 
 # ------------------------------------------------------------------------------------------------

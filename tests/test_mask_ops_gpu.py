@@ -1,0 +1,140 @@
+"""-m gpu: the box2mask building blocks (BatchNorm2d, stand-alone activations, bilinear x2, channel log-softmax,
+masked NLL, BCE) against the fp32 torch reference of the SAME op on the CPU (tolerance 5e-5 of max|ref| unless noted)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _ops():
+    from neurips18_hierchical_image_manipulation_amd import ops
+    return ops
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+@pytest.mark.parametrize('shape', [(4, 16, 9, 13), (2, 70, 32, 32), (1, 8, 5, 7), (32, 3, 4, 4)], ids=str)
+@pytest.mark.parametrize('act', ['none', 'relu'])
+@pytest.mark.parametrize('training', [True, False])
+def test_batchnorm_fwd_bwd(shape, act, training):
+    ops = _ops()
+    B, Cn, H, W = shape
+    x = (_rand(*shape, seed=1) * 2 + 0.5).requires_grad_(True)
+    gamma = (1 + _rand(Cn, seed=2, scale=0.1)).requires_grad_(True)
+    beta = _rand(Cn, seed=3, scale=0.1).requires_grad_(True)
+    rm0, rv0 = _rand(Cn, seed=4, scale=0.2), 1 + _rand(Cn, seed=5, scale=0.1).abs()
+    rm, rv = rm0.clone(), rv0.clone()
+    y_ref = F.batch_norm(x, rm, rv, gamma, beta, training, 0.1, 1e-5)
+    if act == 'relu':
+        y_ref = F.relu(y_ref)
+    gy = _rand(*shape, seed=6)
+    gx_ref, gg_ref, gb_ref = torch.autograd.grad(y_ref, (x, gamma, beta), gy)
+    xd, gd, bd = (t.detach().to(DEV).requires_grad_(True) for t in (x, gamma, beta))
+    rmd, rvd = rm0.clone().to(DEV), rv0.clone().to(DEV)
+    y = ops.batch_norm(xd, gd, bd, rmd, rvd, training, 0.1, 1e-5, act)
+    assert_close('bn fwd', y, y_ref)
+    assert_close('bn running_mean', rmd, rm)
+    assert_close('bn running_var', rvd, rv)
+    gx, gg, gb = torch.autograd.grad(y, (xd, gd, bd), gy.to(DEV))
+    assert_close('bn dx', gx, gx_ref, rtol=1e-4)
+    assert_close('bn dgamma', gg, gg_ref, rtol=1e-4)
+    assert_close('bn dbeta', gb, gb_ref, rtol=1e-4)
+
+
+def test_batchnorm_residual_and_direct_grads():
+    ops = _ops()
+    x = _rand(3, 8, 6, 10, seed=1).requires_grad_(True)
+    r = _rand(3, 8, 6, 10, seed=2).requires_grad_(True)
+    gamma, beta = torch.ones(8, requires_grad=True), torch.zeros(8, requires_grad=True)
+    y_ref = F.batch_norm(x, None, None, gamma, beta, True, 0.1, 1e-5) + r
+    gy = _rand(*y_ref.shape, seed=3)
+    gx_ref, gr_ref = torch.autograd.grad(y_ref, (x, r), gy)
+    xd, rd = (t.detach().to(DEV).requires_grad_(True) for t in (x, r))
+    gd, bd = gamma.detach().to(DEV).requires_grad_(True), beta.detach().to(DEV).requires_grad_(True)
+    y = ops.batch_norm(xd, gd, bd, None, None, True, residual=rd)
+    assert_close('bn+res fwd', y, y_ref)
+    gx, gr = torch.autograd.grad(y, (xd, rd), gy.to(DEV))
+    assert_close('bn+res dx', gx, gx_ref, rtol=1e-4)
+    assert_close('bn+res dres', gr, gr_ref)
+
+
+@pytest.mark.parametrize('act', ['relu', 'lrelu', 'tanh', 'sigmoid'])
+def test_standalone_activation(act):
+    ops = _ops()
+    x = _rand(2, 5, 7, 9, seed=1).requires_grad_(True)
+    ref = {'relu': F.relu, 'lrelu': lambda t: F.leaky_relu(t, 0.2), 'tanh': torch.tanh, 'sigmoid': torch.sigmoid}[act](x)
+    gy = _rand(*x.shape, seed=2)
+    (gx_ref,) = torch.autograd.grad(ref, x, gy)
+    xd = x.detach().to(DEV).requires_grad_(True)
+    y = ops.activation(xd, act, 0.2)
+    assert_close('act fwd', y, ref)
+    (gx,) = torch.autograd.grad(y, xd, gy.to(DEV))
+    assert_close('act bwd', gx, gx_ref)
+
+
+@pytest.mark.parametrize('shape', [(2, 3, 4, 5), (1, 8, 16, 16), (2, 2, 1, 7), (1, 1, 9, 1)], ids=str)
+@pytest.mark.parametrize('align', [False, True])
+def test_bilinear_upsample2(shape, align):
+    ops = _ops()
+    x = _rand(*shape, seed=1).requires_grad_(True)
+    ref = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=align)
+    gy = _rand(*ref.shape, seed=2)
+    (gx_ref,) = torch.autograd.grad(ref, x, gy)
+    xd = x.detach().to(DEV).requires_grad_(True)
+    y = ops.upsample_bilinear2(xd, align)
+    assert_close('upsample fwd', y, ref)
+    (gx,) = torch.autograd.grad(y, xd, gy.to(DEV))
+    assert_close('upsample bwd', gx, gx_ref)
+
+
+@pytest.mark.parametrize('shape', [(2, 35, 9, 11), (1, 2, 4, 4), (3, 70, 16, 16)], ids=str)
+def test_log_softmax_channels(shape):
+    ops = _ops()
+    x = (_rand(*shape, seed=1) * 3).requires_grad_(True)
+    ref = F.log_softmax(x, dim=1)
+    gy = _rand(*shape, seed=2)
+    (gx_ref,) = torch.autograd.grad(ref, x, gy)
+    xd = x.detach().to(DEV).requires_grad_(True)
+    y = ops.log_softmax_channels(xd)
+    assert_close('log_softmax fwd', y, ref)
+    (gx,) = torch.autograd.grad(y, xd, gy.to(DEV))
+    assert_close('log_softmax bwd', gx, gx_ref)
+
+
+def test_masked_nll_matches_mask_recon_loss():
+    """reference models/mask_losses.py:12-27: labels where mask < 0.5 become ignore_index 255."""
+    ops = _ops()
+    B, Cn, H, W = 3, 35, 12, 14
+    logits = (_rand(B, Cn, H, W, seed=1) * 2).requires_grad_(True)
+    logp = F.log_softmax(logits, 1)
+    g = torch.Generator().manual_seed(2)
+    label = torch.randint(0, Cn, (B, H, W), generator=g)
+    mask = (torch.rand(B, 1, H, W, generator=g) > 0.4).float()
+    tgt = label.clone()
+    tgt[mask[:, 0] < 0.5] = 255
+    ref = F.nll_loss(logp, tgt, ignore_index=255)
+    (gl_ref,) = torch.autograd.grad(ref, logits)
+    ld = logits.detach().to(DEV).requires_grad_(True)
+    loss = ops.masked_nll(ops.log_softmax_channels(ld), label.float().unsqueeze(1).to(DEV), mask.to(DEV))
+    assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
+    (gl,) = torch.autograd.grad(loss, ld)
+    assert_close('masked nll grad', gl, gl_ref)
+
+
+def test_bce_mean():
+    ops = _ops()
+    p = torch.sigmoid(_rand(4, 1, 9, 11, seed=1) * 3).requires_grad_(True)
+    t = (torch.rand(4, 1, 9, 11, generator=torch.Generator().manual_seed(2)) > 0.5).float()
+    ref = F.binary_cross_entropy(p, t)
+    (gp_ref,) = torch.autograd.grad(ref, p)
+    pd = p.detach().to(DEV).requires_grad_(True)
+    loss = ops.bce_mean(pd, t.to(DEV))
+    assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
+    (gp,) = torch.autograd.grad(loss, pd)
+    assert_close('bce grad', gp, gp_ref)
