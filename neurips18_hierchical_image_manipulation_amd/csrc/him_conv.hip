@@ -914,6 +914,10 @@ static long long setup_dgrad(GConvP& g, WTransP& wt, int Cout, int Cin, int KH, 
       const int ih0 = ((ph - pad) % s + s) % s, iw0 = ((pw - pad) % s + s) % s;
       const int NA = ih0 < IH ? (IH - ih0 + s - 1) / s : 0;
       const int NC = iw0 < IW ? (IW - iw0 + s - 1) / s : 0;
+      if (JH == 0 || JW == 0 || NA == 0 || NC == 0) {  // kernel smaller than the stride (conv1x1 s2): these input
+        if (NA > 0 && NC > 0) g.kno_finish |= 2;        // positions receive no gradient -> the caller zero-fills
+        continue;
+      }
       GPhase& P = g.ph[q];
       P.A = Wt + off;
       P.JH = JH;
@@ -2464,6 +2468,10 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
   wt.W = w;
   const int IH = refl ? d->H + 2 * d->pad : d->H, IW = refl ? d->W + 2 * d->pad : d->W;
   long long nw = setup_dgrad(g, wt, d->Cout, d->Cin, d->KH, d->KW, d->stride, refl ? 0 : d->pad, IH, IW, Wt);
+  const bool holes = (g.kno_finish & 2) != 0;  // stride phases without a filter tap: zero gradient there
+  g.kno_finish = 0;
+  if (holes && (bias || act != HIM_ACT_NONE))
+    return fail(HIM_E_UNSUPPORTED, "transposed conv with kernel < stride and a fused bias/activation");
   if (dfold) g.pad_mode = PAD_DFOLD;
   WT2P t2;
   if (fast) {  // regroup tap-major with the Cout axis padded to 16: At_q[ci][(jh*JW+jw)*Cop + co]
@@ -2532,6 +2540,12 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
     rc = check_launch("wtrans");
   }
   if (rc || build_only) return rc;
+  if (holes) {
+    rc = hipMemsetAsync(out, 0, (size_t)d->B * d->Cin * d->H * d->W * sizeof(float), st) == hipSuccess
+             ? HIM_OK
+             : fail(HIM_E_LAUNCH, "dgrad: memset failed");
+    if (rc) return rc;
+  }
   if (dfold) {
     hipLaunchKernelGGL(reflect_extend_kernel, dim3(cdiv((long long)(d->OH + 2) * (d->OW + 2), 256), d->B * d->Cout),
                        dim3(256), 0, st, gy, dpad, d->OH, d->OW);

@@ -77,6 +77,26 @@ class InstanceNorm2d(nn.Module):
         self.ch, self.eps = ch, eps
 
 
+class BatchNorm2d(nn.Module):
+    """nn.BatchNorm2d(affine=True) parameter / buffer holder (state_dict keys weight, bias, running_mean, running_var,
+    num_batches_tracked); applied through ``ops.batch_norm`` with the module's train/eval mode."""
+
+    def __init__(self, ch, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.ch, self.eps, self.momentum = ch, eps, momentum
+        self.weight = nn.Parameter(torch.ones(ch))
+        self.bias = nn.Parameter(torch.zeros(ch))
+        self.register_buffer('running_mean', torch.zeros(ch))
+        self.register_buffer('running_var', torch.ones(ch))
+        self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+
+    def apply_to(self, x, act='none', slope=0.0, residual=None):
+        if self.training:
+            self.num_batches_tracked += 1
+        return ops.batch_norm(x, _pw(self.weight), _pw(self.bias), self.running_mean, self.running_var, self.training,
+                              self.momentum, self.eps, act, slope, residual)
+
+
 class ReLU(nn.Module):
     act, slope = 'relu', 0.0
 

@@ -53,6 +53,19 @@ def init_state_dict(shapes, seed, kind='gan'):
             fan_in = shape[1] * shape[2] * shape[3]
             std = 0.02 if kind == 'gan' else float(np.sqrt(2.0 / fan_in))
             arr = g.standard_normal(n, dtype=np.float32) * np.float32(std)
+        elif name.endswith('num_batches_tracked'):          # BatchNorm2d bookkeeping (int64 scalar)
+            out[name] = torch.zeros(shape, dtype=torch.int64)
+            continue
+        elif name.endswith('running_var'):                  # BatchNorm2d statistics: positive, around 1
+            arr = np.float32(1.0) + np.abs(g.standard_normal(n, dtype=np.float32)) * np.float32(0.1)
+        elif name.endswith('running_mean'):
+            arr = g.standard_normal(n, dtype=np.float32) * np.float32(0.1)
+        elif name.endswith('weight') and len(shape) == 1:   # BatchNorm2d gamma ~ N(1, 0.02) (layer_util.py:14-15)
+            arr = np.float32(1.0) + g.standard_normal(n, dtype=np.float32) * np.float32(0.02)
+        elif name.endswith('bias') and len(tuple(shapes[name[:-4] + 'weight'].shape)
+                                           if hasattr(shapes[name[:-4] + 'weight'], 'shape')
+                                           else tuple(shapes[name[:-4] + 'weight'])) == 1:
+            arr = (g.random(n, dtype=np.float32) * 2.0 - 1.0) * np.float32(0.1)   # BatchNorm2d beta (non-zero on purpose)
         elif name.endswith('bias'):
             wname = name[:-4] + 'weight'
             ws = tuple(shapes[wname].shape) if hasattr(shapes[wname], 'shape') else tuple(shapes[wname])

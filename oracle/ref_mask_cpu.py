@@ -1,0 +1,134 @@
+"""CPU restatement of the reference's box2mask generator  --  TEST INFRASTRUCTURE (see oracle/ref_cpu.py header).
+
+MaskTwoStreamConvSwitch_NET (reference models/MaskTwoStreamConvSwitch_NET.py:13-208) with the blocks of
+models/layer_util.py: ConvResnetBlock (:128-171), DeconvResnetBlock (:173-250), ResnetBlock (:333-378).  State-dict keys
+and shapes are the reference's.  Pinned against the imported reference class by tests/golden/make_golden.py (fixture
+box2mask_net.npz: forward in training and eval mode; parameter gradients of the reference run under
+``torch.autograd.graph.allow_mutation_on_saved_tensors`` -- its in-place ReLUs alias saved tensors, which torch >= 1.x
+rejects otherwise).
+
+Aliasing quirk restated OUT OF PLACE.  Every (De)ConvResnetBlock starts its deep path with ``nn.ReLU(True)`` applied
+to the block input itself (layer_util.py:150-153, 196-205): the tensor is rectified IN PLACE, so
+  * the shortcut path reads relu(x), not x (layer_util.py:166-170: ``residual = x`` is the same tensor), and
+  * the encoder features kept for the skip connections (MaskTwoStreamConvSwitch_NET.py:179-183) have been rectified by
+    the NEXT encoder block by the time the decoder concatenates them (:164-167).
+nn.Upsample(mode='bilinear') is evaluated with align_corners=False (what the reference code does under the torch of
+this container; torch 0.3.1 used align_corners=True -- flag ``align_corners``).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class _Up(nn.Module):
+    def __init__(self, align):
+        super().__init__()
+        self.align = align
+
+    def forward(self, x):
+        return F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=self.align)
+
+
+class ConvResnetBlock(nn.Module):   # layer_util.py:128-171 (num_layers = 1)
+    def __init__(self, cin, cout, stride, k):
+        super().__init__()
+        self.shortcut = None if (cin == cout and stride == 1) else nn.Sequential(nn.Conv2d(cin, cout, 1, stride),
+                                                                                 nn.BatchNorm2d(cout))
+        self.deep = nn.Sequential(nn.ReLU(), nn.Conv2d(cin, cout, k, stride, (k - 1) // 2), nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        r = F.relu(x)                      # the in-place ReLU: both paths (and the caller's alias) see relu(x)
+        res = r if self.shortcut is None else self.shortcut(r)
+        return self.deep[2](self.deep[1](r)) + res, r
+
+
+class DeconvResnetBlock(nn.Module):  # layer_util.py:173-250 (even kernel -> ConvTranspose2d, num_layers = 1)
+    def __init__(self, cin, cout, stride, k, align):
+        super().__init__()
+        sc = []
+        if cin != cout:
+            sc += [nn.Conv2d(cin, cout, 1), nn.BatchNorm2d(cout)]
+        if stride > 1:
+            sc += [_Up(align)]
+        self.shortcut = nn.Sequential(*sc) if sc else None
+        assert k % 2 == 0 and stride > 1
+        self.deep = nn.Sequential(nn.ReLU(), nn.ConvTranspose2d(cin, cout, k, stride, (k - 1) // 2, stride - 2),
+                                  nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        r = F.relu(x)
+        res = r if self.shortcut is None else self.shortcut(r)
+        return self.deep[2](self.deep[1](r)) + res
+
+
+class ResnetBlock(nn.Module):        # layer_util.py:333-378, reflect padding, BatchNorm
+    def __init__(self, dim):
+        super().__init__()
+        self.conv_block = nn.Sequential(nn.ReflectionPad2d(1), nn.Conv2d(dim, dim, 3), nn.BatchNorm2d(dim), nn.ReLU(),
+                                        nn.ReflectionPad2d(1), nn.Conv2d(dim, dim, 3), nn.BatchNorm2d(dim))
+
+    def forward(self, x):
+        return x + self.conv_block(x)
+
+
+class MaskTwoStreamConvSwitchNet(nn.Module):
+    def __init__(self, label_nc=35, output_nc=35, conv_dim=64, num_layers=3, conv_size=4, n_blocks=6,
+                 cond_in='ctx_obj', which_stream='obj_context', align_corners=False):
+        super().__init__()
+        self.num_layers = num_layers
+        self.which_stream = which_stream
+        input_nc = label_nc * 2 if cond_in == 'ctx_obj' else label_nc
+        dims = [conv_dim, 96, 128, 256, 512]
+        enc = [nn.Conv2d(input_nc, dims[0], 7, 2, 3), nn.BatchNorm2d(dims[0]), nn.ReLU()]
+        for i in range(num_layers):
+            enc.append(ConvResnetBlock(dims[i], dims[i + 1], 2, conv_size))
+        self.conv_encoder_modules = nn.Sequential(*enc)
+        latent = dims[num_layers]
+        self.latent_encoder = nn.Sequential(*[ResnetBlock(latent) for _ in range(int(math.floor(n_blocks / 2)))])
+
+        def decoder(out_nc, skip):
+            layers, od = [], latent
+            for i in range(num_layers + 1):
+                idim = od
+                od = dims[num_layers - i - 1] if i < num_layers else idim // 2
+                if skip and 1 <= i <= num_layers:
+                    idim *= 2
+                layers.append(DeconvResnetBlock(idim, od, 2, conv_size, align_corners))
+            layers.append(nn.Conv2d(od, out_nc, 3, 1, 1))
+            return nn.Sequential(*layers)
+
+        def latent_dec():
+            return nn.Sequential(*[ResnetBlock(latent) for _ in range(int(math.ceil(n_blocks / 2)))])
+
+        if 'obj' in which_stream:
+            self.obj_conv_decoder_modules = decoder(1, False)
+            self.obj_latent_decoder = latent_dec()
+        if 'context' in which_stream:
+            self.ctx_conv_decoder_modules = decoder(output_nc, True)
+            self.ctx_latent_decoder = latent_dec()
+
+    def _decode(self, dec, feat, skips):
+        for i, layer in enumerate(dec):
+            if skips is not None and 1 <= i <= self.num_layers:
+                feat = torch.cat((skips[-i], feat), 1)
+            feat = layer(feat)
+        return feat
+
+    def forward(self, x, cls_onehot=None):
+        e = self.conv_encoder_modules
+        f = e[2](e[1](e[0](x)))
+        skips = []                          # what the decoder will find in enc_features after the in-place ReLUs
+        for i in range(3, 3 + self.num_layers):
+            f, r = e[i](f)
+            skips.append(r)                 # = relu(previous stage output); for i = 3 it is the stem's ReLU output itself
+        latent = self.latent_encoder(f)
+        ctx_logit = ctx_prob = obj_logit = obj_prob = None
+        if 'context' in self.which_stream:
+            ctx_logit = self._decode(self.ctx_conv_decoder_modules, self.ctx_latent_decoder(latent), skips)
+            ctx_prob = F.log_softmax(ctx_logit, 1)
+        if 'obj' in self.which_stream:
+            obj_logit = self._decode(self.obj_conv_decoder_modules, self.obj_latent_decoder(latent), None)
+            obj_prob = torch.sigmoid(obj_logit)
+        return ctx_logit, ctx_prob, obj_logit, obj_prob

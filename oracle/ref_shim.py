@@ -120,3 +120,41 @@ def ref_step(model, batch, color=False):
     loss_D.backward()
     model.optimizer_D.step()
     return {k: float(v.detach()) for k, v in ld.items()}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# box2mask (second hot path): the generator classes are Python-2 code (xrange, dict.iteritems, int '/')
+# ------------------------------------------------------------------------------------------------------------------
+def _load_patched(name, subs):
+    """Import reference module ``models/<name>.py`` with textual Python-2 -> 3 substitutions applied IN MEMORY (the file
+    under /root/reference is not touched and nothing of it is written to disk)."""
+    path = os.path.join(REF, 'models', name + '.py')
+    with open(path) as f:
+        src = f.read()
+    for a, b in subs:
+        src = src.replace(a, b)
+    mod = types.ModuleType(name)
+    mod.__file__ = path
+    sys.modules[name] = mod
+    exec(compile(src, path, 'exec'), mod.__dict__)
+    return mod
+
+
+def box2mask_generator(**flags):
+    """The reference's MaskTwoStreamConvSwitch_NET (models/MaskTwoStreamConvSwitch_NET.py) built on CPU from the flags
+    of scripts/train_box2mask_city.sh (overridable)."""
+    install()
+    import builtins
+    builtins.xrange = range
+    importlib.import_module('layer_util')
+    py3 = [('.iteritems()', '.items()'), ('output_dim = input_dim/2', 'output_dim = input_dim//2')]
+    _load_patched('MaskContextAE_NET', py3)
+    M = _load_patched('MaskTwoStreamConvSwitch_NET', py3)
+    d = dict(label_nc=35, output_nc=35, fineSize=256, num_layers=3, conv_dim=64, conv_size=4, embed_dim=1024, z_dim=512,
+             norm_layer='batch', use_dropout=False, skip_start=1, skip_end=3, use_resnetblock=1, num_resnetblocks=1,
+             fusion_type='add', first_conv_stride=1, first_conv_size=5, which_stream='obj_context', cond_in='ctx_obj',
+             use_simpleRes=False, n_blocks=6, add_dilated_layers=False)
+    d.update(flags)
+    net = M.MaskTwoStreamConvSwitch_NET(types.SimpleNamespace(**d))
+    net.initialize()
+    return net

@@ -151,6 +151,62 @@ def golden_nets():
     print('nets_misc: LocalEnhancer / SN / edges pinned')
 
 
+def golden_box2mask_net():
+    """Second hot path: the box2mask generator MaskTwoStreamConvSwitch_NET with the flags of
+    scripts/train_box2mask_city.sh, 64x64 inputs, batch 2.  Forward in training and eval mode is pinned bit-exactly
+    (oracle vs imported reference); the reference's parameter gradients are obtained under
+    torch.autograd.graph.allow_mutation_on_saved_tensors (its in-place ReLUs alias saved tensors) and pinned through
+    per-parameter sums; BatchNorm running statistics after one training-mode forward are stored for two layers."""
+    from oracle import ref_mask_cpu
+    ref = ref_shim.box2mask_generator()
+    ora = ref_mask_cpu.MaskTwoStreamConvSwitchNet()
+    assert list(ref.state_dict().keys()) == list(ora.state_dict().keys())
+    sd = synth.init_state_dict(ora.state_dict(), 21)
+    x = torch.randn(2, 70, 64, 64, generator=torch.Generator().manual_seed(3))
+    gy = [torch.randn(2, 35, 64, 64, generator=torch.Generator().manual_seed(5)),
+          torch.randn(2, 1, 64, 64, generator=torch.Generator().manual_seed(6))]
+    # inputs are regenerated from the seeds by the tests; the checksums guard against a generator change
+    out = dict(x_sum=np.array([x.double().sum().item(), x.double().abs().sum().item()]),
+               gy_sum=np.array([gy[0].double().sum().item(), gy[1].double().sum().item()]))
+    for mode in ('eval', 'train'):
+        ref.load_state_dict(sd)
+        ora.load_state_dict(sd)
+        getattr(ref, mode)()
+        getattr(ora, mode)()
+        with torch.autograd.graph.allow_mutation_on_saved_tensors():
+            a = ref(x.clone(), None)
+            ((a[1] * gy[0]).sum() + (a[3] * gy[1]).sum()).backward()
+        b = ora(x.clone())
+        ((b[1] * gy[0]).sum() + (b[3] * gy[1]).sum()).backward()
+        for p, q in zip(a, b):
+            assert torch.equal(p, q), (mode, (p - q).abs().max())
+        out['ctx_prob_' + mode] = a[1].detach().numpy()
+        out['obj_prob_' + mode] = a[3].detach().numpy()
+        names, sums = [], []
+        gr = dict(ref.named_parameters())
+        for k, po in ora.named_parameters():
+            gr_k, go_k = gr[k].grad, po.grad
+            scale = float(gr_k.abs().max())
+            if k.endswith('bias'):   # conv biases in front of a BatchNorm have a TRUE gradient of 0: what is left is
+                scale = max(scale, float(gr[k[:-4] + 'weight'].grad.abs().max()))   # rounding noise of the layer's scale
+            assert float((gr_k - go_k).abs().max()) <= 4e-6 * max(scale, 1e-3), (mode, k, scale)
+            names.append(k)
+            sums.append([gr_k.double().sum().item(), gr_k.double().abs().sum().item()])
+        for k, po in ora.named_parameters():
+            gr[k].grad = None
+            po.grad = None
+        out['grad_names'] = np.array(names)
+        out['grad_sums_' + mode] = np.array(sums)
+        if mode == 'train':
+            st = ref.state_dict()
+            for k in ('conv_encoder_modules.1.running_mean', 'conv_encoder_modules.1.running_var',
+                      'ctx_conv_decoder_modules.3.deep.2.running_mean', 'ctx_conv_decoder_modules.3.deep.2.running_var'):
+                assert torch.equal(st[k], ora.state_dict()[k])
+                out['after_' + k.replace('.', '_')] = st[k].numpy()
+    np.savez_compressed(os.path.join(HERE, 'box2mask_net.npz'), **out)
+    print('box2mask_net: forward (train/eval) bit-exact, gradients and running statistics pinned')
+
+
 TINY = dict(model='pix2pixHD_condImg', netG='global', ngf=8, ndf=8, n_downsample_global=4, n_blocks_global=2,
             num_D=2, n_layers_D=3, label_nc=35, no_instance=True)
 TINY_GATE = dict(TINY, use_output_gate=True, num_D=3)
@@ -182,5 +238,7 @@ if __name__ == '__main__':
         trajectory('c1_traj', C1, 1, 128, 256, 20)
     if 'c2' in what:
         trajectory('c2_traj', C2, 8, 256, 512, 20)
+    if 'box2mask' in what:
+        golden_box2mask_net()
     if 'c4' in what:
         trajectory('c4_traj', C4, 4, 256, 256, 3, color=True)   # bs 4 of the bs-16 config keeps it to minutes

@@ -56,6 +56,9 @@ CONV_CASES = [
     (2, 256, 16, 32, 256, 3, 1, 1, 'reflect', 'none'),   # folded reflect dgrad under split-K
     (2, 20, 9, 70, 2, 3, 1, 1, 'zero', 'none'),          # tiny-M sliding-window wgrad, zero pad, W > one wave
     (1, 12, 70, 9, 4, 5, 1, 2, 'reflect', 'none'),       # tiny-M sliding-window wgrad 5x5, H > one row chunk
+    (2, 64, 32, 32, 96, 1, 2, 0, 'zero', 'none'),        # ConvResnetBlock shortcut: 1x1 stride 2 (empty stride phases)
+    (2, 16, 9, 11, 16, 1, 2, 0, 'zero', 'none'),         # 1x1 stride 2 on odd sizes
+    (2, 70, 32, 32, 64, 7, 2, 3, 'zero', 'none'),        # box2mask stem conv7 stride 2
 ]
 
 
