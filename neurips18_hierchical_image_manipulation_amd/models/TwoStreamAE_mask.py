@@ -1,0 +1,174 @@
+"""box2mask trainer on the HIP kernels: the reference's ``TwoStreamAE_mask`` (models/TwoStreamAE_mask.py) for the
+configuration of scripts/train_box2mask_city.sh (``--model AE_maskgen_twostream --no_comb --which_stream obj_context
+--cond_in ctx_obj --use_gan --which_gan patch_multiscale --objReconLoss bce --norm_layer batch --use_output_gate
+--use_ganFeat_loss``).  ``forward(..., eval_mode=False)`` IS the training step, as in the reference (:167-254): losses,
+then the generator's Adam step, then the discriminator's, all inside the call.
+
+Departures that do not change the arithmetic: the three one-hot tensors are built straight into the 70-channel condition
+buffer; ``x * mask.repeat`` + ``torch.cat`` are one kernel; the discriminator pass on the attached fake runs with frozen D
+weights (the reference computes those weight gradients and zeroes them before loss_D.backward(), :237-247); both Adams
+are fused flat-arena steps."""
+import argparse
+from collections import OrderedDict
+
+import torch
+
+from .. import ops
+from ..nn import frozen_params
+from ..optim import FusedAdam
+from .base_model import BaseModel
+from .Discriminator_NET import MultiscaleDiscriminator
+from .MaskTwoStreamConvSwitch_NET import MaskTwoStreamConvSwitch_NET
+from .pix2pixHD_condImg_model import pick_device
+
+DEFAULTS = dict(label_nc=35, output_nc=35, num_layers=3, conv_dim=64, conv_size=4, norm_layer='batch', n_blocks=6,
+                which_stream='obj_context', cond_in='ctx_obj', use_gan=True, which_gan='patch_multiscale', gan_weight=0.1,
+                rec_weight=1.0, use_output_gate=True, ndf=64, num_layers_D=3, objReconLoss='bce', use_ganFeat_loss=True,
+                lambda_feat=1.0, lr=0.0002, beta1=0.5, beta2=0.999, lr_control=False, no_comb=True, isTrain=True,
+                gpu_ids=[0], checkpoints_dir='./checkpoints', name='box2mask', niter=400, niter_decay=0)
+
+
+def complete(opt):
+    if isinstance(opt, dict):
+        opt = argparse.Namespace(**opt)
+    for k, v in DEFAULTS.items():
+        if not hasattr(opt, k):
+            setattr(opt, k, v)
+    return opt
+
+
+class TwoStreamAE_mask(BaseModel):
+    def name(self):
+        return 'TwoStreamAE_mask'
+
+    def __init__(self, opt):
+        opt = complete(opt)
+        super().__init__(opt)
+        if not opt.no_comb:
+            raise NotImplementedError('MaskTwoStreamConv_NET (without --no_comb) is not on the HIP path')
+        if opt.which_stream != 'obj_context' or opt.cond_in != 'ctx_obj':
+            raise NotImplementedError('box2mask HIP path: --which_stream obj_context --cond_in ctx_obj (the shipped recipe)')
+        if opt.use_gan and opt.which_gan != 'patch_multiscale':
+            raise NotImplementedError('box2mask HIP path: --which_gan patch_multiscale (LSGAN) only')
+        if opt.objReconLoss != 'bce':
+            raise NotImplementedError('box2mask HIP path: --objReconLoss bce only')
+        if opt.lr_control:
+            raise NotImplementedError('--lr_control reads the losses on the host every step (Discriminator_NET.py:190-211)')
+        self.device = pick_device(opt)
+        self.use_gan, self.use_output_gate = bool(opt.use_gan), bool(opt.use_output_gate)
+        self.netG = MaskTwoStreamConvSwitch_NET(opt).to(self.device)
+        self.loss_names = ['G_Recon_comb', 'G_Recon_obj', 'KL_loss', 'loss_G_GAN', 'loss_D_GAN', 'loss_G_GAN_Feat']
+        if self.isTrain:
+            self.old_lr = opt.lr
+            self.optimizer = FusedAdam(self.netG.parameters(), lr=opt.lr, betas=(opt.beta1, opt.beta2))
+            if self.use_gan:
+                self.netD = MultiscaleDiscriminator(1 + 2 * opt.label_nc, opt.ndf, opt.num_layers_D, opt.norm_layer, False, 2,
+                                                    True).to(self.device)
+                self.optimizer_D = FusedAdam(self.netD.parameters(), lr=opt.lr, betas=(opt.beta1, 0.999))
+
+    def _dev(self, t):
+        return None if t is None else t.to(self.device, dtype=torch.float32).contiguous()
+
+    # -- TwoStreamAE_mask.encode_input (:127-152) + construct_input_cond (:353-360) ---------------------------------
+    def encode_cond(self, mask_ctx_in, mask_in, cls):
+        """cat(one-hot box mask in the object's class channel, one-hot(context label map)) -> (B, 2*label_nc, H, W)."""
+        nc = self.opt.label_nc
+        ctx, box = self._dev(mask_ctx_in), self._dev(mask_in)
+        B, _, H, W = ctx.shape
+        cond = torch.zeros((B, 2 * nc, H, W), dtype=torch.float32, device=self.device)
+        from .._cabi import lib
+        lib.him_onehot(ctx.data_ptr(), cond.data_ptr(), B, nc, 2 * nc, nc, H * W, torch.cuda.current_stream().cuda_stream)
+        ids = [int(c) for c in cls.reshape(-1).tolist()]
+        for b, c in enumerate(ids):
+            cond[b, c].copy_(box[b, 0])
+        return cond
+
+    def _gan(self, preds, real):
+        loss = 0
+        for p in preds:
+            loss = loss + ops.mse_const(p[-1], 1.0 if real else 0.0)
+        return loss
+
+    def forward(self, label_map, mask_obj_in, mask_ctx_in, mask_obj_out, mask_out, mask_obj_inst, cls, mask_in,
+                eval_mode=False):
+        opt = self.opt
+        cond = self.encode_cond(mask_ctx_in, mask_in, cls)
+        gate = self._dev(mask_out)
+        self.netG.train(not eval_mode)
+        _, comb_prob, _, obj_prob = self.netG(cond)
+        if eval_mode:
+            return self._labels(comb_prob, obj_prob, label_map, gate)
+        label = self._dev(label_map)
+        loss_comb = ops.masked_nll(comb_prob, label, gate)
+        if self.use_output_gate:
+            obj_prob = ops.mul_mask(obj_prob, gate)
+        obj_gt = self._dev(mask_obj_inst)
+        loss_obj = ops.bce_mean(obj_prob, obj_gt)
+        zero = torch.zeros((), device=self.device)
+        loss_G_GAN, loss_D, loss_feat = zero, zero, torch.zeros(1, device=self.device)
+        if self.use_gan:
+            m = gate if self.use_output_gate else None
+            real_d = self.netD(ops.cat_channels([obj_gt, cond], m, 1))
+            fake_d = self.netD(ops.cat_channels([obj_prob.detach(), cond], m, 1))
+            loss_D = 0.5 * self._gan(real_d, True) + 0.5 * self._gan(fake_d, False)
+            if opt.use_ganFeat_loss:          # returned, never added to loss_G (reference :225-227)
+                with torch.no_grad():
+                    fw, dw = 4.0 / (opt.num_layers_D + 1), 1.0 / 2.0
+                    for i in range(2):
+                        for j in range(len(fake_d[i]) - 1):
+                            loss_feat = loss_feat + dw * fw * ops.l1_mean(fake_d[i][j], real_d[i][j]) * opt.lambda_feat
+            with frozen_params():
+                loss_G_GAN = self._gan(self.netD(ops.cat_channels([obj_prob, cond], m, 1)), True)
+        loss_G = loss_obj + opt.rec_weight * loss_comb + opt.gan_weight * loss_G_GAN
+        self.optimizer.zero_grad()
+        loss_G.backward()
+        self.optimizer.step()
+        if self.use_gan:
+            self.optimizer_D.zero_grad()
+            loss_D.backward()
+            self.optimizer_D.step()
+        return [loss_comb.detach(), loss_obj.detach(), 0, loss_G_GAN.detach(), loss_D.detach(), loss_feat.detach()], \
+               [None, obj_prob.detach()]
+
+    def _labels(self, comb_prob, obj_prob, label_map, gate):
+        """reconstruct()'s outputs in eval mode (:270-296): arg-max label map inside the box, ground truth outside."""
+        with torch.no_grad():
+            nc = self.opt.label_nc
+            label = self._dev(label_map)
+            inside = comb_prob.argmax(1, keepdim=True).float()
+            # postprocess_output: prob*mask + (1-mask)*one_hot(gt); its arg-max is the gt label outside the box
+            comb = torch.where(gate >= 0.5, inside, label)
+            del nc
+        return {'comb_pred_label': comb, 'obj_pred_label': obj_prob.detach()}
+
+    def generate(self, input_dict):
+        return self.forward(input_dict['label_map'], input_dict.get('mask_obj_in'), input_dict['mask_ctx_in'],
+                            input_dict.get('mask_obj_out'), input_dict['mask_out'], input_dict.get('mask_obj_inst'),
+                            input_dict['cls'], input_dict['mask_in'], eval_mode=True)
+
+    # -- checkpoints: the reference's per-module dict (base_model.py:52-66) ------------------------------------------
+    @property
+    def params_dict(self):
+        g, d = self.netG, OrderedDict()
+        for i, m in enumerate(g.conv_encoder_modules):
+            d['conv_encoder_%d' % i] = m
+        d['latent_encoder'] = g.latent_encoder
+        for i, m in enumerate(g.obj_conv_decoder_modules):
+            d['obj_conv_decoder_%d' % i] = m
+        d['obj_latent_decoder'] = g.obj_latent_decoder
+        for i, m in enumerate(g.ctx_conv_decoder_modules):
+            d['ctx_conv_decoder_%d' % i] = m
+        d['ctx_latent_decoder'] = g.ctx_latent_decoder
+        return d
+
+    def save(self, which_epoch):
+        self.save_network_dict(self.params_dict, self.optimizer, 'G', which_epoch, self.gpu_ids)
+        if self.use_gan:
+            self.save_network(self.netD, 'D', which_epoch, self.gpu_ids)
+
+    def update_learning_rate(self, epoch=0, data_size=0):
+        if epoch > self.opt.niter:
+            lr = self.old_lr - self.opt.lr / self.opt.niter_decay
+            for g in self.optimizer.param_groups + (self.optimizer_D.param_groups if self.use_gan else []):
+                g['lr'] = lr
+            self.old_lr = lr

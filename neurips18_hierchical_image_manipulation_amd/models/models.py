@@ -3,6 +3,9 @@
 
 def create_model(opt, data_size=None):
     from ..options import complete
+    if (opt.get('model') if isinstance(opt, dict) else getattr(opt, 'model', None)) == 'AE_maskgen_twostream':
+        from .TwoStreamAE_mask import TwoStreamAE_mask          # box2mask trainer (train_box2mask.py)
+        return TwoStreamAE_mask(opt)
     opt = complete(opt)
     if opt.model == 'pix2pixHD_condImg':
         from .pix2pixHD_condImg_model import Pix2PixHDModel_condImg

@@ -121,7 +121,7 @@ def run_layers(layers, x, final_residual=None):
     ``final_residual`` is added by the LAST InstanceNorm of the list (ResnetBlock tail)."""
     layers = list(layers)
     n, i = len(layers), 0
-    last_norm = max([j for j, l in enumerate(layers) if isinstance(l, InstanceNorm2d)], default=-1)
+    last_norm = max([j for j, l in enumerate(layers) if isinstance(l, (InstanceNorm2d, BatchNorm2d))], default=-1)
     while i < n:
         l = layers[i]
         pad_mode, rpad = 'zero', 0
@@ -135,7 +135,7 @@ def run_layers(layers, x, final_residual=None):
             norm = act = None
             norm_idx = -2
             j = i + 1
-            if j < n and isinstance(layers[j], InstanceNorm2d):
+            if j < n and isinstance(layers[j], (InstanceNorm2d, BatchNorm2d)):
                 norm, norm_idx = layers[j], j
                 j += 1
             if j < n and isinstance(layers[j], _ACTS):
@@ -155,10 +155,16 @@ def run_layers(layers, x, final_residual=None):
                 res = final_residual if (final_residual is not None and norm_idx == last_norm) else None
                 if res is not None and act is not None:
                     raise ValueError('residual after an activated norm is not a ResnetBlock tail')
-                x = ops.instance_norm(x, res, aname, slope, norm.eps)
+                if isinstance(norm, BatchNorm2d):
+                    x = norm.apply_to(x, aname, slope, res)
+                else:
+                    x = ops.instance_norm(x, res, aname, slope, norm.eps)
             i = j
         elif isinstance(l, InstanceNorm2d):
             x = ops.instance_norm(x, None, 'none', 0.0, l.eps)
+            i += 1
+        elif isinstance(l, BatchNorm2d):
+            x = l.apply_to(x)
             i += 1
         elif isinstance(l, _ACTS):
             raise ValueError('stand-alone activation is not on the hot path')

@@ -40,6 +40,19 @@ def make_batch(step, rank, B, H, W, label_nc=35, color=False, block=16):
     return OrderedDict((k, torch.from_numpy(np.ascontiguousarray(v))) for k, v in out.items())
 
 
+def make_box2mask_batch(step, rank, B, H, W, label_nc=35):
+    """Synthetic box2mask sample (keys of data/segmentation_dataset.py for the box2mask loader): piecewise-constant label
+    map, a centred object box ``mask_in``, the dilated context box ``mask_out``, the context map (label outside
+    ``mask_out``, the last class id inside), the object's class = the label at the centre, and its instance mask inside
+    the box."""
+    base = make_batch(step, rank, B, H, W, label_nc)
+    label, mask_in, mask_out = base['label'], base['mask_in'], base['mask_out']
+    cls = label[:, :, H // 2, W // 2].long().view(B, 1)
+    ctx = label * (1.0 - mask_out) + float(label_nc - 1) * mask_out
+    inst = (label == cls.view(B, 1, 1, 1).float()).float() * mask_in
+    return OrderedDict(label=label, mask_in=mask_in, mask_out=mask_out, mask_ctx_in=ctx, cls=cls, mask_obj_inst=inst)
+
+
 def init_state_dict(shapes, seed, kind='gan'):
     """``shapes``: ordered name -> shape (a module's ``state_dict()`` works).  kind 'gan': weights
     N(0,0.02), bias U(+-1/sqrt(fan_in)); kind 'vgg': He-normal weights, zero bias (synthetic VGG)."""

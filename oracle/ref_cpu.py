@@ -183,9 +183,10 @@ class GlobalTwoStreamGenerator(nn.Module):
 class MultiscaleDiscriminator(nn.Module):
     """models/Discriminator_NET.py:11-118 with getIntermFeat=True (keys ``scale<i>_layer<j>.0.*``)."""
 
-    def __init__(self, input_nc, ndf=64, n_layers=3, num_D=3):
+    def __init__(self, input_nc, ndf=64, n_layers=3, num_D=3, norm='instance'):
         super().__init__()
         self.num_D, self.n_layers = num_D, n_layers
+        _in_layer = globals()['_in_layer'] if norm == 'instance' else nn.BatchNorm2d   # 'batch': box2mask D
         for i in range(num_D):
             blocks = [[nn.Conv2d(input_nc, ndf, 4, 2, 2), nn.LeakyReLU(0.2, False)]]
             nf = ndf

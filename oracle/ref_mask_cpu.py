@@ -132,3 +132,76 @@ class MaskTwoStreamConvSwitchNet(nn.Module):
             obj_logit = self._decode(self.obj_conv_decoder_modules, self.obj_latent_decoder(latent), None)
             obj_prob = torch.sigmoid(obj_logit)
         return ctx_logit, ctx_prob, obj_logit, obj_prob
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the box2mask training step: TwoStreamAE_mask.forward (reference models/TwoStreamAE_mask.py:167-254)
+# ------------------------------------------------------------------------------------------------------------------
+LOSS_NAMES = ['G_Recon_comb', 'G_Recon_obj', 'KL_loss', 'loss_G_GAN', 'loss_D_GAN', 'loss_G_GAN_Feat']
+
+
+def encode_input(label_map, mask_ctx_in, mask_in, cls, label_nc):
+    """TwoStreamAE_mask.encode_input (:127-152): one-hot of the ground-truth map, of the context map, and the object box
+    mask written into the channel of the object's class."""
+    B, _, H, W = label_map.shape
+    gt = torch.zeros(B, label_nc, H, W).scatter_(1, label_map.long(), 1.0)
+    ctx = torch.zeros(B, label_nc, H, W).scatter_(1, mask_ctx_in.long(), 1.0)
+    obj = torch.zeros(B, label_nc, H, W)
+    for b in range(B):
+        obj[b, int(cls[b, 0])] = mask_in[b, 0]
+    return gt, ctx, obj
+
+
+class TwoStreamAEMask(object):
+    """CPU restatement of the reference trainer with the flags of scripts/train_box2mask_city.sh
+    (which_stream obj_context, cond_in ctx_obj, use_gan patch_multiscale, objReconLoss bce, use_output_gate,
+    use_ganFeat_loss, norm_layer batch).  ``step`` = one TwoStreamAE_mask.forward(eval_mode=False): losses, then the G
+    Adam step, then the D Adam step (:237-248)."""
+
+    def __init__(self, label_nc=35, ndf=64, num_layers_D=3, gan_weight=0.1, rec_weight=1.0, lambda_feat=1.0, lr=0.0002,
+                 beta1=0.5, beta2=0.999, use_output_gate=True, use_ganFeat_loss=True):
+        from oracle import ref_cpu
+        self.label_nc, self.gan_weight, self.rec_weight, self.lambda_feat = label_nc, gan_weight, rec_weight, lambda_feat
+        self.use_output_gate, self.use_ganFeat_loss, self.num_layers_D = use_output_gate, use_ganFeat_loss, num_layers_D
+        self.netG = MaskTwoStreamConvSwitchNet(label_nc, label_nc)
+        self.netD = ref_cpu.MultiscaleDiscriminator(1 + 2 * label_nc, ndf, num_layers_D, num_D=2, norm='batch')
+        self.gan_loss = ref_cpu.gan_loss
+        self.optimizer = torch.optim.Adam(self.netG.parameters(), lr=lr, betas=(beta1, beta2))
+        self.optimizer_D = torch.optim.Adam(self.netD.parameters(), lr=lr, betas=(beta1, 0.999))
+
+    def step(self, batch):
+        label, mask_out, mask_in = batch['label'], batch['mask_out'], batch['mask_in']
+        gt_onehot, ctx, obj = encode_input(label, batch['mask_ctx_in'], mask_in, batch['cls'], self.label_nc)
+        cond = torch.cat((obj, ctx), 1)
+        self.netG.train()
+        _, comb_prob, _, obj_prob = self.netG(cond)
+        tgt = label[:, 0].long().clone()
+        tgt[mask_out[:, 0] < 0.5] = 255                       # MaskReconLoss (mask_losses.py:20-26)
+        loss_comb = F.nll_loss(comb_prob, tgt, ignore_index=255)
+        if self.use_output_gate:
+            obj_prob = obj_prob * mask_out
+        obj_gt = batch['mask_obj_inst']
+        loss_obj = F.binary_cross_entropy(obj_prob, obj_gt)
+        real, fake, dcond = obj_gt, obj_prob, cond
+        if self.use_output_gate:
+            real, fake, dcond = real * mask_out, fake * mask_out, dcond * mask_out
+        real_d = self.netD(torch.cat((real, dcond), 1))
+        fake_d = self.netD(torch.cat((fake.detach(), dcond), 1))
+        loss_D_real, loss_D_fake = self.gan_loss(real_d, True), self.gan_loss(fake_d, False)
+        loss_D = 0.5 * loss_D_real + 0.5 * loss_D_fake
+        loss_feat = torch.zeros(1)
+        if self.use_ganFeat_loss:                              # computed and returned, never added to loss_G (:225-227)
+            fw, dw = 4.0 / (self.num_layers_D + 1), 1.0 / 2.0
+            for i in range(2):
+                for j in range(len(fake_d[i]) - 1):
+                    loss_feat = loss_feat + dw * fw * F.l1_loss(fake_d[i][j], real_d[i][j].detach()) * self.lambda_feat
+        loss_G_GAN = self.gan_loss(self.netD(torch.cat((fake, dcond), 1)), True)
+        loss_G = loss_obj + self.rec_weight * loss_comb + self.gan_weight * loss_G_GAN
+        self.optimizer.zero_grad()
+        loss_G.backward()
+        self.optimizer.step()
+        self.optimizer_D.zero_grad()
+        loss_D.backward()
+        self.optimizer_D.step()
+        vals = [loss_comb, loss_obj, 0.0, loss_G_GAN, loss_D, loss_feat]
+        return dict(zip(LOSS_NAMES, [float(v.detach().reshape(-1)[0]) if torch.is_tensor(v) else v for v in vals]))

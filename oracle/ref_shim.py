@@ -158,3 +158,39 @@ def box2mask_generator(**flags):
     net = M.MaskTwoStreamConvSwitch_NET(types.SimpleNamespace(**d))
     net.initialize()
     return net
+
+
+def box2mask_trainer(**flags):
+    """The reference's TwoStreamAE_mask (models/TwoStreamAE_mask.py) on CPU with the flags of
+    scripts/train_box2mask_city.sh (overridable).  Its forward() runs the whole training step (G and D Adam included)."""
+    install()
+    import builtins
+    builtins.xrange = range
+    importlib.import_module('layer_util')
+    py3 = [('.iteritems()', '.items()'), ('output_dim = input_dim/2', 'output_dim = input_dim//2')]
+    _load_patched('MaskContextAE_NET', py3)
+    _load_patched('MaskTwoStreamConvSwitch_NET', py3)
+    bm = _load_patched('base_model', py3)
+    sys.modules['models.base_model'] = bm
+    if not hasattr(nn, 'NLLLoss2d'):
+        nn.NLLLoss2d = nn.NLLLoss
+    T = _load_patched('TwoStreamAE_mask', py3)
+    d = dict(label_nc=35, output_nc=35, fineSize=256, num_layers=3, conv_dim=64, conv_size=4, embed_dim=1024, z_dim=512,
+             norm_layer='batch', use_dropout=False, skip_start=1, skip_end=3, use_resnetblock=1, num_resnetblocks=1,
+             fusion_type='add', first_conv_stride=1, first_conv_size=5, which_stream='obj_context', cond_in='ctx_obj',
+             use_simpleRes=False, n_blocks=6, add_dilated_layers=False, no_comb=True, use_gan=True,
+             which_gan='patch_multiscale', gan_weight=0.1, rec_weight=1.0, use_output_gate=True, ndf=64, num_layers_D=3,
+             objReconLoss='bce', use_ganFeat_loss=True, lambda_feat=1.0, lr=0.0002, beta1=0.5, beta2=0.999,
+             lr_control=False, isTrain=True, gpu_ids=[0], checkpoints_dir='/tmp/him_b2m', name='g', resize_or_crop='none',
+             continue_train=False, load_pretrain='', which_epoch='latest', niter=400, niter_decay=0)
+    d.update(flags)
+    real = torch.cuda.is_available
+    torch.cuda.is_available = lambda: True
+    stdout = sys.stdout
+    sys.stdout = io.StringIO()
+    try:
+        model = T.TwoStreamAE_mask(types.SimpleNamespace(**d))
+    finally:
+        sys.stdout = stdout
+        torch.cuda.is_available = lambda: False
+    return model

@@ -207,6 +207,40 @@ def golden_box2mask_net():
     print('box2mask_net: forward (train/eval) bit-exact, gradients and running statistics pinned')
 
 
+def golden_box2mask_traj(steps=6):
+    """box2mask training step (TwoStreamAE_mask.forward = losses + G Adam + D Adam) of the REAL reference, run under
+    torch.autograd.graph.allow_mutation_on_saved_tensors, next to the oracle restatement: 6 steps, 64x64, batch 2,
+    ndf 16, the remaining flags of scripts/train_box2mask_city.sh."""
+    from oracle import ref_mask_cpu
+    fl = dict(ndf=16, label_nc=35, num_layers_D=3, gan_weight=0.1, lr=0.0002, beta1=0.5, beta2=0.999)
+    ref = ref_shim.box2mask_trainer(**fl)
+    ora = ref_mask_cpu.TwoStreamAEMask(label_nc=35, ndf=16, num_layers_D=3, gan_weight=0.1, lr=0.0002, beta1=0.5, beta2=0.999)
+    assert list(ref.netD.state_dict().keys()) == list(ora.netD.state_dict().keys())
+    sdG = synth.init_state_dict(ora.netG.state_dict(), 21)
+    sdD = synth.init_state_dict(ora.netD.state_dict(), 22)
+    for m in (ref, ora):
+        m.netG.load_state_dict(sdG)
+        m.netD.load_state_dict(sdD)
+    rl, ol = [], []
+    for s in range(steps):
+        b = synth.make_box2mask_batch(s, 0, 2, 64, 64, 35)
+        with torch.autograd.graph.allow_mutation_on_saved_tensors():
+            r, _ = ref.forward(b['label'], None, b['mask_ctx_in'], None, b['mask_out'], b['mask_obj_inst'], b['cls'],
+                               b['mask_in'], eval_mode=False)
+        rl.append([float(x.detach().reshape(-1)[0]) if torch.is_tensor(x) else float(x) for x in r])
+        o = ora.step(b)
+        ol.append([o[k] for k in ref_mask_cpu.LOSS_NAMES])
+    rl, ol = np.array(rl, np.float64), np.array(ol, np.float64)
+    rel = np.abs(rl - ol) / np.maximum(np.abs(rl), 1e-12)
+    print('box2mask_traj: %d steps, max rel(oracle vs reference) per step = %s' % (
+        steps, ' '.join('%.1e' % v for v in rel.max(1))))
+    # free-running GAN + BatchNorm training amplifies the rounding difference between the two runs step by step (same
+    # mechanism as tests/golden/chaos_envelope.json for mask2image): exact at step 0, 1e-7 for the first steps
+    assert rel[:3].max() < 2e-6 and rel.max() < 5e-3, rel
+    np.savez_compressed(os.path.join(HERE, 'box2mask_traj.npz'), flags=json.dumps(fl), B=2, H=64, W=64,
+                        losses=rl.astype(np.float32), loss_names=np.array(ref_mask_cpu.LOSS_NAMES))
+
+
 TINY = dict(model='pix2pixHD_condImg', netG='global', ngf=8, ndf=8, n_downsample_global=4, n_blocks_global=2,
             num_D=2, n_layers_D=3, label_nc=35, no_instance=True)
 TINY_GATE = dict(TINY, use_output_gate=True, num_D=3)
@@ -240,5 +274,6 @@ if __name__ == '__main__':
         trajectory('c2_traj', C2, 8, 256, 512, 20)
     if 'box2mask' in what:
         golden_box2mask_net()
+        golden_box2mask_traj()
     if 'c4' in what:
         trajectory('c4_traj', C4, 4, 256, 256, 3, color=True)   # bs 4 of the bs-16 config keeps it to minutes
