@@ -125,11 +125,14 @@ class GradReducer(object):
 
 
 def attach_data_parallel(model, bucket_bytes=64 << 20, force=False):
-    """Give a mask2image model per-network reducers (no-op for world size 1 unless ``force``)."""
+    """Give a mask2image / box2mask model per-network reducers (no-op for world size 1 unless ``force``).
+    BatchNorm layers keep per-rank batch statistics (the reference's DataParallel behaviour); only gradients are averaged."""
     if not dist.is_initialized() or (dist.get_world_size() <= 1 and not force):
         return model
     for tag in ('G', 'D'):
-        opt = getattr(model, 'optimizer_' + tag)
+        opt = getattr(model, 'optimizer_' + tag, None)   # box2mask trainer: optimizer_G is its ``optimizer``
+        if opt is None:
+            continue
         arena = opt.arena
         red = GradReducer(arena.grad, [p._him_arena_range for p in arena.params], bucket_bytes, force=force)
         red.attach(arena.params)

@@ -58,6 +58,7 @@ class TwoStreamAE_mask(BaseModel):
         self.use_gan, self.use_output_gate = bool(opt.use_gan), bool(opt.use_output_gate)
         self.netG = MaskTwoStreamConvSwitch_NET(opt).to(self.device)
         self.loss_names = ['G_Recon_comb', 'G_Recon_obj', 'KL_loss', 'loss_G_GAN', 'loss_D_GAN', 'loss_G_GAN_Feat']
+        self.reducer_G = self.reducer_D = None     # set by dist.attach_data_parallel (one process per GPU)
         if self.isTrain:
             self.old_lr = opt.lr
             self.optimizer = FusedAdam(self.netG.parameters(), lr=opt.lr, betas=(opt.beta1, opt.beta2))
@@ -65,6 +66,11 @@ class TwoStreamAE_mask(BaseModel):
                 self.netD = MultiscaleDiscriminator(1 + 2 * opt.label_nc, opt.ndf, opt.num_layers_D, opt.norm_layer, False, 2,
                                                     True).to(self.device)
                 self.optimizer_D = FusedAdam(self.netD.parameters(), lr=opt.lr, betas=(opt.beta1, 0.999))
+
+    @property
+    def optimizer_G(self):
+        """alias used by dist.attach_data_parallel (the reference calls the generator's optimizer ``optimizer``)."""
+        return self.optimizer
 
     def _dev(self, t):
         return None if t is None else t.to(self.device, dtype=torch.float32).contiguous()
@@ -121,11 +127,19 @@ class TwoStreamAE_mask(BaseModel):
                 loss_G_GAN = self._gan(self.netD(ops.cat_channels([obj_prob, cond], m, 1)), True)
         loss_G = loss_obj + opt.rec_weight * loss_comb + opt.gan_weight * loss_G_GAN
         self.optimizer.zero_grad()
+        if self.reducer_G is not None:
+            self.reducer_G.begin()
         loss_G.backward()
+        if self.reducer_G is not None:
+            self.reducer_G.finish()
         self.optimizer.step()
         if self.use_gan:
             self.optimizer_D.zero_grad()
+            if self.reducer_D is not None:
+                self.reducer_D.begin(contributions=2)   # D(real) and D(fake.detach()) both reach D's weights
             loss_D.backward()
+            if self.reducer_D is not None:
+                self.reducer_D.finish()
             self.optimizer_D.step()
         return [loss_comb.detach(), loss_obj.detach(), 0, loss_G_GAN.detach(), loss_D.detach(), loss_feat.detach()], \
                [None, obj_prob.detach()]

@@ -43,7 +43,34 @@ chk = torch.stack([p.detach().double().sum() for p in a.netG.parameters()]).sum(
 allc = [torch.zeros_like(chk) for _ in range(world)]
 dist.all_gather(allc, chk)
 assert all(torch.equal(allc[0], c) for c in allc)
+nbG, nbD = len(a.reducer_G.buckets), len(a.reducer_D.buckets)
+
+# ---- the box2mask trainer (BatchNorm generator + 2-scale BatchNorm PatchGAN) through the same reducer -----------------
+def build_b2m():
+    m = create_model(dict(model='AE_maskgen_twostream', ndf=16, gpu_ids=[local], isTrain=True, checkpoints_dir='/tmp/him_ddp',
+                          name='b'))
+    m.netG.load_state_dict(synth.init_state_dict(m.netG.state_dict(), 21))
+    m.netD.load_state_dict(synth.init_state_dict(m.netD.state_dict(), 22))
+    return m
+def b2m_step(m, bt):
+    out, _ = m.forward(bt['label'], None, bt['mask_ctx_in'], None, bt['mask_out'], bt['mask_obj_inst'], bt['cls'], bt['mask_in'])
+    return [float(x.reshape(-1)[0]) if torch.is_tensor(x) else float(x) for x in out]
+a = build_b2m()
+attach_data_parallel(a, bucket_bytes=1 << 16, force=True)
+assert a.reducer_G is not None and a.reducer_D is not None and len(a.reducer_G.buckets) > 3
+b = build_b2m() if world == 1 else None
+for s in range(3):
+    bt = synth.make_box2mask_batch(s, rank, 2, 64, 64)
+    la = b2m_step(a, bt)
+    assert all(a.reducer_G.launched) and all(a.reducer_D.launched)
+    if b is not None:
+        assert la == b2m_step(b, bt), (la,)
+torch.cuda.synchronize()
+if b is not None:
+    for p, q in zip(list(a.netG.parameters()) + list(a.netD.parameters()), list(b.netG.parameters()) + list(b.netD.parameters())):
+        assert torch.equal(p, q)
 dist.barrier()
 if rank == 0:
-    print('DDP SELFCHECK OK world=%d buckets G=%d D=%d' % (world, len(a.reducer_G.buckets), len(a.reducer_D.buckets)))
+    print('DDP SELFCHECK OK world=%d buckets G=%d D=%d (mask2image) G=%d D=%d (box2mask)' % (
+        world, nbG, nbD, len(a.reducer_G.buckets), len(a.reducer_D.buckets)))
 dist.destroy_process_group()
