@@ -1030,10 +1030,11 @@ struct WinoGeom {
   int OH, OW;        // output grid the 2x2 tiles cover
   int TY, TX, T, Tp;
   int po;            // patch origin offset: input row = 2*ty - po + i   (1: pad-1 conv, 2: full correlation)
+  int fold;          // data gradient of a REFLECT-padded conv folded into the patches of the border tiles (below)
 };
 static WinoGeom wino_geom(int B, int C, int H, int W, int OH, int OW, int po) {
   WinoGeom g;
-  g.B = B; g.C = C; g.H = H; g.W = W; g.OH = OH; g.OW = OW; g.po = po;
+  g.B = B; g.C = C; g.H = H; g.W = W; g.OH = OH; g.OW = OW; g.po = po; g.fold = 0;
   g.TY = (OH + 1) / 2; g.TX = (OW + 1) / 2;
   g.T = B * g.TY * g.TX;
   g.Tp = (g.T + 127) / 128 * 128;
@@ -1077,6 +1078,33 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
         const float v = src[ys[i] + xs[j]];
         d[i][j] = (oky[i] && okx[j]) ? v : 0.f;
       }
+    if (g.fold && (ty == 0 || ty == g.TY - 1 || tx == 0 || tx == g.TX - 1)) {
+      // Reflect-pad data gradient without a padded grid.  dx[1] needs W0^T dy[0] on top of the zero-pad gradient and
+      // dx[H-2] needs W2^T dy[H-1] (the mirrored pad rows feed the neighbours of the border).  In F(2,3) the LAST
+      // patch row of the top tile meets only output 1 / filter row W0, and the FIRST patch row of the bottom tile only
+      // output H-2 / filter row W2 -- so adding dy[0] to the top tile's patch row 3 and dy[H-1] to the bottom tile's
+      // patch row 0 (columns alike, corners get the product terms) yields exactly the folded gradient (H, W even).
+      const int ey = ty == 0 ? 0 : g.H - 1, ei = ty == 0 ? 3 : 0;          // extra source row -> patch row ei
+      const int ex = tx == 0 ? 0 : g.W - 1, ej = tx == 0 ? 3 : 0;
+      const bool rowx = ty == 0 || ty == g.TY - 1, colx = tx == 0 || tx == g.TX - 1;
+      float addr[4], addc[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) addr[j] = (rowx && okx[j]) ? src[ey * g.W + xs[j]] : 0.f;   // dy[ey][patch col j]
+#pragma unroll
+      for (int i = 0; i < 4; ++i) addc[i] = (colx && oky[i]) ? src[ys[i] + ex] : 0.f;         // dy[patch row i][ex]
+      const float corner = (rowx && colx) ? src[ey * g.W + ex] : 0.f;
+      // (H, W >= 4 is required by the caller: the top/bottom and left/right border tiles are distinct)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float e = 0.f;
+          if (i == ei) e += addr[j];
+          if (j == ej) e += addc[i];
+          if (i == ei && j == ej) e += corner;
+          d[i][j] += e;
+        }
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1368,8 +1396,9 @@ static int wino_batched_gemm(const float* A, const float* Bm, float* Cm, int M, 
 // dst[B][Mout][OH][OW] = act(winograd-conv(src[B][Csrc][H][W], U) + bias); ws holds V and Mo
 static int run_wino_conv(int B, int Csrc, int H, int W, int Mout, int OH, int OW, int po, bool reflect,
                          const float* src, const float* U, const float* bias, int act, float slope, float* dst,
-                         float* ws, hipStream_t st) {
-  const WinoGeom gi = wino_geom(B, Csrc, H, W, OH, OW, po);
+                         float* ws, hipStream_t st, bool fold = false) {
+  WinoGeom gi = wino_geom(B, Csrc, H, W, OH, OW, po);
+  gi.fold = fold ? 1 : 0;
   float* V = ws;
   float* Mo = V + (size_t)16 * Csrc * gi.Tp;
   const dim3 gin(cdiv(gi.Tp, 256), Csrc);
@@ -2403,8 +2432,12 @@ static bool dfold_ok(const HimConv2d* d) {
 static bool wino_dgrad_ok(const HimConv2d* d) {
   return wino_shape_ok(d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad, d->H, d->W) && d->OH == d->H && d->OW == d->W;
 }
+static bool wino_dgrad_fold(const HimConv2d* d) {  // reflect folded into the border tiles' patches (see wino_input_kernel)
+  return d->pad_mode == HIM_PAD_REFLECT && (d->H % 2) == 0 && (d->W % 2) == 0 && d->H >= 4 && d->W >= 4 &&
+         !getenv("HIM_WINO_PADDED_DGRAD");
+}
 static size_t wino_dgrad_floats(const HimConv2d* d) {  // U' + V + Mo (+ padded gradient for reflect)
-  const bool refl = d->pad_mode == HIM_PAD_REFLECT;
+  const bool refl = d->pad_mode == HIM_PAD_REFLECT && !wino_dgrad_fold(d);
   const int GH = refl ? d->H + 2 : d->H, GW = refl ? d->W + 2 : d->W;
   return (size_t)16 * d->Cin * d->Cout + wino_conv_floats(d->B, d->Cout, d->Cin, GH, GW) +
          (refl ? (size_t)d->B * d->Cin * GH * GW : 0);
@@ -2445,13 +2478,14 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
       int rcu = check_launch("wino_weight");
       if (rcu || build_only) return rcu;
     }
-    const bool rf = d->pad_mode == HIM_PAD_REFLECT;
+    const bool fold = wino_dgrad_fold(d);
+    const bool rf = d->pad_mode == HIM_PAD_REFLECT && !fold;
     const int GH = rf ? d->H + 2 : d->H, GW = rf ? d->W + 2 : d->W;
     float* wsv = U + (size_t)16 * d->Cin * d->Cout;
     float* dpadw = wsv + wino_conv_floats(d->B, d->Cout, d->Cin, GH, GW);
     // reflect: full correlation (offset 2) -> padded gradient -> fold; zero pad: the plain pad-1 correlation
     int rcw = run_wino_conv(d->B, d->Cout, d->OH, d->OW, d->Cin, GH, GW, rf ? 2 : 1, false, gy, panel ? panel : U,
-                            nullptr, HIM_ACT_NONE, 0.f, rf ? dpadw : out, wsv, st);
+                            nullptr, HIM_ACT_NONE, 0.f, rf ? dpadw : out, wsv, st, fold);
     if (rcw || !rf) return rcw;
     hipLaunchKernelGGL(reflect_fold_kernel, dim3(cdiv((long long)d->H * d->W, 256), d->B * d->Cin), dim3(256), 0, st,
                        (const float*)dpadw, out, d->B * d->Cin, d->H, d->W, 1, 1, (size_t)0);
