@@ -139,6 +139,67 @@ def cpu_baseline():
                        'torch CPU fp32 oracle, %d threads: %.1f s' % (bs, cores, dt))
 
 
+C4 = dict(model='pix2pixHD_condImgColor', netG='global_twostream', ngf=64, ndf=64, n_downsample_global=4,
+          n_blocks_global=9, num_D=2, n_layers_D=3, label_nc=49, no_instance=True, no_imgCond=True,
+          which_encoder='ctx_label', use_skip=True, use_output_gate=True, mask_gan_input=True)
+
+
+def other_workload(args):
+    """Same protocol (resident synthetic batches, barrier + synchronize on both sides, max over ranks) for BASELINE
+    config 4 (two-stream colour generator, 256x256, bs 16 per GPU) and config 5's shape (box2mask, 256x256, bs 32)."""
+    from neurips18_hierchical_image_manipulation_amd import synth
+    from neurips18_hierchical_image_manipulation_amd.dist import init_process_group_from_env, attach_data_parallel
+    from neurips18_hierchical_image_manipulation_amd.models import create_model
+    rank, local, world = init_process_group_from_env()
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+    if args.workload == 'c4':
+        bs, name = 16, 'C4: mask2image ADE20K-shaped 256x256, colour two-stream generator, label_nc 49, 2-scale PatchGAN + VGG19'
+        model = create_model(dict(C4, gpu_ids=[local], isTrain=True, checkpoints_dir='/tmp/him_bench', name='c4', batchSize=bs))
+        batches = [{k: v.to(device) for k, v in synth.make_batch(s, rank, bs, 256, 256, 49, True).items()} for s in range(4)]
+        step = lambda i: model.optimize_parameters(batches[i % 4])  # noqa: E731
+    else:
+        bs, name = 32, 'box2mask 256x256 (scripts/train_box2mask_city.sh flags): BatchNorm two-stream mask generator + 2-scale PatchGAN'
+        model = create_model(dict(model='AE_maskgen_twostream', gpu_ids=[local], isTrain=True, checkpoints_dir='/tmp/him_bench',
+                                  name='b2m'))
+        batches = [{k: (v.to(device) if k != 'cls' else v) for k, v in synth.make_box2mask_batch(s, rank, bs, 256, 256).items()}
+                   for s in range(4)]
+
+        def step(i):
+            b = batches[i % 4]
+            return model.forward(b['label'], None, b['mask_ctx_in'], None, b['mask_out'], b['mask_obj_inst'], b['cls'],
+                                 b['mask_in'])[0]
+    attach_data_parallel(model)
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({'metric': '%s train images/sec' % args.workload, 'value': round(bs * world * args.steps / dt, 3),
+                          'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                          'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+                          'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                          'config': {'workload': name, 'global_batch': bs * world, 'per_gpu_batch': bs,
+                                     'parallelism': 'dp%d' % world}, 'roofline': None, 'cpu_baseline': None}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -146,7 +207,12 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--workload', choices=['c2', 'c4', 'box2mask'], default='c2',
+                    help='c2 (default) = the BASELINE.json metric; c4 / box2mask = the other measured configurations '
+                         '(DESIGN.md), reported with the same protocol but without roofline / cpu_baseline legs')
     args = ap.parse_args()
+    if args.workload != 'c2':
+        return other_workload(args)
 
     from neurips18_hierchical_image_manipulation_amd import synth
     from neurips18_hierchical_image_manipulation_amd.dist import init_process_group_from_env, attach_data_parallel
