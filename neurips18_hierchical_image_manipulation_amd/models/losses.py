@@ -43,7 +43,4 @@ class VGGLoss(nn.Module):
         x_vgg = self.vgg(x)
         if y_vgg is None:
             y_vgg = self.target_features(y)
-        loss = 0
-        for i in range(len(x_vgg)):
-            loss = loss + self.weights[i] * ops.l1_mean(x_vgg[i], y_vgg[i])
-        return loss
+        return ops.l1_weighted_sum(list(zip(x_vgg, y_vgg)), self.weights)

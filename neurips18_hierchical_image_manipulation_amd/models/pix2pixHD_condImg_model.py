@@ -9,6 +9,7 @@ import os
 import random
 from collections import OrderedDict
 
+import numpy as np
 import torch
 
 from .. import ops, synth
@@ -256,10 +257,10 @@ class Pix2PixHDModel_condImg(BaseModel):
         if not opt.no_ganFeat_loss:
             feat_weights = 4.0 / (opt.n_layers_D + 1)
             D_weights = 1.0 / opt.num_D
-            for i in range(opt.num_D):
-                for j in range(len(pred_fake[i]) - 1):
-                    loss_G_GAN_Feat = loss_G_GAN_Feat + D_weights * feat_weights * \
-                        self.criterionFeat(pred_fake[i][j], pred_real[i][j]) * opt.lambda_feat
+            pairs = [(pred_fake[i][j], pred_real[i][j]) for i in range(opt.num_D) for j in range(len(pred_fake[i]) - 1)]
+            # D_weights * feat_weights * L1 * lambda_feat per term (reference :235-242), folded into one weight vector
+            w = float(np.float32(np.float32(D_weights * feat_weights)) * np.float32(opt.lambda_feat))
+            loss_G_GAN_Feat = loss_G_GAN_Feat + ops.l1_weighted_sum(pairs, [w] * len(pairs))
 
         loss_G_VGG = torch.zeros(1, device=self.device)
         if not opt.no_vgg_loss:
