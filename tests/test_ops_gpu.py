@@ -340,6 +340,9 @@ WINO_CASES = [
     (3, 16, 2, 2, 16, 'reflect'),        # a single tile per image
     (1, 128, 6, 10, 128, 'reflect'),     # 128-multiple channels: Winograd weight gradient (batched NT GEMM)
     (2, 128, 8, 8, 256, 'zero'),         # Winograd weight gradient, rectangular
+    (2, 32, 4, 4, 32, 'reflect'),        # folded reflect gradient: top and bottom border tiles are neighbours
+    (1, 32, 4, 36, 16, 'reflect'),       # folded reflect gradient, wide plane
+    (1, 16, 6, 5, 16, 'reflect'),        # even H, odd W: padded-gradient fallback
 ]
 
 
