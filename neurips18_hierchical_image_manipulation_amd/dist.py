@@ -104,7 +104,11 @@ class GradReducer(object):
             ev.record(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
-                dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group)
+                if dist.get_backend(self.group) == 'nccl':       # RCCL: averaging collective
+                    dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group)
+                else:                                            # gloo on device tensors (tests): no AVG op
+                    dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+                    view.div_(self.world)
         else:
             dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
             view.div_(self.world)

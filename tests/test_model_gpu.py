@@ -290,6 +290,21 @@ def test_rccl_reducer_path_single_rank_is_identity():
     assert r.returncode == 0 and 'DDP SELFCHECK OK' in r.stdout, r.stdout[-3000:]
 
 
+def test_two_ranks_on_one_gpu_keep_replicas_identical():
+    """The whole multi-process trainer path (rank-seeded batches, wgrad-completion-triggered buckets on the comm stream,
+    deferred generator exchange + Adam, contribution counting for D) with TWO ranks sharing this GPU over gloo -- RCCL
+    refuses two ranks on one device, so the collective backend is the only thing this does not exercise.  Both
+    trainers (mask2image and box2mask); the ranks must end with identical parameters."""
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr',
+           '127.0.0.1', '--master-port', str(29900 + os.getpid() % 90), os.path.join(root, 'tools', 'ddp_selfcheck.py')]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900,
+                       env=dict(os.environ, HIM_DDP_BACKEND='gloo'))
+    assert r.returncode == 0 and 'DDP SELFCHECK OK world=2' in r.stdout, r.stdout[-3000:]
+
+
 def test_c4_colour_two_stream_full_width_vs_reference():
     """BASELINE config 4 (ADE20K-shaped 256x256, pix2pixHD_condImgColor, two-stream + skips + gate, label_nc 49,
     ngf 64): golden from the real reference at batch 4; step 0 tight, then teacher-forced parity."""

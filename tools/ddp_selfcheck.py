@@ -11,9 +11,15 @@ from neurips18_hierchical_image_manipulation_amd.models import create_model
 
 os.environ.setdefault('WORLD_SIZE', '1')
 rank, local, world = int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)), int(os.environ['WORLD_SIZE'])
+backend = os.environ.get('HIM_DDP_BACKEND', 'nccl')   # 'gloo': several ranks may share ONE GPU (logic test without RCCL)
+local = local % torch.cuda.device_count()
+os.environ['LOCAL_RANK'] = str(local)               # models pick their device from LOCAL_RANK
 torch.cuda.set_device(local)
 if not dist.is_initialized():
-    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+    if backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
 flags = dict(model='pix2pixHD_condImg', netG='global', ngf=16, ndf=16, n_downsample_global=3, n_blocks_global=2,
              num_D=2, n_layers_D=3, label_nc=35, no_instance=True, gpu_ids=[local], isTrain=True,
              checkpoints_dir='/tmp/him_ddp', name='t')
@@ -69,6 +75,10 @@ torch.cuda.synchronize()
 if b is not None:
     for p, q in zip(list(a.netG.parameters()) + list(a.netD.parameters()), list(b.netG.parameters()) + list(b.netD.parameters())):
         assert torch.equal(p, q)
+chk = torch.stack([p.detach().double().sum() for p in list(a.netG.parameters()) + list(a.netD.parameters())]).sum().reshape(1)
+allc = [torch.zeros_like(chk) for _ in range(world)]
+dist.all_gather(allc, chk)
+assert all(torch.equal(allc[0], c) for c in allc), 'box2mask replicas diverged'
 dist.barrier()
 if rank == 0:
     print('DDP SELFCHECK OK world=%d buckets G=%d D=%d (mask2image) G=%d D=%d (box2mask)' % (
