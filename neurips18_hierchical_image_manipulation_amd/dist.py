@@ -24,7 +24,11 @@ def init_process_group_from_env(backend=None):
         return 0, 0, 1
     rank, local = int(os.environ['RANK']), int(os.environ.get('LOCAL_RANK', '0'))
     if backend is None:
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        backend = os.environ.get('HIM_DDP_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+    if backend != 'nccl' and torch.cuda.is_available():
+        # logic tests: several gloo ranks may share one GPU (RCCL refuses that); models read LOCAL_RANK
+        local = local % torch.cuda.device_count()
+        os.environ['LOCAL_RANK'] = str(local)
     if backend == 'nccl':
         torch.cuda.set_device(local)
     if not dist.is_initialized():
