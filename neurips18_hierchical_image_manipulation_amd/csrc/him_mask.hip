@@ -34,20 +34,41 @@ __device__ __forceinline__ float act_grad_from_z(float z, int act, float slope) 
 }
 
 // ---- BatchNorm2d ------------------------------------------------------------------------------------------------
-// partial[(c*S + s)*2 + {0,1}] = sum, sum of squares of (x - shift_c) over slice s of channel c; shift_c = x[0][c][0]
+// partial[(c*S + s)*2 + {0,1}] = sum, sum of squares of (x - shift_c) over slice s of channel c; shift_c = x[0][c][0].
+// A slice is a contiguous range of the channel's B*hw positions; inside one image plane the run is contiguous in memory
+// (float4 loads when hw % 4 == 0), so no per-element division.
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, float* __restrict__ partial, int B, int C,
                                                        int hw) {
   __shared__ float sh[8];
   const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
   const long long n = (long long)B * hw;
-  const long long lo = n * s / S, hi = n * (s + 1) / S;
+  long long lo = n * s / S, hi = n * (s + 1) / S;
+  const bool vec = (hw & 3) == 0;
+  if (vec) {
+    lo &= ~3ll;
+    hi = (s == S - 1) ? n : (hi & ~3ll);
+  }
   const float shift = x[(size_t)c * hw];
   float a = 0.f, q = 0.f;
-  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
-    const int b = (int)(i / hw), r = (int)(i - (long long)b * hw);
-    const float d = x[((size_t)b * C + c) * hw + r] - shift;
-    a += d;
-    q += d * d;
+  for (long long p0 = lo; p0 < hi;) {
+    const int b = (int)(p0 / hw), r0 = (int)(p0 - (long long)b * hw);
+    const int r1 = (int)min((long long)hw, r0 + (hi - p0));
+    const float* __restrict__ pl = x + ((size_t)b * C + c) * hw;
+    if (vec) {
+      for (int r = r0 + threadIdx.x * 4; r < r1; r += 1024) {
+        const float4 v = *(const float4*)(pl + r);
+        const float d0 = v.x - shift, d1 = v.y - shift, d2 = v.z - shift, d3 = v.w - shift;
+        a += (d0 + d1) + (d2 + d3);
+        q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      }
+    } else {
+      for (int r = r0 + threadIdx.x; r < r1; r += 256) {
+        const float d = pl[r] - shift;
+        a += d;
+        q += d * d;
+      }
+    }
+    p0 += r1 - r0;
   }
   a = block_sum_256(a, sh);
   q = block_sum_256(q, sh);
@@ -86,17 +107,35 @@ __global__ void bn_finalize_kernel(const float* __restrict__ x, const float* __r
   }
 }
 
-// y = act((x - mean)*rstd*gamma + beta) (+ residual)
-__global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ residual, float* __restrict__ y,
-                                const float* __restrict__ mean, const float* __restrict__ rstd,
-                                const float* __restrict__ gamma, const float* __restrict__ beta, long long n, int C, int hw,
-                                int act, float slope) {
-  GS_LOOP(i, n) {
-    const int c = (int)((i / hw) % C);
-    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-    float v = apply_act((x[i] - mean[c]) * rstd[c] * g + b, act, slope);
-    if (residual) v += residual[i];
-    y[i] = v;
+// y = act((x - mean)*rstd*gamma + beta) (+ residual); grid (ceil(hw/1024), B*C): the plane index gives the channel
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ residual,
+                                                       float* __restrict__ y, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int C, int hw, int act, float slope) {
+  const int plane = blockIdx.y, c = plane % C;
+  const float g = (gamma ? gamma[c] : 1.f) * rstd[c];
+  const float b = (beta ? beta[c] : 0.f) - mean[c] * g;
+  const size_t base = (size_t)plane * hw;
+  if ((hw & 3) == 0) {
+    const int r = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (r >= hw) return;
+    const float4 v = *(const float4*)(x + base + r);
+    float4 o;
+    o.x = apply_act(fmaf(v.x, g, b), act, slope);
+    o.y = apply_act(fmaf(v.y, g, b), act, slope);
+    o.z = apply_act(fmaf(v.z, g, b), act, slope);
+    o.w = apply_act(fmaf(v.w, g, b), act, slope);
+    if (residual) {
+      const float4 rr = *(const float4*)(residual + base + r);
+      o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+    }
+    *(float4*)(y + base + r) = o;
+  } else {
+    for (int r = blockIdx.x * 1024 + threadIdx.x; r < min(hw, (int)(blockIdx.x + 1) * 1024); r += 256) {
+      float v = apply_act(fmaf(x[base + r], g, b), act, slope);
+      if (residual) v += residual[base + r];
+      y[base + r] = v;
+    }
   }
 }
 
@@ -109,16 +148,36 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   __shared__ float sh[8];
   const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
   const long long n = (long long)B * hw;
-  const long long lo = n * s / S, hi = n * (s + 1) / S;
+  long long lo = n * s / S, hi = n * (s + 1) / S;
+  const bool vec = (hw & 3) == 0;
+  if (vec) {
+    lo &= ~3ll;
+    hi = (s == S - 1) ? n : (hi & ~3ll);
+  }
   const float mu = mean[c], rs = rstd[c], g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
   float a = 0.f, q = 0.f;
-  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
-    const int b = (int)(i / hw), r = (int)(i - (long long)b * hw);
-    const size_t idx = ((size_t)b * C + c) * hw + r;
-    const float xh = (x[idx] - mu) * rs;
-    const float dz = dy[idx] * act_grad_from_z(xh * g + bt, act, slope);
-    a += dz;
-    q += dz * xh;
+  for (long long p0 = lo; p0 < hi;) {
+    const int b = (int)(p0 / hw), r0 = (int)(p0 - (long long)b * hw);
+    const int r1 = (int)min((long long)hw, r0 + (hi - p0));
+    const size_t base = ((size_t)b * C + c) * hw;
+    if (vec) {
+      for (int r = r0 + threadIdx.x * 4; r < r1; r += 1024) {
+        const float4 v = *(const float4*)(x + base + r), gy = *(const float4*)(dy + base + r);
+        const float h0 = (v.x - mu) * rs, h1 = (v.y - mu) * rs, h2 = (v.z - mu) * rs, h3 = (v.w - mu) * rs;
+        const float z0 = gy.x * act_grad_from_z(h0 * g + bt, act, slope), z1 = gy.y * act_grad_from_z(h1 * g + bt, act, slope);
+        const float z2 = gy.z * act_grad_from_z(h2 * g + bt, act, slope), z3 = gy.w * act_grad_from_z(h3 * g + bt, act, slope);
+        a += (z0 + z1) + (z2 + z3);
+        q += (z0 * h0 + z1 * h1) + (z2 * h2 + z3 * h3);
+      }
+    } else {
+      for (int r = r0 + threadIdx.x; r < r1; r += 256) {
+        const float xh = (x[base + r] - mu) * rs;
+        const float dz = dy[base + r] * act_grad_from_z(xh * g + bt, act, slope);
+        a += dz;
+        q += dz * xh;
+      }
+    }
+    p0 += r1 - r0;
   }
   a = block_sum_256(a, sh);
   q = block_sum_256(q, sh);
@@ -144,18 +203,34 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, float*
   if (dbeta) dbeta[c] = accumulate ? dbeta[c] + a : a;
 }
 
-// training: dx = gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat)); eval: dx = gamma*rstd*dz
-__global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
-                                    const float* __restrict__ mean, const float* __restrict__ rstd,
-                                    const float* __restrict__ gamma, const float* __restrict__ beta,
-                                    const float* __restrict__ sums, long long n, int C, int hw, float inv_n, int act,
-                                    float slope, int training) {
-  GS_LOOP(i, n) {
-    const int c = (int)((i / hw) % C);
-    const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f, rs = rstd[c];
-    const float xh = (x[i] - mean[c]) * rs;
-    const float dz = dy[i] * act_grad_from_z(xh * g + bt, act, slope);
-    dx[i] = training ? g * rs * (dz - sums[c * 2] * inv_n - xh * sums[c * 2 + 1] * inv_n) : g * rs * dz;
+// training: dx = gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat)); eval: dx = gamma*rstd*dz.  grid (ceil(hw/1024), B*C)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           float* __restrict__ dx, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ sums,
+                                                           int C, int hw, float inv_n, int act, float slope, int training) {
+  const int plane = blockIdx.y, c = plane % C;
+  const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f, rs = rstd[c], mu = mean[c];
+  const float m1 = training ? sums[c * 2] * inv_n : 0.f, m2 = training ? sums[c * 2 + 1] * inv_n : 0.f;
+  const float gr = g * rs;
+  const size_t base = (size_t)plane * hw;
+  if ((hw & 3) == 0) {
+    const int r = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (r >= hw) return;
+    const float4 v = *(const float4*)(x + base + r), gy = *(const float4*)(dy + base + r);
+    const float h0 = (v.x - mu) * rs, h1 = (v.y - mu) * rs, h2 = (v.z - mu) * rs, h3 = (v.w - mu) * rs;
+    float4 o;
+    o.x = gr * (gy.x * act_grad_from_z(h0 * g + bt, act, slope) - m1 - h0 * m2);
+    o.y = gr * (gy.y * act_grad_from_z(h1 * g + bt, act, slope) - m1 - h1 * m2);
+    o.z = gr * (gy.z * act_grad_from_z(h2 * g + bt, act, slope) - m1 - h2 * m2);
+    o.w = gr * (gy.w * act_grad_from_z(h3 * g + bt, act, slope) - m1 - h3 * m2);
+    *(float4*)(dx + base + r) = o;
+  } else {
+    for (int r = blockIdx.x * 1024 + threadIdx.x; r < min(hw, (int)(blockIdx.x + 1) * 1024); r += 256) {
+      const float xh = (x[base + r] - mu) * rs;
+      const float dz = dy[base + r] * act_grad_from_z(xh * g + bt, act, slope);
+      dx[base + r] = gr * (dz - m1 - xh * m2);
+    }
   }
 }
 
@@ -362,15 +437,15 @@ int him_batchnorm_fwd(const float* x, const float* residual, const float* gamma,
                       float* run_var, float* y, float* save_mean, float* save_rstd, int B, int C, int hw, float eps,
                       float momentum, int training, int act, float slope, void* ws, size_t ws_bytes, void* stream) {
   if (B <= 0 || C <= 0 || hw <= 0) return fail(HIM_E_INVALID, "batchnorm: B=%d C=%d hw=%d", B, C, hw);
+  if ((long long)B * C > 65535) return fail(HIM_E_UNSUPPORTED, "batchnorm: B*C = %lld planes > 65535", (long long)B * C);
   if (!training && (!run_mean || !run_var)) return fail(HIM_E_INVALID, "batchnorm: eval mode needs running statistics");
   if (!ws || ws_bytes < him_batchnorm_ws(C)) return fail(HIM_E_WORKSPACE, "batchnorm: ws too small");
   float* partial = (float*)ws;
   if (training) hipLaunchKernelGGL(bn_stats_kernel, dim3(C, BN_SLICES), dim3(256), 0, ST, x, partial, B, C, hw);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, ST, x, (const float*)partial, save_mean, save_rstd,
                      run_mean, run_var, B, C, hw, BN_SLICES, eps, momentum, training);
-  const long long n = (long long)B * C * hw;
-  hipLaunchKernelGGL(bn_apply_kernel, gs_grid(n), dim3(256), 0, ST, x, residual, y, (const float*)save_mean,
-                     (const float*)save_rstd, gamma, beta, n, C, hw, act, slope);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(cdiv(hw, 1024), B * C), dim3(256), 0, ST, x, residual, y, (const float*)save_mean,
+                     (const float*)save_rstd, gamma, beta, C, hw, act, slope);
   return check_launch("batchnorm_fwd");
 }
 
@@ -378,6 +453,7 @@ int him_batchnorm_bwd(const float* x, const float* gamma, const float* beta, con
                       const float* dy, float* dx, float* dgamma, float* dbeta, int B, int C, int hw, int training, int act,
                       float slope, int accumulate, void* ws, size_t ws_bytes, void* stream) {
   if (B <= 0 || C <= 0 || hw <= 0) return fail(HIM_E_INVALID, "batchnorm: B=%d C=%d hw=%d", B, C, hw);
+  if ((long long)B * C > 65535) return fail(HIM_E_UNSUPPORTED, "batchnorm: B*C = %lld planes > 65535", (long long)B * C);
   if (!ws || ws_bytes < him_batchnorm_ws(C)) return fail(HIM_E_WORKSPACE, "batchnorm: ws too small");
   float* partial = (float*)ws;
   float* sums = partial + (size_t)C * BN_SLICES * 2;
@@ -386,9 +462,8 @@ int him_batchnorm_bwd(const float* x, const float* gamma, const float* beta, con
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, ST, (const float*)partial, sums, dgamma, dbeta, C,
                      BN_SLICES, accumulate);
   if (dx) {
-    const long long n = (long long)B * C * hw;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, gs_grid(n), dim3(256), 0, ST, x, dy, dx, save_mean, save_rstd, gamma, beta,
-                       (const float*)sums, n, C, hw, 1.f / ((float)B * (float)hw), act, slope, training);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv(hw, 1024), B * C), dim3(256), 0, ST, x, dy, dx, save_mean, save_rstd,
+                       gamma, beta, (const float*)sums, C, hw, 1.f / ((float)B * (float)hw), act, slope, training);
   }
   return check_launch("batchnorm_bwd");
 }
