@@ -252,6 +252,7 @@ class _Conv2d(torch.autograd.Function):
             lib.him_conv2d_fwd(ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), _p(ws), nb, _stream())
         ctx.d = d
         ctx.x, ctx.w, ctx.b = x, w, b
+        ctx.gslice = getattr(x, '_him_grad_slice', None)
         # the OUTPUT must go through save_for_backward: a plain ctx attribute closes a tensor -> grad_fn -> ctx -> tensor
         # cycle through C++ that no collector sees, and with it the whole upstream graph of every step leaks
         ctx.save_for_backward(y if act != ACT_NONE else None)
@@ -270,7 +271,21 @@ class _Conv2d(torch.autograd.Function):
         else:
             dz = dy
         dx = dw = db = None
-        if ctx.needs_input_grad[0] and id(w) not in SKIP_DGRAD:
+        gs = ctx.gslice
+        if ctx.needs_input_grad[0] and id(w) not in SKIP_DGRAD and gs is not None and gs[1] <= 4 < d.Cin:
+            # only channels [c0, c0+n) of the input can use a gradient (first PatchGAN conv: the image channels behind
+            # 35..70 channels of data): data gradient of the n-channel weight slice (tiny-M kernel), zeros elsewhere
+            c0, n = gs
+            d2 = HimConv2d.from_buffer_copy(d)
+            d2.Cin = n
+            dxs = torch.empty((d.B, n, d.H, d.W), dtype=torch.float32, device=x.device)
+            wsl = w.detach()[:, c0:c0 + n].contiguous()
+            nb = lib.him_conv2d_bwd_data_ws(ctypes.byref(d2))
+            ws = _ws(nb, x)
+            lib.him_conv2d_bwd_data(ctypes.byref(d2), _p(dz), _p(wsl), _p(dxs), _p(ws), nb, st)
+            dx = torch.zeros_like(x)
+            lib.him_copy_channels(_p(dxs), n, 0, _p(dx), d.Cin, c0, n, d.B, d.H * d.W, 0, 0, 0, st)
+        elif ctx.needs_input_grad[0] and id(w) not in SKIP_DGRAD:
             dx = torch.empty_like(x)
             nb = lib.him_conv2d_bwd_data_ws(ctypes.byref(d))
             ws = _ws(nb, x)
@@ -401,6 +416,7 @@ class _Deconv2d(torch.autograd.Function):
             lib.him_deconv2d_fwd(ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), _p(ws), nb, _stream())
         ctx.d = d
         ctx.x, ctx.w, ctx.b = x, w, b
+        ctx.gslice = getattr(x, '_him_grad_slice', None)
         # the OUTPUT must go through save_for_backward: a plain ctx attribute closes a tensor -> grad_fn -> ctx -> tensor
         # cycle through C++ that no collector sees, and with it the whole upstream graph of every step leaks
         ctx.save_for_backward(y if act != ACT_NONE else None)
@@ -729,7 +745,11 @@ class _AvgPool3s2(torch.autograd.Function):
 
 def avgpool3s2(x):
     """nn.AvgPool2d(3, stride=2, padding=1, count_include_pad=False)."""
-    return _AvgPool3s2.apply(x)
+    y = _AvgPool3s2.apply(x)
+    gs = getattr(x, '_him_grad_slice', None)
+    if gs is not None:
+        y._him_grad_slice = gs      # channel-wise op: the same slice is the only one that needs a gradient
+    return y
 
 
 class _MaxPool(torch.autograd.Function):
@@ -801,7 +821,19 @@ class _CatMask(torch.autograd.Function):
 
 
 def cat_channels(tensors, mask=None, mask_mode=0):
-    return _CatMask.apply(mask, int(mask_mode if mask is not None else 0), *tensors)
+    out = _CatMask.apply(mask, int(mask_mode if mask is not None else 0), *tensors)
+    need = [bool(t.requires_grad) for t in tensors]
+    if torch.is_grad_enabled() and any(need) and not all(need):
+        # only a channel slice of this tensor can receive a gradient (discriminator input = [data | image]): consumers
+        # may restrict their data gradient to it (``_Conv2d.backward``)
+        c, lo, hi = 0, None, 0
+        for t, n in zip(tensors, need):
+            if n:
+                lo = c if lo is None else lo
+                hi = c + t.shape[1]
+            c += t.shape[1]
+        out._him_grad_slice = (lo, hi - lo)
+    return out
 
 
 def mul_mask(x, mask):
