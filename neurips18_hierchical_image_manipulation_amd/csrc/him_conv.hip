@@ -2000,17 +2000,25 @@ __global__ __launch_bounds__(256) void wgrad_small_win_kernel(const WGradP p, in
   }
 #pragma unroll
     for (int r = 0; r < KS; ++r) HIM_SW_ROW(y0 - pad + r, win[r])
+    float gv[MM], gn[MM];   // dy of this row / of the next one (loaded a step ahead: one resident wave pair per SIMD
+#pragma unroll           // cannot hide a load that is consumed right away)
+    for (int m = 0; m < MM; ++m) {
+      const float v = g[(size_t)m * HW + y0 * W];
+      gn[m] = lane_on ? v : 0.f;
+    }
+    float nxt[KS], nx2[KS];   // x rows entering the window one / two steps from now
+    HIM_SW_ROW(y0 + 1 + pad, nxt)
     for (int pyb = y0; pyb < y1; pyb += KS) {
 #pragma unroll
       for (int ph = 0; ph < KS; ++ph) {
         const int py = pyb + ph;
         if (py < y1) {
-          float nxt[KS], gv[MM];
-          HIM_SW_ROW(py + 1 + pad, nxt)
+          HIM_SW_ROW(py + 2 + pad, nx2)
 #pragma unroll
           for (int m = 0; m < MM; ++m) {
-            const float v = g[(size_t)m * HW + py * W];
-            gv[m] = lane_on ? v : 0.f;
+            gv[m] = gn[m];
+            const float v = g[(size_t)m * HW + min(py + 1, H - 1) * W];
+            gn[m] = lane_on ? v : 0.f;
           }
           // x row (py - pad + th) sits in logical slot th = physical (th + ph) % KS
 #pragma unroll
@@ -2020,7 +2028,10 @@ __global__ __launch_bounds__(256) void wgrad_small_win_kernel(const WGradP p, in
 #pragma unroll
               for (int m = 0; m < MM; ++m) acc[m][th * KS + tw] = fmaf(gv[m], win[(th + ph) % KS][tw], acc[m][th * KS + tw]);
 #pragma unroll
-          for (int k = 0; k < KS; ++k) win[ph][k] = nxt[k];
+          for (int k = 0; k < KS; ++k) {
+            win[ph][k] = nxt[k];
+            nxt[k] = nx2[k];
+          }
         }
       }
     }
