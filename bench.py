@@ -1,15 +1,16 @@
 #!/usr/bin/env python
 """Benchmark of the mask2image training hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # N > 1: spawns N ranks itself (one process per GPU, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-           bench.py --gpus N --steps K --warmup W
+           bench.py --gpus N --steps K --warmup W          # same thing, ranks provided by the launcher
 
 One "step" = one full training step (G forward, 3x multi-scale D forward, LSGAN + feature-matching + VGG losses,
 G backward + Adam, D backward + Adam) on one synthetic Cityscapes-shaped batch that is already resident in HBM.
-Workload = BASELINE.json configs[1]: 512x256 (NCHW (8,.,256,512)), bs 8 per GPU, GlobalGenerator ngf 64 /
+Default workload = BASELINE.json configs[1] (C2): 512x256 (NCHW (8,.,256,512)), bs 8 per GPU, GlobalGenerator ngf 64 /
 4 downsamples / 9 ResnetBlocks (182.6 M params), 3-scale PatchGAN, VGG19 perceptual loss, fp32 throughout.
-Rank 0 prints ONE JSON line (metric = BASELINE.json's images/s; weak scaling: bs 8 per GPU).
+Rank 0 prints ONE JSON line (metric = BASELINE.json's images/s; weak scaling: bs 8 per GPU).  `--workload c2local | c4
+| box2mask` run the other measured configurations under the same protocol (same JSON schema incl. roofline/cpu_baseline).
 """
 import argparse
 import json
@@ -24,13 +25,79 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+PEAK_F32_MFMA = 157.3  # TFLOP/s, v_mfma_f32_32x32x2_f32 (MI355X_MICROARCH.md)
+
 C2 = dict(model='pix2pixHD_condImg', netG='global', ngf=64, ndf=64, n_downsample_global=4, n_blocks_global=9,
           num_D=3, n_layers_D=3, label_nc=35, no_instance=True)
-H, W, BS = 256, 512, 8
-PEAK_F32_MFMA = 157.3  # TFLOP/s, v_mfma_f32_32x32x2_f32 (MI355X_MICROARCH.md)
-G_FWD_GFLOP_PER_IMG = 246.3  # conv + transposed-conv FLOPs of GlobalGenerator at 256x512
+C1 = dict(C2, num_D=1)                      # BASELINE configs[0]: 256x128 bs 1, global G, 1-scale D (CPU plumbing case)
+C2LOCAL = dict(C2, netG='local', ngf=32, n_local_enhancers=1, n_blocks_local=3)
+C4 = dict(model='pix2pixHD_condImgColor', netG='global_twostream', ngf=64, ndf=64, n_downsample_global=4,
+          n_blocks_global=9, num_D=2, n_layers_D=3, label_nc=49, no_instance=True, no_imgCond=True,
+          which_encoder='ctx_label', use_skip=True, use_output_gate=True, mask_gan_input=True)
+
+WORKLOADS = {
+    # name: flags, per-GPU batch, H, W, label_nc, colour batch keys, G-forward direct-form GFLOP / image
+    'c2': dict(flags=C2, bs=8, H=256, W=512, label_nc=35, color=False, g_gflop=246.3,
+               metric='mask2image train images/sec at 512x256 bs=8',
+               desc='C2: mask2image Cityscapes-shaped 512x256, GlobalGenerator ngf64/4down/9blocks (182.6M params) + '
+                    '3-scale PatchGAN + VGG19 loss (synthetic weights), full train step G+D Adam, fp32'),
+    'c2local': dict(flags=C2LOCAL, bs=8, H=256, W=512, label_nc=35, color=False, g_gflop=94.7,
+                    metric='mask2image (LocalEnhancer) train images/sec at 512x256 bs=8',
+                    desc='C2 with netG=local: LocalEnhancer ngf32 (global G ngf64 at 256x128 + 1 local enhancer, 182.9M '
+                         'params) + 3-scale PatchGAN + VGG19 loss (synthetic weights), full train step, fp32'),
+    'c4': dict(flags=C4, bs=16, H=256, W=256, label_nc=49, color=True, g_gflop=147.1,
+               metric='mask2image colour two-stream train images/sec at 256x256 bs=16',
+               desc='C4: mask2image ADE20K-shaped 256x256, pix2pixHD_condImgColor two-stream generator + skips + gate, '
+                    'label_nc 49, 2-scale PatchGAN + VGG19 loss, full train step, fp32'),
+    'box2mask': dict(flags=dict(model='AE_maskgen_twostream'), bs=32, H=256, W=256, label_nc=35, color=False,
+                     g_gflop=23.4, metric='box2mask train images/sec at 256x256 bs=32',
+                     desc='C5 shape: box2mask 256x256 (scripts/train_box2mask_city.sh flags), BatchNorm two-stream mask '
+                          'generator (13.9M params) + 2-scale BatchNorm PatchGAN, G+D Adam inside forward, fp32'),
+}
 
 
+# --------------------------------------------------------------------------------------------------------------------
+# launcher
+# --------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(args):
+    """``python bench.py --gpus N`` from a bare shell: re-execute this script as N ranks (one process per GPU) through
+    torch.distributed.run on 127.0.0.1; the ranks' stdout/stderr pass through, so rank 0's JSON line is this process's
+    JSON line.  Under torch.distributed.run (RANK set) this is never reached."""
+    import subprocess
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC only on this host driver (RCCL needs it)
+    env.setdefault('OMP_NUM_THREADS', str(max((os.cpu_count() or 8) // args.gpus, 1)))
+    return subprocess.call(cmd, env=env)
+
+
+def check_world(args, world):
+    """--gpus N must mean N ranks over RCCL: anything else would print a number for a job that was not run."""
+    if world != max(args.gpus, 1):
+        raise SystemExit('bench.py: --gpus %d but %d rank(s) are running (WORLD_SIZE)' % (args.gpus, world))
+    if world == 1:
+        return None
+    be = dist.get_backend()
+    if be != 'nccl' and os.environ.get('HIM_DDP_BACKEND') != be:      # HIM_DDP_BACKEND=gloo: logic test, ranks share a GPU
+        raise SystemExit('bench.py: %d ranks need the RCCL backend ("nccl"), got %r' % (world, be))
+    if be == 'nccl' and torch.cuda.device_count() < world:
+        raise SystemExit('bench.py: --gpus %d but only %d device(s) visible' % (world, torch.cuda.device_count()))
+    if dist.get_world_size() != world:
+        raise SystemExit('bench.py: process group has %d ranks, expected %d' % (dist.get_world_size(), world))
+    return be
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# roofline legs
+# --------------------------------------------------------------------------------------------------------------------
 def _event_ms(fn, iters):
     """HIP-event timing on the stream the kernels are launched on (torch's current stream)."""
     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -42,21 +109,35 @@ def _event_ms(fn, iters):
     return start.elapsed_time(end) / iters
 
 
-def dominant_kernel_roofline(device):
+def _profile_json(name):
+    p = os.path.join(ROOT, 'profiles', name)
+    if os.path.isfile(p):
+        with open(p) as f:
+            return json.load(f)
+    return None
+
+
+def dominant_kernel_roofline(device, bs, ntiles):
     """The launch that carries most of the step's matrix work: stage 2 of the Winograd F(2x2,3x3) ResnetBlock conv
-    (refpad(1) + conv3x3 1024->1024 on (8,1024,16,32)) = ONE batched fp32-MFMA GEMM over the 16 transform positions,
-    [16] x (1024 x 1024) x (1024 x 1024 tiles) = 34.36 GFLOP EXECUTED per launch (the direct form of the same conv is
-    77.31 GFLOP: Winograd does 2.25x fewer multiplies).  18 forward + 18 data-gradient + 18 weight-gradient launches of
-    this shape per step.  `achieved` = executed FLOP / average launch time, HIP events on the launch stream around
-    him_winograd_gemm (exactly the kernel the conv launches); MFMA-bound: algorithmic bytes = the three 67.1 MB
-    operands read/written once = 201 MB, intensity 171 FLOP/B >> the fp32 ridge of ~25.
-    `traffic` = HBM-side bytes per launch from the committed PMC passes (profiles/r01_pmc_dominant_kernel.json:
-    FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE), null if that file is absent.
-    `conv_launch` times the WHOLE conv (input transform + GEMM + output transform, cached weight panel) and states its
-    rate in direct-form-equivalent FLOP, for comparison with a non-Winograd implementation."""
+    (refpad(1) + conv3x3 1024->1024) = ONE batched fp32-MFMA GEMM over the 16 transform positions,
+    [16] x (1024 x 1024) x (1024 x ntiles) with ntiles = B * H/2 * W/2 (C2: 8x8x16 = 1024, 34.36 GFLOP EXECUTED per
+    launch; the direct form of the same conv is 77.31 GFLOP: Winograd does 2.25x fewer multiplies).  18 forward + 18
+    data-gradient + 18 weight-gradient launches of this shape per step.
+    `achieved` = executed FLOP / average launch time.  `source: "microbench"`: the launches timed here are issued
+    back-to-back by this function through the C ABI (him_winograd_gemm = exactly the kernel/grid the conv launches),
+    with HIP events on the launch stream -- NOT the launches inside the timed training step (those share the GPU with
+    side-stream kernels); `avg_launch_ms_rocprof` is the same kernel's average duration in the committed rocprofv3
+    kernel trace of the same microbench (profiles/), which the HIP-event figure must agree with (back-to-back launches
+    overlap their tails by a few %).  MFMA-bound: algorithmic bytes = the three operands read/written once, intensity
+    171 FLOP/B >> the fp32 ridge of ~25.
+    `traffic` = HBM-side bytes per launch from the committed PMC passes (FETCH_SIZE x2 (gfx950 correction) +
+    WRITE_SIZE; profiles/*pmc_dominant_kernel.json), null if that file is absent or the shape differs.
+    `conv_launch` times the WHOLE conv (transforms + GEMM, cached weight panel) and states its rate in
+    direct-form-equivalent FLOP, for comparison with a non-Winograd implementation."""
     from neurips18_hierchical_image_manipulation_amd import ops
     from neurips18_hierchical_image_manipulation_amd._cabi import lib
-    M = K = N = 1024
+    M = K = 1024
+    N = ntiles
     a = torch.randn(16, M, K, device=device) * 0.02
     b = torch.randn(16, K, N, device=device)
     c = torch.empty(16, M, N, device=device)
@@ -68,7 +149,11 @@ def dominant_kernel_roofline(device):
     flops = 2.0 * 16 * M * K * N
     ach = flops / (ms * 1e-3) / 1e12
     # the whole conv launch, as the trainer runs it (Parameter weight: cached Winograd panel)
-    x = torch.randn(BS, 1024, 16, 32, device=device)
+    hw = ntiles * 4 // bs
+    h = 1
+    while h * h * 2 < hw:
+        h *= 2
+    x = torch.randn(bs, 1024, h, hw // h, device=device)
     w = torch.nn.Parameter(torch.randn(1024, 1024, 3, 3, device=device) * 0.02, requires_grad=False)
     bias = torch.zeros(1024, device=device)
     with torch.no_grad():
@@ -76,130 +161,139 @@ def dominant_kernel_roofline(device):
         for _ in range(3):
             conv()
         cms = _event_ms(conv, 20)
-    direct = 2.0 * 1024 * (BS * 16 * 32) * (1024 * 9)
-    traffic = None
-    pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_dominant_kernel.json')
-    if os.path.isfile(pmc):
-        with open(pmc) as f:
-            traffic = int(json.load(f)['traffic_bytes_corrected'])
-    return dict(bound='mfma',
-                kernel='gconv_fast_kernel<2,2,2,2,0,false> as the batched Winograd GEMM [16]x(1024x1024)x(1024x1024) '
-                       '(ResnetBlock conv3x3 1024->1024 @16x32, bs 8)',
+    direct = 2.0 * 1024 * (bs * hw) * (1024 * 9)
+    traffic = rocprof_ms = None
+    pmc = _profile_json('r02_pmc_dominant_kernel.json') or _profile_json('r01_pmc_dominant_kernel.json')
+    if pmc is not None and int(pmc.get('N', 1024)) == N:
+        traffic = int(pmc['traffic_bytes_corrected'])
+    kt = _profile_json('r02_gemm_bench_rocprof.json')
+    if kt is not None and int(kt.get('N', 1024)) == N:
+        rocprof_ms = kt.get('avg_launch_ms')
+    return dict(bound='mfma', source='microbench',
+                kernel='batched Winograd GEMM [16]x(1024x1024)x(1024x%d) on the fp32-MFMA conv kernel '
+                       '(ResnetBlock conv3x3 1024->1024, bs %d)' % (N, bs),
                 achieved=round(ach, 2), peak=PEAK_F32_MFMA, unit='TFLOP/s', frac=round(ach / PEAK_F32_MFMA, 4),
-                traffic=traffic, traffic_unit='bytes/launch (PMC, corrected)', algorithmic_bytes=3 * 16 * M * N * 4,
-                flop_per_launch=flops, avg_launch_ms=round(ms, 4),
+                traffic=traffic, traffic_unit='bytes/launch (PMC, corrected)', algorithmic_bytes=16 * 4 * (M * K + K * N + M * N),
+                flop_per_launch=flops, avg_launch_ms=round(ms, 4), avg_launch_ms_rocprof=rocprof_ms,
                 conv_launch=dict(ms=round(cms, 4), direct_form_gflop=round(direct / 1e9, 2),
                                  direct_form_equivalent_tflops=round(direct / (cms * 1e-3) / 1e12, 1),
                                  executed_tflops=round(flops / (cms * 1e-3) / 1e12, 1)))
 
 
-def g_forward_roofline(model, batch):
-    """The 'fused G-conv forward' the north star prices: whole GlobalGenerator forward at C2.  SURVEY 8(d) counts it in
-    direct-form FLOP (1.970 TFLOP per bs-8 batch); the 18 ResnetBlock convs run as Winograd (34.36 instead of 77.31 GFLOP
-    each) and the stem's 35 one-hot input channels are table lookups, i.e. 0.967 TFLOP are actually issued to the matrix
-    pipe.  Both rates are reported; the roofline fraction is the EXECUTED one."""
+def direct_conv_roofline(device, bs, cin, cout, k, stride, pad, h, w, what):
+    """Roofline of a direct-form MFMA conv launch (workloads whose dominant kernel is not the Winograd GEMM)."""
+    from neurips18_hierchical_image_manipulation_amd import ops
+    x = torch.randn(bs, cin, h, w, device=device)
+    wt = torch.nn.Parameter(torch.randn(cout, cin, k, k, device=device) * 0.02, requires_grad=False)
+    bias = torch.zeros(cout, device=device)
     with torch.no_grad():
-        model.encode_input(batch['label'], batch['inst'], batch['image'], None, mask_in=batch['mask_in'])
+        conv = lambda: ops.conv2d(x, wt, bias, stride, pad, 'zero', 'none')  # noqa: E731
+        for _ in range(3):
+            y = conv()
+        ms = _event_ms(conv, 20)
+    flops = 2.0 * y.numel() * cin * k * k
+    ach = flops / (ms * 1e-3) / 1e12
+    return dict(bound='mfma', source='microbench', kernel=what, achieved=round(ach, 2), peak=PEAK_F32_MFMA,
+                unit='TFLOP/s', frac=round(ach / PEAK_F32_MFMA, 4), traffic=None,
+                algorithmic_bytes=4 * (x.numel() + wt.numel() + y.numel()), flop_per_launch=flops,
+                avg_launch_ms=round(ms, 4))
+
+
+def g_forward_roofline(model, batch, wl):
+    """The 'fused G-conv forward' the north star prices: the whole generator forward.  SURVEY 8(d) counts it in
+    direct-form FLOP; the >= 512-channel 3x3 stride-1 convs run as Winograd (2.25x fewer multiplies) and the stem's
+    one-hot input channels are table lookups.  Both rates are reported; the roofline fraction is the EXECUTED one
+    (only computed for the C2 GlobalGenerator, whose layer table is fixed: 18 ResnetBlock convs + the 38->64 stem)."""
+    from neurips18_hierchical_image_manipulation_amd import ops
+    kw = dict(mask_in=batch['mask_in'])
+    if 'obj_mask' in batch:
+        kw['obj_mask'] = batch['obj_mask']
+    with torch.no_grad():
+        input_mask, _, _, _, cond_image = model.encode_input(batch['label'], batch['inst'], batch['image'], None, **kw)
         buf, _, _, mask = model._enc
-        fn = lambda: model.netG(buf, mask)  # noqa: E731
+        fn = lambda: model._generate(buf, input_mask, cond_image, mask)  # noqa: E731
         for _ in range(2):
             fn()
         ms = _event_ms(fn, 5)
-    direct = G_FWD_GFLOP_PER_IMG * BS / 1e3
-    from neurips18_hierchical_image_manipulation_amd import ops
-    wino = ops.set_winograd_min_channels(0)
-    ops.set_winograd_min_channels(wino)
-    executed = direct
-    if 0 < wino <= 1024:            # 18 ResnetBlock convs: 34.36 instead of 77.31 GFLOP each
-        executed -= 18 * (77.309 - 34.360) / 1e3
-    if ops._ONEHOT_ON:              # stem conv7x7 38->64: the 35 one-hot channels are LDS lookups, 3 dense ones stay
-        executed -= 2.0 * 64 * 35 * 49 * (BS * H * W) / 1e12
-    return dict(ms=round(ms, 3), tflops_direct_form_equivalent=round(direct / (ms * 1e-3), 2),
-                tflops_executed=round(executed / (ms * 1e-3), 2),
-                frac_of_f32_mfma_peak=round(executed / (ms * 1e-3) / PEAK_F32_MFMA, 4),
-                frac_direct_form_equivalent=round(direct / (ms * 1e-3) / PEAK_F32_MFMA, 4))
+    bs, H, W = wl['bs'], wl['H'], wl['W']
+    direct = wl['g_gflop'] * bs / 1e3
+    out = dict(ms=round(ms, 3), direct_form_tflop=round(direct, 4),
+               tflops_direct_form_equivalent=round(direct / (ms * 1e-3), 2),
+               frac_direct_form_equivalent=round(direct / (ms * 1e-3) / PEAK_F32_MFMA, 4))
+    if wl is WORKLOADS['c2']:
+        wino = ops.set_winograd_min_channels(0)
+        ops.set_winograd_min_channels(wino)
+        executed = direct
+        if 0 < wino <= 1024:            # 18 ResnetBlock convs: 34.36 instead of 77.31 GFLOP each
+            executed -= 18 * (77.309 - 34.360) / 1e3
+        if ops._ONEHOT_ON:              # stem conv7x7 38->64: the 35 one-hot channels are LDS lookups, 3 dense ones stay
+            executed -= 2.0 * 64 * 35 * 49 * (bs * H * W) / 1e12
+        out.update(tflops_executed=round(executed / (ms * 1e-3), 2),
+                   frac_of_f32_mfma_peak=round(executed / (ms * 1e-3) / PEAK_F32_MFMA, 4))
+    return out
 
 
-def cpu_baseline():
-    """The CPU oracle (validated bit-exact against the imported reference) timed on this box's host cores on a
-    bounded sample of the same workload: full training steps at 512x256 with batch 2 (not 8): one untimed warm-up
-    step (oneDNN primitive creation), then one timed step."""
+# --------------------------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle; test infrastructure, timed AFTER the GPU region, rank 0 at N = 1 only)
+# --------------------------------------------------------------------------------------------------------------------
+def _cpu_model_name():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def _time_oracle_steps(make_model, make_batch, step_fn, timed, budget_s):
+    om = make_model()
+    step_fn(om, make_batch(0))                      # warm-up (oneDNN primitive creation, allocator)
+    times = []
+    for s in range(timed):
+        b = make_batch(1 + s)
+        t0 = time.time()
+        step_fn(om, b)
+        times.append(time.time() - t0)
+        if sum(times) > budget_s:
+            break
+    return times
+
+
+def cpu_baseline(name, wl, timed=3, budget_s=75.0):
+    """The CPU oracle (validated bit-exact against the imported reference, tests/golden/make_golden.py) on this box's
+    host cores, the SAME workload at the SAME batch size: 1 untimed warm-up step, then up to `timed` full training steps
+    (stopped early once `budget_s` seconds of timed work are spent, so the default bench run stays within minutes).
+    For the default workload the reference's own CPU-runnable case C1 (BASELINE configs[0]: 256x128, bs 1) is timed
+    beside it."""
     from oracle import ref_cpu
     from neurips18_hierchical_image_manipulation_amd import synth
     cores = torch.get_num_threads()
-    bs = 2
-    om = ref_cpu.Mask2ImageModel(ref_cpu.Opt(**C2))
-    om.optimize_parameters(synth.make_batch(0, 0, bs, H, W))
-    b = synth.make_batch(1, 0, bs, H, W)
-    t0 = time.time()
-    om.optimize_parameters(b)
-    dt = time.time() - t0
-    return dict(value=round(bs / dt, 4), unit='images/s', cores=cores, kind='port',
-                sample='1 timed full training step after 1 warm-up step, 512x256, batch %d of the bs-8 workload, '
-                       'torch CPU fp32 oracle, %d threads: %.1f s' % (bs, cores, dt))
-
-
-C4 = dict(model='pix2pixHD_condImgColor', netG='global_twostream', ngf=64, ndf=64, n_downsample_global=4,
-          n_blocks_global=9, num_D=2, n_layers_D=3, label_nc=49, no_instance=True, no_imgCond=True,
-          which_encoder='ctx_label', use_skip=True, use_output_gate=True, mask_gan_input=True)
-
-
-def other_workload(args):
-    """Same protocol (resident synthetic batches, barrier + synchronize on both sides, max over ranks) for BASELINE
-    config 4 (two-stream colour generator, 256x256, bs 16 per GPU) and config 5's shape (box2mask, 256x256, bs 32)."""
-    from neurips18_hierchical_image_manipulation_amd import synth
-    from neurips18_hierchical_image_manipulation_amd.dist import init_process_group_from_env, attach_data_parallel
-    from neurips18_hierchical_image_manipulation_amd.models import create_model
-    rank, local, world = init_process_group_from_env()
-    device = torch.device('cuda', local)
-    torch.cuda.set_device(device)
-    if args.workload == 'c4':
-        bs, name = 16, 'C4: mask2image ADE20K-shaped 256x256, colour two-stream generator, label_nc 49, 2-scale PatchGAN + VGG19'
-        model = create_model(dict(C4, gpu_ids=[local], isTrain=True, checkpoints_dir='/tmp/him_bench', name='c4', batchSize=bs))
-        batches = [{k: v.to(device) for k, v in synth.make_batch(s, rank, bs, 256, 256, 49, True).items()} for s in range(4)]
-        step = lambda i: model.optimize_parameters(batches[i % 4])  # noqa: E731
+    bs, H, W = wl['bs'], wl['H'], wl['W']
+    if name == 'box2mask':
+        from oracle import ref_mask_cpu
+        times = _time_oracle_steps(lambda: ref_mask_cpu.TwoStreamAEMask(),
+                                   lambda s: synth.make_box2mask_batch(s, 0, bs, H, W), lambda m, b: m.step(b), timed, budget_s)
     else:
-        bs, name = 32, 'box2mask 256x256 (scripts/train_box2mask_city.sh flags): BatchNorm two-stream mask generator + 2-scale PatchGAN'
-        model = create_model(dict(model='AE_maskgen_twostream', gpu_ids=[local], isTrain=True, checkpoints_dir='/tmp/him_bench',
-                                  name='b2m'))
-        batches = [{k: (v.to(device) if k != 'cls' else v) for k, v in synth.make_box2mask_batch(s, rank, bs, 256, 256).items()}
-                   for s in range(4)]
-
-        def step(i):
-            b = batches[i % 4]
-            return model.forward(b['label'], None, b['mask_ctx_in'], None, b['mask_out'], b['mask_obj_inst'], b['cls'],
-                                 b['mask_in'])[0]
-    attach_data_parallel(model)
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    if rank == 0:
-        print(json.dumps({'metric': '%s train images/sec' % args.workload, 'value': round(bs * world * args.steps / dt, 3),
-                          'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-                          'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
-                          'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-                          'config': {'workload': name, 'global_batch': bs * world, 'per_gpu_batch': bs,
-                                     'parallelism': 'dp%d' % world}, 'roofline': None, 'cpu_baseline': None}), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        times = _time_oracle_steps(lambda: ref_cpu.Mask2ImageModel(ref_cpu.Opt(**wl['flags'])),
+                                   lambda s: synth.make_batch(s, 0, bs, H, W, wl['label_nc'], wl['color']),
+                                   lambda m, b: m.optimize_parameters(b), timed, budget_s)
+    sec = sum(times) / len(times)
+    out = dict(value=round(bs / sec, 4), unit='images/s', cores=cores, kind='port', cpu=_cpu_model_name(),
+               sample='%d timed full training step(s) after 1 warm-up step, %dx%d, batch %d (the bench workload itself), '
+                      'torch CPU fp32 oracle, %d threads: %s s/step' % (len(times), W, H, bs, cores,
+                                                                        '/'.join('%.1f' % t for t in times)))
+    if name == 'c2':
+        t1 = _time_oracle_steps(lambda: ref_cpu.Mask2ImageModel(ref_cpu.Opt(**C1)),
+                                lambda s: synth.make_batch(s, 0, 1, 128, 256), lambda m, b: m.optimize_parameters(b), 3, 30.0)
+        out['c1'] = dict(value=round(1.0 / (sum(t1) / len(t1)), 4), unit='images/s',
+                         sample='BASELINE configs[0] (256x128, bs 1, 1-scale D): %d timed step(s) after 1 warm-up: %s s/step'
+                                % (len(t1), '/'.join('%.2f' % t for t in t1)))
+    return out
 
 
+# --------------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -207,37 +301,50 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--workload', choices=['c2', 'c4', 'box2mask'], default='c2',
-                    help='c2 (default) = the BASELINE.json metric; c4 / box2mask = the other measured configurations '
-                         '(DESIGN.md), reported with the same protocol but without roofline / cpu_baseline legs')
+    ap.add_argument('--cpu-steps', type=int, default=3, help='timed oracle steps of the cpu_baseline leg')
+    ap.add_argument('--workload', choices=sorted(WORKLOADS), default='c2',
+                    help='c2 (default) = the BASELINE.json metric; c2local / c4 / box2mask = the other measured '
+                         'configurations (DESIGN.md), same protocol and JSON schema')
     args = ap.parse_args()
-    if args.workload != 'c2':
-        return other_workload(args)
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(spawn_ranks(args))
 
     from neurips18_hierchical_image_manipulation_amd import synth
-    from neurips18_hierchical_image_manipulation_amd.dist import init_process_group_from_env, attach_data_parallel
+    from neurips18_hierchical_image_manipulation_amd.dist import (init_process_group_from_env, attach_data_parallel,
+                                                                  replica_checksum_equal)
     from neurips18_hierchical_image_manipulation_amd.models import create_model
 
     rank, local, world = init_process_group_from_env()
-    if world != max(args.gpus, 1) and world > 1:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    backend = check_world(args, world)
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
+    wl = WORKLOADS[args.workload]
+    bs, H, W = wl['bs'], wl['H'], wl['W']
 
-    model = create_model(dict(C2, gpu_ids=[local], isTrain=True, checkpoints_dir='/tmp/him_bench', name='bench',
-                              batchSize=BS))
+    model = create_model(dict(wl['flags'], gpu_ids=[local], isTrain=True, checkpoints_dir='/tmp/him_bench',
+                              name='bench_' + args.workload, batchSize=bs))
+    # every rank draws the same Philox weights (and attach_data_parallel broadcasts rank 0's state anyway)
     model.netG.load_state_dict(synth.init_state_dict(model.netG.state_dict(), 1))
     model.netD.load_state_dict(synth.init_state_dict(model.netD.state_dict(), 2))
     attach_data_parallel(model)
 
-    # synthetic batches, resident in HBM before the timed region (4 distinct batches per rank, cycled)
-    batches = []
-    for s in range(4):
-        b = synth.make_batch(s, rank, BS, H, W)
-        batches.append({k: v.to(device) for k, v in b.items()})
+    # synthetic batches, resident in HBM before the timed region (4 distinct batches per rank, cycled; seeded by rank)
+    if args.workload == 'box2mask':
+        batches = [{k: (v.to(device) if k != 'cls' else v) for k, v in synth.make_box2mask_batch(s, rank, bs, H, W).items()}
+                   for s in range(4)]
 
-    def step(i):
-        return model.optimize_parameters(batches[i % len(batches)])
+        def step(i):
+            b = batches[i % 4]
+            names = ['G_Recon_comb', 'G_Recon_obj', 'KL_loss', 'loss_G_GAN', 'loss_D_GAN', 'loss_G_GAN_Feat']
+            out = model.forward(b['label'], None, b['mask_ctx_in'], None, b['mask_out'], b['mask_obj_inst'], b['cls'],
+                                b['mask_in'])[0]
+            return dict(zip(names, out))
+    else:
+        batches = [{k: v.to(device) for k, v in synth.make_batch(s, rank, bs, H, W, wl['label_nc'], wl['color']).items()}
+                   for s in range(4)]
+
+        def step(i):
+            return model.optimize_parameters(batches[i % 4])
 
     for i in range(args.warmup):
         step(i)
@@ -253,33 +360,47 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    identical = None
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        identical = replica_checksum_equal(model)      # averaged gradients + identical start => identical replicas
 
     if rank == 0:
         ms = dt / args.steps * 1e3
+
+        def _f(v):
+            return round(float(v.detach().reshape(-1)[0]) if torch.is_tensor(v) else float(v), 5)
         out = {
-            'metric': 'mask2image train images/sec at 512x256 bs=8',
-            'value': round(BS * world * args.steps / dt, 3), 'unit': 'images/s', 'n_gpus': world,
+            'metric': wl['metric'],
+            'value': round(bs * world * args.steps / dt, 3), 'unit': 'images/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'C2: mask2image Cityscapes-shaped 512x256, GlobalGenerator ngf64/4down/9blocks '
-                                   '(182.6M params) + 3-scale PatchGAN + VGG19 loss (synthetic weights), full '
-                                   'train step G+D Adam, fp32', 'global_batch': BS * world, 'per_gpu_batch': BS,
+            'config': {'workload': wl['desc'], 'global_batch': bs * world, 'per_gpu_batch': bs,
                        'parallelism': 'dp%d' % world},
-            'last_losses': {k: round(float(v.detach()), 5) for k, v in losses.items()},
+            'last_losses': {k: _f(v) for k, v in losses.items()},
         }
+        if world > 1:
+            out['ranks'] = {'world_size': dist.get_world_size(), 'backend': 'rccl' if backend == 'nccl' else backend,
+                            'replicas_identical': identical}
         if not args.no_roofline:
-            out['roofline'] = dominant_kernel_roofline(device)
-            out['g_forward'] = g_forward_roofline(model, batches[0])
+            if args.workload == 'box2mask':
+                out['roofline'] = direct_conv_roofline(device, bs, 256, 256, 3, 1, 1, 32, 32,
+                                                       'direct fp32-MFMA conv3x3 256->256 @32x32 bs 32 (ResnetBlock latent convs '
+                                                       'of MaskTwoStreamConvSwitch_NET)')
+            else:
+                ntiles = {'c2': 8 * 8 * 16, 'c2local': 8 * 4 * 8, 'c4': 16 * 8 * 8}[args.workload]
+                out['roofline'] = dominant_kernel_roofline(device, bs, ntiles)
+                out['g_forward'] = g_forward_roofline(model, batches[0], wl)
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline()
+            out['cpu_baseline'] = cpu_baseline(args.workload, wl, args.cpu_steps)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if identical is False:
+        raise SystemExit('bench.py: data-parallel replicas diverged')
 
 
 if __name__ == '__main__':

@@ -132,11 +132,57 @@ class GradReducer(object):
         self.armed = False
 
 
-def attach_data_parallel(model, bucket_bytes=64 << 20, force=False):
+def broadcast_replica_state(model, src=0):
+    """Every rank adopts rank ``src``'s parameters, Adam state and module buffers (BatchNorm running statistics,
+    spectral-norm ``u``).  The reference's ``nn.DataParallel`` re-broadcasts the module from GPU 0 on EVERY forward
+    (``models/models.py:21-22``); with one replica per process the broadcast is needed exactly once -- afterwards the
+    replicas receive identical averaged gradients and identical Adam updates.  Returns the number of floats sent."""
+    from .ops import invalidate_panels
+    sent = 0
+    for tag in ('G', 'D'):
+        opt = getattr(model, 'optimizer_' + tag, None)
+        if opt is None:
+            continue
+        for flat in (opt.arena.data, opt.exp_avg, opt.exp_avg_sq):
+            dist.broadcast(flat, src=src)
+            sent += flat.numel()
+        step = torch.tensor([opt.step_count], dtype=torch.int64, device=opt.arena.data.device)
+        dist.broadcast(step, src=src)
+        opt.step_count = int(step.item())
+        invalidate_panels(opt.arena.params)      # cached weight panels were built from the pre-broadcast values
+    for name in ('netG', 'netD'):
+        net = getattr(model, name, None)
+        if net is None:
+            continue
+        for buf in net.buffers():
+            if buf.is_floating_point():
+                dist.broadcast(buf, src=src)
+                sent += buf.numel()
+    return sent
+
+
+def replica_checksum_equal(model):
+    """True when every rank holds bit-identical parameters (sum of the raw int32 views of both arenas)."""
+    sums = []
+    for tag in ('G', 'D'):
+        opt = getattr(model, 'optimizer_' + tag, None)
+        if opt is not None:
+            sums.append(opt.arena.data.view(torch.int32).to(torch.int64).sum())
+    mine = torch.stack(sums)
+    lo, hi = mine.clone(), mine.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return bool(torch.equal(lo, hi))
+
+
+def attach_data_parallel(model, bucket_bytes=64 << 20, force=False, broadcast=True):
     """Give a mask2image / box2mask model per-network reducers (no-op for world size 1 unless ``force``).
+    Rank 0's parameters / Adam state / buffers are broadcast first (see ``broadcast_replica_state``).
     BatchNorm layers keep per-rank batch statistics (the reference's DataParallel behaviour); only gradients are averaged."""
     if not dist.is_initialized() or (dist.get_world_size() <= 1 and not force):
         return model
+    if broadcast and dist.get_world_size() > 1:
+        broadcast_replica_state(model)
     for tag in ('G', 'D'):
         opt = getattr(model, 'optimizer_' + tag, None)   # box2mask trainer: optimizer_G is its ``optimizer``
         if opt is None:

@@ -74,7 +74,11 @@ class BaseModel(torch.nn.Module):
             if network_label == 'G':
                 raise RuntimeError('Generator must exist!')
             return
-        loaded = torch.load(path, map_location='cpu')
+        self._load_with_fallback(network, torch.load(path, map_location='cpu'), network_label)
+
+    @staticmethod
+    def _load_with_fallback(network, loaded, network_label):
+        """strict -> the checkpoint's subset of our keys -> shape-matched merge (reference models/base_model.py:76-110)."""
         try:
             network.load_state_dict(loaded)
             return
@@ -107,7 +111,7 @@ class BaseModel(torch.nn.Module):
             return
         ck = torch.load(path, map_location='cpu')
         for k, v in network_dict.items():
-            v.load_state_dict(ck['network'][k])
+            self._load_with_fallback(v, ck['network'][k], '%s.%s' % (network_label, k))
         if optimizer is not None:
             optimizer.load_state_dict(ck['optimizer'])
 

@@ -13,8 +13,6 @@ def create_model(opt, data_size=None):
     elif opt.model == 'pix2pixHD_condImgColor':
         from .pix2pixHD_condImgColor_model import Pix2PixHDModel_condImgColor
         model = Pix2PixHDModel_condImgColor(opt)
-    elif opt.model == 'AE_maskgen_twostream':
-        raise NotImplementedError('box2mask (AE_maskgen_twostream) is outside this build\'s hot path (SURVEY 8f.2)')
     else:
         raise NotImplementedError('the model is not implemented')
     if getattr(opt, 'verbose', False):

@@ -96,7 +96,7 @@ class Pix2PixHDModel_condImg(BaseModel):
                 netD_input_nc = 3
             from .Discriminator_NET import MultiscaleDiscriminator
             self.netD = MultiscaleDiscriminator(netD_input_nc, opt.ndf, opt.n_layers_D, opt.norm, opt.no_lsgan,
-                                                opt.num_D, not opt.no_ganFeat_loss or True)
+                                                opt.num_D, True)   # intermediate features always returned
             self.netD.to(self.device)
 
         if not self.isTrain or opt.continue_train or opt.load_pretrain:
@@ -123,9 +123,15 @@ class Pix2PixHDModel_condImg(BaseModel):
                 self.criterionVGG.to(self.device)
             self.loss_names = ['G_GAN', 'G_GAN_Feat', 'G_VGG', 'D_real', 'D_fake']
             if opt.niter_fix_global > 0:
-                raise NotImplementedError('niter_fix_global > 0 (per-parameter lr groups) is not supported by the '
-                                          'flat-arena Adam')
-            self.optimizer_G = FusedAdam(self.netG.parameters(), lr=opt.lr, betas=(opt.beta1, 0.999))
+                # only the local enhancer trains at first (reference :122-130): one group per parameter, lr 0 elsewhere
+                if getattr(opt, 'verbose', False):
+                    print('------------- Only training the local enhancer network (for %d epochs) ------------'
+                          % opt.niter_fix_global)
+                params = [{'params': [value], 'lr': opt.lr if key.startswith('model' + str(opt.n_local_enhancers)) else 0.0}
+                          for key, value in self.netG.named_parameters()]
+            else:
+                params = list(self.netG.parameters())
+            self.optimizer_G = FusedAdam(params, lr=opt.lr, betas=(opt.beta1, 0.999))
             self.optimizer_D = FusedAdam(self.netD.parameters(), lr=opt.lr, betas=(opt.beta1, 0.999))
             self.reducer_G = self.reducer_D = None
             # gradient routing of the shared fake-image discriminator pass (see forward)
@@ -185,6 +191,7 @@ class Pix2PixHDModel_condImg(BaseModel):
         main = torch.cuda.current_stream(self.device)
         side = ops._side_stream(self.device)
         side.wait_stream(main)
+        self._wait_d_update(side)
         out = {'stream': side, 'y_vgg': None}
         with torch.cuda.stream(side):
             out['pred_real'] = self.discriminate(netD_cond, real_image, mask_cond, False)
@@ -224,6 +231,9 @@ class Pix2PixHDModel_condImg(BaseModel):
         fake_image = self._generate(buf, input_mask, cond_image, mask_in)
         if ahead is not None:
             torch.cuda.current_stream(self.device).wait_stream(ahead['stream'])
+        if self.isTrain:
+            self._wait_d_update()          # the previous step's D exchange + Adam (own stream) end before D is read here
+            self._d_update_pending = False
 
         # Fake detection and loss / real detection and loss / GAN loss (:218-233).  The reference runs the discriminator
         # on the fake image twice -- once detached (loss_D_fake) and once attached (loss_G_GAN + feature matching) --
@@ -392,13 +402,40 @@ class Pix2PixHDModel_condImg(BaseModel):
         main.wait_stream(opt_stream)
         if gan:
             if self.reducer_D is not None:
-                self.reducer_D.finish()
-            self.optimizer_D.step()
+                # D's exchange (34 MB over xGMI) + Adam step go to a stream of their own and are NOT waited for here:
+                # D's parameters are first needed by the next step's discriminator passes, so the exchange hides under the
+                # next encode_input + generator forward (forward() makes the consumers wait, see _wait_d_update)
+                d_stream = ops._d_opt_stream(self.device)
+                d_stream.wait_stream(main)
+                with torch.cuda.stream(d_stream):
+                    self.reducer_D.finish()
+                    self.optimizer_D.step()
+                self._d_update_pending = True
+            else:
+                self.optimizer_D.step()
         self.generated = generated
-        return loss_dict
+        # both graphs have been consumed: drop them now (not at the next forward), so the previous step's G+D+VGG
+        # activations are not resident while the next forward allocates its own
+        self.loss_G = self.loss_D = None
+        self._fake_gate = None
+        return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in loss_dict.items()}
+
+    def _wait_d_update(self, stream=None):
+        """Make ``stream`` (default: the current one) wait for a discriminator update still running on its own stream."""
+        if getattr(self, '_d_update_pending', False):
+            (stream or torch.cuda.current_stream(self.device)).wait_stream(ops._d_opt_stream(self.device))
+
+    def sync(self):
+        """Join every helper stream into the current one (before parameters are read from outside the step)."""
+        cur = torch.cuda.current_stream(self.device)
+        ops.join_side_stream(self.device)
+        cur.wait_stream(ops._opt_stream(self.device))
+        self._wait_d_update(cur)
+        self._d_update_pending = False
 
     # ------------------------------------------------------------------------------------------
     def save(self, which_epoch):
+        self.sync()
         self.save_network(self.netG, 'G', which_epoch, self.gpu_ids)
         self.save_network(self.netD, 'D', which_epoch, self.gpu_ids)
 

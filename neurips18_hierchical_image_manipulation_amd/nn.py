@@ -90,6 +90,14 @@ class BatchNorm2d(nn.Module):
         self.register_buffer('running_var', torch.ones(ch))
         self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
 
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        # checkpoints written by torch < 0.4.1 (the reference's era) carry no ``num_batches_tracked``: keep the counter
+        key = prefix + 'num_batches_tracked'
+        if key not in state_dict:
+            state_dict = dict(state_dict)
+            state_dict[key] = self.num_batches_tracked.detach().clone()
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+
     def apply_to(self, x, act='none', slope=0.0, residual=None):
         if self.training:
             self.num_batches_tracked += 1

@@ -75,6 +75,18 @@ def _opt_stream(device):
     return s
 
 
+_DOPT = {}
+
+
+def _d_opt_stream(device):
+    """Stream of the discriminator's gradient exchange + optimizer step in data-parallel runs (hidden under the NEXT
+    step's input encoding and generator forward)."""
+    s = _DOPT.get(device)
+    if s is None:
+        s = _DOPT[device] = torch.cuda.Stream(device=device)
+    return s
+
+
 def join_side_stream(device=None):
     for dev, s in _SIDE.items():
         if device is None or dev == device:
@@ -188,7 +200,13 @@ def _panel(w, d, kind, is_deconv):
     cache = w.__dict__.get('_him_panels')
     if cache is None:
         cache = w.__dict__['_him_panels'] = {}
-    key = (kind, d.stride)
+    # every descriptor field the panel LAYOUT can depend on (include/him.h "Weight panels": Winograd eligibility needs
+    # pad 1 + planes >= 2x2 + an unchanged plane size for the data gradient; tiny heads switch on the output size)
+    if is_deconv:
+        key = (kind, d.stride, d.pad, d.out_pad)
+    else:
+        key = (kind, d.stride, d.pad, d.pad_mode, d.H >= 2 and d.W >= 2, d.OH == d.H and d.OW == d.W,
+               d.B * d.OH * d.OW < 131072)
     e = cache.get(key)
     if e is None:
         e = cache[key] = _Panel()

@@ -58,9 +58,23 @@ class FusedAdam(object):
     Numerics follow torch's single-tensor Adam: lerp first moment, sqrt(v)/sqrt(bc2)+eps, lr/bc1."""
 
     def __init__(self, params, lr=2e-4, betas=(0.5, 0.999), eps=1e-8, arena=None):
+        """``params``: an iterable of Parameters, or torch-style groups ``[{'params': [...], 'lr': ...}, ...]`` (the
+        reference freezes the global generator that way, ``models/pix2pixHD_condImg_model.py:122-130``: one group per
+        parameter with lr 0 outside the local enhancer).  All groups share ONE arena in the order given; ``step`` runs
+        one kernel per maximal contiguous run of parameters with equal hyper-parameters (one launch in the common case)."""
         params = list(params)
-        self.arena = arena if arena is not None else FlatArena(params)
-        self.param_groups = [dict(params=self.arena.params, lr=lr, betas=tuple(betas), eps=eps)]
+        if params and isinstance(params[0], dict):
+            groups = [dict(g, params=list(g['params'])) for g in params]
+        else:
+            groups = [dict(params=params)]
+        flat = [p for g in groups for p in g['params']]
+        self.arena = arena if arena is not None else FlatArena(flat)
+        if [id(p) for p in self.arena.params] != [id(p) for p in flat]:
+            raise ValueError('the arena holds a different parameter list than the optimizer was given')
+        self.param_groups = []
+        for g in groups:
+            self.param_groups.append(dict(params=g['params'], lr=g.get('lr', lr), betas=tuple(g.get('betas', betas)),
+                                          eps=g.get('eps', eps)))
         self.exp_avg = torch.zeros_like(self.arena.data)
         self.exp_avg_sq = torch.zeros_like(self.arena.data)
         self.step_count = 0
@@ -68,15 +82,32 @@ class FusedAdam(object):
     def zero_grad(self, set_to_none=False):
         self.arena.zero_grad()
 
+    def _runs(self):
+        """[(start, end, lr, b1, b2, eps)] over the arena: contiguous parameters with equal hyper-parameters merged."""
+        a = self.arena
+        runs, i = [], 0
+        for g in self.param_groups:
+            n = len(g['params'])
+            if n == 0:
+                continue
+            start = a.offsets[i]
+            end = a.offsets[i + n] if i + n < len(a.offsets) else a.total
+            hp = (float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']))
+            if runs and runs[-1][2:] == hp and runs[-1][1] == start:
+                runs[-1] = (runs[-1][0], end) + hp
+            else:
+                runs.append((start, end) + hp)
+            i += n
+        return runs
+
     def step(self):
-        g = self.param_groups[0]
         self.step_count += 1
         a = self.arena
         from .ops import join_side_stream
         join_side_stream(a.grad.device)        # wait for the side-stream weight gradients
-        lib.him_adam_step(a.data.data_ptr(), a.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
-                          a.total, float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
-                          self.step_count, _stream())
+        for (s, e, lr, b1, b2, eps) in self._runs():
+            lib.him_adam_step(a.data.data_ptr() + 4 * s, a.grad.data_ptr() + 4 * s, self.exp_avg.data_ptr() + 4 * s,
+                              self.exp_avg_sq.data_ptr() + 4 * s, e - s, lr, b1, b2, eps, self.step_count, _stream())
         from .ops import refresh_panels
         refresh_panels(a.params)               # regrouped weight panels of the conv kernels follow the update
 
@@ -91,10 +122,57 @@ class FusedAdam(object):
         self.step_count = int(step)
 
     def state_dict(self):
-        return dict(step=self.step_count, exp_avg=self.exp_avg.cpu(), exp_avg_sq=self.exp_avg_sq.cpu(),
-                    param_groups=[{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups])
+        """``torch.optim.Adam.state_dict()`` layout (what the reference's ``save_network_dict`` pickles,
+        ``models/base_model.py:52-66``): per-parameter ``step / exp_avg / exp_avg_sq`` keyed by the parameter's index,
+        plus ``param_groups`` with index lists -- loadable by a ``torch.optim.Adam`` over the same parameter list."""
+        a = self.arena
+        state = {}
+        if self.step_count > 0:
+            for i, (p, o) in enumerate(zip(a.params, a.offsets)):
+                n = p.numel()
+                state[i] = dict(step=torch.tensor(float(self.step_count)),
+                                exp_avg=self.exp_avg[o:o + n].view(p.shape).cpu().clone(),
+                                exp_avg_sq=self.exp_avg_sq[o:o + n].view(p.shape).cpu().clone())
+        groups, i = [], 0
+        for g in self.param_groups:
+            d = {k: v for k, v in g.items() if k != 'params'}
+            for k, v in (('weight_decay', 0), ('amsgrad', False), ('maximize', False), ('foreach', None),
+                         ('capturable', False), ('differentiable', False), ('fused', None)):
+                d.setdefault(k, v)
+            d['params'] = list(range(i, i + len(g['params'])))
+            i += len(g['params'])
+            groups.append(d)
+        return dict(state=state, param_groups=groups)
 
     def load_state_dict(self, sd):
+        """Accepts a ``torch.optim.Adam`` state dict (any torch era: ``step`` as int or tensor) or this class's round-1
+        flat-arena format (``step / exp_avg / exp_avg_sq`` over the padded arena)."""
+        if 'state' in sd:
+            a = self.arena
+            st = sd['state']
+            if len(st) == 0:
+                self.exp_avg.zero_()
+                self.exp_avg_sq.zero_()
+                self.step_count = 0
+            else:
+                keys = sorted(st.keys(), key=lambda k: int(k))
+                if len(keys) != len(a.params):
+                    raise ValueError('optimizer state holds %d parameters, the arena %d' % (len(keys), len(a.params)))
+                for k, p in zip(keys, a.params):
+                    if tuple(st[k]['exp_avg'].shape) != tuple(p.shape):
+                        raise ValueError('optimizer state %s: shape %s vs parameter %s'
+                                         % (k, tuple(st[k]['exp_avg'].shape), tuple(p.shape)))
+                steps = set(int(float(st[k]['step'])) for k in keys)
+                if len(steps) != 1:
+                    raise ValueError('per-parameter step counts differ (%s): one fused step count only' % sorted(steps))
+                self.load_moments([st[k]['exp_avg'] for k in keys], [st[k]['exp_avg_sq'] for k in keys], steps.pop())
+            for g, s in zip(self.param_groups, sd['param_groups']):
+                for k in ('lr', 'betas', 'eps'):
+                    if k in s:
+                        g[k] = tuple(s[k]) if k == 'betas' else s[k]
+                if s.get('weight_decay', 0) or s.get('amsgrad', False):
+                    raise NotImplementedError('weight_decay / amsgrad are not used by the reference and not supported')
+            return
         self.step_count = int(sd['step'])
         self.exp_avg.copy_(sd['exp_avg'])
         self.exp_avg_sq.copy_(sd['exp_avg_sq'])

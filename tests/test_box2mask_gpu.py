@@ -95,13 +95,13 @@ def test_box2mask_generator_state_dict_roundtrip(tmp_path):
 B2M_NAMES = ['G_Recon_comb', 'G_Recon_obj', 'KL_loss', 'loss_G_GAN', 'loss_D_GAN', 'loss_G_GAN_Feat']
 
 
-def _trainers():
+def _trainers(**override):
     import json
     from neurips18_hierchical_image_manipulation_amd import synth
     from neurips18_hierchical_image_manipulation_amd.models import create_model
     from oracle import ref_mask_cpu
     g = load_golden('box2mask_traj')
-    fl = json.loads(str(g['flags']))
+    fl = dict(json.loads(str(g['flags'])), **override)
     model = create_model(dict(fl, model='AE_maskgen_twostream', gpu_ids=[0], isTrain=True, checkpoints_dir='/tmp/him_b2m',
                               name='t'))
     ora = ref_mask_cpu.TwoStreamAEMask(**fl)
@@ -155,3 +155,48 @@ def test_box2mask_teacher_forced_steps_vs_oracle():
         worst = max(worst, max(abs(a - r) / max(abs(r), 1e-12) for a, r in zip(got, ref)))
     print('box2mask teacher-forced worst relative loss error: %.2e' % worst)
     assert worst < 2e-5, worst
+
+
+def _adopt_b2m(model, ora):
+    model.netG.load_state_dict(ora.netG.state_dict())
+    model.netD.load_state_dict(ora.netD.state_dict())
+    for hip_opt, ref_opt, net in ((model.optimizer, ora.optimizer, ora.netG), (model.optimizer_D, ora.optimizer_D, ora.netD)):
+        if ref_opt.state:
+            st = [ref_opt.state[p] for p in net.parameters()]
+            hip_opt.load_moments([x['exp_avg'] for x in st], [x['exp_avg_sq'] for x in st], int(st[0]['step']))
+
+
+def test_box2mask_config5_full_size_teacher_forced_step():
+    """BASELINE config 5's per-GPU shape: 256x256, bs 32, ndf 64 (scripts/train_box2mask_city.sh), two training steps from
+    the oracle's state (the second one exercises non-zero Adam moments and updated BatchNorm running statistics): the
+    six losses, and what the step WROTE -- generator / discriminator parameters and BatchNorm running statistics --
+    against the oracle's, before the next adoption."""
+    from neurips18_hierchical_image_manipulation_amd import synth
+    g, model, ora = _trainers(ndf=64)
+    for s in range(2):
+        _adopt_b2m(model, ora)
+        before = {k: v.detach().clone() for net in (ora.netG, ora.netD) for k, v in net.named_parameters()}
+        b = synth.make_box2mask_batch(s, 0, 32, 256, 256, 35)
+        got = _hip_step(model, b)
+        ref = ora.step(b)
+        ref = [ref[k] for k in B2M_NAMES]
+        worst = max(abs(a - r) / max(abs(r), 1e-12) for a, r in zip(got, ref))
+        assert worst < 2e-5, (s, got, ref)
+        torch.cuda.synchronize()
+        for hnet, onet in ((model.netG, ora.netG), (model.netD, ora.netD)):
+            names = set(hnet.state_dict().keys())
+            num = den = 0.0
+            for (k, hp), op in zip(hnet.named_parameters(), onet.parameters()):
+                if _dead_bias(k, names):
+                    continue
+                d_h = hp.detach().double().cpu() - before[k].double()
+                d_o = op.detach().double() - before[k].double()
+                num += float((d_h - d_o).pow(2).sum())
+                den += float(d_o.pow(2).sum())
+            rel = (num / max(den, 1e-300)) ** 0.5
+            assert rel < 2e-2, 'step %d: parameter update relative L2 error %.3e' % (s, rel)
+            hs, os_ = hnet.state_dict(), onet.state_dict()
+            for k in hs:
+                if k.endswith('running_mean') or k.endswith('running_var'):
+                    assert_close(k, hs[k], os_[k], rtol=1e-4)
+        print('box2mask 256x256 bs32 step %d: worst relative loss error %.2e' % (s, worst))

@@ -164,3 +164,98 @@ def test_gloo_world2_bucketed_reducer(tmp_path):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-3000:]
     assert 'RANK0 OK' in r.stdout and 'RANK1 OK' in r.stdout
+
+
+def test_fused_adam_state_dict_is_torch_adam_format():
+    """Checkpoint interop of the optimizer (reference models/base_model.py:52-66 pickles torch.optim.Adam.state_dict()):
+    a torch Adam state loads into FusedAdam, and FusedAdam's state loads into a torch Adam, moments intact."""
+    from neurips18_hierchical_image_manipulation_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    shapes = [(4, 3, 3, 3), (4,), (70,), (2, 4, 1, 1)]
+    tp = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    ta = torch.optim.Adam(tp, lr=1e-3, betas=(0.5, 0.999))
+    for _ in range(2):
+        for p in tp:
+            p.grad = torch.randn_like(p)
+        ta.step()
+    hp = [torch.nn.Parameter(p.detach().clone()) for p in tp]
+    fa = FusedAdam(hp, lr=2e-4, betas=(0.9, 0.99))
+    fa.load_state_dict(ta.state_dict())
+    assert fa.step_count == 2 and fa.param_groups[0]['lr'] == 1e-3 and fa.param_groups[0]['betas'] == (0.5, 0.999)
+    for p, o, t in zip(hp, fa.arena.offsets, tp):
+        n = p.numel()
+        assert torch.equal(fa.exp_avg[o:o + n].view(p.shape), ta.state[t]['exp_avg'])
+        assert torch.equal(fa.exp_avg_sq[o:o + n].view(p.shape), ta.state[t]['exp_avg_sq'])
+    sd = fa.state_dict()
+    assert set(sd.keys()) == {'state', 'param_groups'} and sd['param_groups'][0]['params'] == [0, 1, 2, 3]
+    tb = torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in tp], lr=5.0)
+    tb.load_state_dict(sd)                                   # torch validates group sizes / keys
+    for q, t in zip(tb.param_groups[0]['params'], tp):
+        assert torch.equal(tb.state[q]['exp_avg'], ta.state[t]['exp_avg'])
+        assert float(tb.state[q]['step']) == 2.0
+    assert tb.param_groups[0]['lr'] == 1e-3
+    # legacy torch (0.3.1-era) state: python-int steps
+    legacy = ta.state_dict()
+    for st in legacy['state'].values():
+        st['step'] = 2
+    fa2 = FusedAdam([torch.nn.Parameter(p.detach().clone()) for p in tp])
+    fa2.load_state_dict(legacy)
+    assert fa2.step_count == 2
+    # a fresh optimizer round-trips an empty state
+    fa3 = FusedAdam([torch.nn.Parameter(p.detach().clone()) for p in tp])
+    fa3.load_state_dict(FusedAdam([torch.nn.Parameter(p.detach().clone()) for p in tp]).state_dict())
+    assert fa3.step_count == 0
+
+
+def test_fused_adam_param_groups_merge_into_contiguous_runs():
+    from neurips18_hierchical_image_manipulation_amd.optim import FusedAdam
+    ps = [torch.nn.Parameter(torch.zeros(n)) for n in (5, 64, 130, 7, 9)]
+    groups = [{'params': [p], 'lr': lr} for p, lr in zip(ps, (0.0, 0.0, 2e-4, 2e-4, 0.0))]
+    fa = FusedAdam(groups, lr=2e-4, betas=(0.5, 0.999))
+    runs = fa._runs()
+    assert [(r[0], r[1], r[2]) for r in runs] == [(0, 128, 0.0), (128, 128 + 192 + 64, 2e-4), (384, fa.arena.total, 0.0)]
+    for g in fa.param_groups:       # update_learning_rate writes every group (reference :320-323)
+        g['lr'] = 1e-4
+    assert len(fa._runs()) == 1 and fa._runs()[0][:3] == (0, fa.arena.total, 1e-4)
+
+
+def test_batchnorm_loads_checkpoints_without_num_batches_tracked():
+    """torch < 0.4.1 (the reference's era) wrote no num_batches_tracked; strict loading must still work."""
+    from neurips18_hierchical_image_manipulation_amd import nn as hn
+    bn = hn.BatchNorm2d(6)
+    old = {'weight': torch.full((6,), 2.0), 'bias': torch.ones(6), 'running_mean': torch.ones(6) * 3,
+           'running_var': torch.ones(6) * 4}
+    bn.load_state_dict(old)
+    assert float(bn.running_var[0]) == 4.0 and int(bn.num_batches_tracked) == 0
+    seq = torch.nn.Sequential(hn.Conv2d(3, 6, 3), hn.BatchNorm2d(6))
+    sd = {k: v for k, v in seq.state_dict().items() if not k.endswith('num_batches_tracked')}
+    seq.load_state_dict(sd)
+
+
+def test_legacy_format_checkpoint_files_load(tmp_path):
+    """<epoch>_net_G.pth written by torch.save in the legacy (pre-zipfile, torch <= 1.5) container format and holding
+    CUDA-less plain tensors -- what the reference's published checkpoints are -- goes through load_network's fallbacks."""
+    from types import SimpleNamespace
+    from neurips18_hierchical_image_manipulation_amd.models.base_model import BaseModel
+    from neurips18_hierchical_image_manipulation_amd.models.Pix2Pix_NET import GlobalGenerator
+    net = GlobalGenerator(38, 3, 4, 2, 1)
+    want = {k: torch.randn_like(v) for k, v in net.state_dict().items()}
+    bm = BaseModel(SimpleNamespace(gpu_ids=[], isTrain=False, checkpoints_dir=str(tmp_path), name='ck'))
+    os.makedirs(bm.save_dir, exist_ok=True)
+    torch.save(want, bm._path('G', 'latest'), _use_new_zipfile_serialization=False)
+    bm.load_network(net, 'G', 'latest')
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, want[k])
+    # excessive layers in the file -> subset load; fewer layers -> shape-matched merge
+    extra = dict(want, **{'model.99.weight': torch.zeros(1)})
+    torch.save(extra, bm._path('G', 'more'), _use_new_zipfile_serialization=False)
+    bm.load_network(net, 'G', 'more')
+    fewer = {k: v for k, v in want.items() if not k.startswith('model.1.')}
+    net2 = GlobalGenerator(38, 3, 4, 2, 1)
+    keep = net2.state_dict()['model.1.weight'].clone()
+    torch.save(fewer, bm._path('G', 'less'))
+    bm.load_network(net2, 'G', 'less')
+    assert torch.equal(net2.state_dict()['model.1.weight'], keep)
+    assert torch.equal(net2.state_dict()['model.4.weight'], want['model.4.weight'])
+    with pytest.raises(RuntimeError, match='Generator must exist'):
+        bm.load_network(net, 'G', 'absent')
