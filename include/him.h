@@ -129,6 +129,13 @@ int him_masked_nll_bwd(const float* label, const float* mask, const float* g, co
                        int C, int hw, void* stream);
 int him_bce_mean_fwd(const float* p, const float* t, size_t n, float* out, void* ws, size_t ws_bytes, void* stream);
 int him_bce_mean_bwd(const float* p, const float* t, size_t n, const float* g, float* dp, void* stream);
+/* The ADE recipe of box2mask (scripts/train_box2mask_ade.sh: --add_dilated_layers --lr_control):
+ *   space_to_batch: y[(b*d+py)*d+px][c][i][j] = x[b][c][i*d+py][j*d+px] (inverse != 0: the reverse copy).  The dilated
+ *     bias-free conv3x3 of DilatedResnetBlock (models/layer_util.py:254-293, dilation = padding = d) is the plain pad-1
+ *     conv on the d*d phase images, so it runs on the same MFMA / Winograd kernels as every other 3x3 layer.
+ *   lr_control: models/Discriminator_NET.py:190-211 on device scalars, out2 = {g_lr, d_lr} (no host read-back). */
+int him_space_to_batch(const float* x, float* y, int B, int C, int H, int W, int d, int inverse, void* stream);
+int him_lr_control(const float* loss_d_real, const float* loss_d_fake, float margin, float* out2, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * One-hot stems: conv over [one-hot(label) | dense channels] evaluated from the label ids.  `label` is the

@@ -74,6 +74,8 @@ _SIGS = {
     'him_masked_nll_fwd': (c_int, [P, P, P, P, c_int, c_int, c_int, P, c_size_t, P]),
     'him_masked_nll_bwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
     'him_bce_mean_fwd': (c_int, [P, P, c_size_t, P, P, c_size_t, P]),
+    'him_space_to_batch': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    'him_lr_control': (c_int, [P, P, c_float, P, P]),
     'him_bce_mean_bwd': (c_int, [P, P, c_size_t, P, P, P]),
     'him_instnorm_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_float, c_int, c_float, P]),
     'him_instnorm_bwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_float, P]),

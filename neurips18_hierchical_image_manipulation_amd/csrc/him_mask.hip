@@ -427,6 +427,41 @@ __global__ void bce_bwd_kernel(const float* __restrict__ p, const float* __restr
 }  // namespace him
 
 using namespace him;
+
+// ---- dilated conv3x3 as d*d dense convs: phase split ("space to batch") --------------------------------------------
+// y[(b*d + py)*d + px][c][i][j] = x[b][c][i*d + py][j*d + px]   (inverse: the same map read the other way).
+// A stride-1 conv with dilation d and zero padding d on x equals the plain pad-1 conv on every phase image (taps of
+// one output only ever meet inputs of the same phase; the phase image's index -1 / H/d is the original's zero padding).
+// Threads run along the ORIGINAL row (coalesced on the full-resolution side; the phase side is d-strided within rows of
+// <= 32 floats at the shapes of the path).
+__global__ __launch_bounds__(256) void space_batch_kernel(const float* __restrict__ src, float* __restrict__ dst, int B,
+                                                          int C, int H, int W, int d, int inverse) {
+  const long long n = (long long)B * C * H * W;
+  const int Hd = H / d, Wd = W / d;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W);
+    long long r = i / W;
+    const int y = (int)(r % H);
+    r /= H;
+    const int c = (int)(r % C), b = (int)(r / C);
+    const int py = y % d, px = x % d;
+    const long long j = ((((long long)(b * d + py) * d + px) * C + c) * Hd + y / d) * Wd + x / d;
+    if (inverse) dst[i] = src[j];
+    else dst[j] = src[i];
+  }
+}
+
+// lr_control (reference models/Discriminator_NET.py:190-211) evaluated on the device: out2 = {g_lr, d_lr} in {0, 1}
+__global__ void lr_control_kernel(const float* __restrict__ d_real, const float* __restrict__ d_fake, float margin,
+                                  float* __restrict__ out2) {
+  const float r = d_real[0], f = d_fake[0];
+  bool upd_d = !(r < margin || f < margin);
+  bool upd_g = !(r > 1.f - margin || f > 1.f - margin);
+  if (!(upd_d || upd_g)) upd_d = upd_g = true;
+  out2[0] = upd_g ? 1.f : 0.f;
+  out2[1] = upd_d ? 1.f : 0.f;
+}
+
 #define ST ((hipStream_t)stream)
 
 extern "C" {
@@ -528,6 +563,17 @@ int him_bce_mean_bwd(const float* p, const float* t, size_t n, const float* g, f
   if (!n) return HIM_OK;
   hipLaunchKernelGGL(bce_bwd_kernel, gs_grid(n), dim3(256), 0, ST, p, t, g, dp, n, (float)(1.0 / (double)n));
   return check_launch("bce_mean_bwd");
+}
+
+int him_space_to_batch(const float* x, float* y, int B, int C, int H, int W, int d, int inverse, void* stream) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || d < 1) return fail(HIM_E_INVALID, "space_to_batch: bad shape");
+  if (H % d || W % d) return fail(HIM_E_UNSUPPORTED, "space_to_batch: %dx%d not divisible by dilation %d", H, W, d);
+  hipLaunchKernelGGL(space_batch_kernel, gs_grid((size_t)B * C * H * W), dim3(256), 0, ST, x, y, B, C, H, W, d, inverse);
+  return check_launch("space_to_batch");
+}
+int him_lr_control(const float* loss_d_real, const float* loss_d_fake, float margin, float* out2, void* stream) {
+  hipLaunchKernelGGL(lr_control_kernel, dim3(1), dim3(1), 0, ST, loss_d_real, loss_d_fake, margin, out2);
+  return check_launch("lr_control");
 }
 
 }  // extern "C"

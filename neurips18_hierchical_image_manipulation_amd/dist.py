@@ -76,7 +76,8 @@ class GradReducer(object):
 
     def attach(self, params):
         """Bind parameters (carrying ``_him_arena_range``) so the wgrad kernels' completion triggers buckets."""
-        for p in params:
+        self.params = list(params)
+        for p in self.params:
             p._him_reducer = self
 
     def begin(self, contributions=1):
@@ -84,7 +85,15 @@ class GradReducer(object):
         discriminator is run twice with live weights inside loss_D)."""
         if not self.active:
             return
-        self.pending = [b[2] * contributions for b in self.buckets]
+        # parameters flagged ``_him_dead_grad`` (conv biases in front of a mean-subtracting norm, nn.run_layers) never
+        # receive a weight-gradient launch: they must not hold their bucket back
+        live = [0] * len(self.buckets)
+        for p in getattr(self, 'params', ()):
+            if not getattr(p, '_him_dead_grad', False):
+                live[self.range_to_bucket[tuple(p._him_arena_range)]] += 1
+        if not getattr(self, 'params', None):
+            live = [b[2] for b in self.buckets]
+        self.pending = [n * contributions for n in live]
         self.launched = [False] * len(self.buckets)
         self.works = []
         self.armed = True

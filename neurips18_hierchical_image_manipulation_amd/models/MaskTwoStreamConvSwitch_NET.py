@@ -10,14 +10,16 @@ result feeds both paths and is handed to the decoder as the skip feature (oracle
 
 Kernels per block: conv / transposed-conv (MFMA implicit GEMM), BatchNorm2d (batch statistics in training mode,
 running statistics in eval mode) fused with the residual add, bilinear x2 of the shortcut, channel log-softmax /
-sigmoid heads.  BatchNorm / 'instance' selection follows ``norm_layer`` ('batch' is what scripts/train_box2mask_city.sh
-trains)."""
+sigmoid heads.  ``norm_layer`` selects BatchNorm2d ('batch', scripts/train_box2mask_city.sh) or InstanceNorm2d(affine=False)
+('instance', scripts/train_box2mask_ade.sh); ``add_dilated_layers`` (ADE) prepends two DilatedResnetBlocks (dilation 2, 4)
+to the latent encoder."""
 import math
 
 import torch.nn as nn
 
 from .. import ops
-from ..nn import Conv2d, ConvTranspose2d, BatchNorm2d, ReflectionPad2d, ReLU, _pw
+from .. import nn as hn
+from ..nn import Conv2d, ConvTranspose2d, BatchNorm2d, InstanceNorm2d, ReflectionPad2d, ReLU, _pw
 
 
 class Upsample(nn.Module):
@@ -28,23 +30,39 @@ class Upsample(nn.Module):
         self.align_corners = align_corners
 
 
-def _conv(l, x, pad_mode='zero', pad=None):
-    return ops.conv2d(x, _pw(l.weight), _pw(l.bias), l.stride, l.padding if pad is None else pad, pad_mode, 'none', 0.0)
+def _norm_factory(kind):
+    """get_norm_layer (reference models/layer_util.py:19-26)."""
+    if kind == 'batch':
+        return BatchNorm2d
+    if kind == 'instance':
+        return InstanceNorm2d
+    raise NotImplementedError('normalization layer [%s] is not found' % kind)
+
+
+def _conv(l, x, pad_mode='zero', pad=None, norm=None):
+    """``norm``: the normalisation applied right behind this conv; its mean subtraction makes the bias gradient exactly
+    zero (see nn.run_layers), so the bias-gradient pass is skipped."""
+    b = _pw(l.bias)
+    if b is not None and hn._DEAD_BIAS_SKIP and (isinstance(norm, InstanceNorm2d) or
+                                                 (isinstance(norm, BatchNorm2d) and norm.training)):
+        l.bias._him_dead_grad = True
+        b = b.detach()
+    return ops.conv2d(x, _pw(l.weight), b, l.stride, l.padding if pad is None else pad, pad_mode, 'none', 0.0)
 
 
 class ConvResnetBlock(nn.Module):
     """relu(x) -> [conv k s] -> BN  +  shortcut(relu(x)) = conv1x1 s -> BN   (layer_util.py:128-171, num_layers 1)."""
 
-    def __init__(self, cin, cout, stride, k):
+    def __init__(self, cin, cout, stride, k, norm=BatchNorm2d):
         super().__init__()
         self.shortcut = None if (cin == cout and stride == 1) else nn.Sequential(Conv2d(cin, cout, 1, stride, 0),
-                                                                                 BatchNorm2d(cout))
-        self.deep = nn.Sequential(ReLU(), Conv2d(cin, cout, k, stride, (k - 1) // 2), BatchNorm2d(cout))
+                                                                                 norm(cout))
+        self.deep = nn.Sequential(ReLU(), Conv2d(cin, cout, k, stride, (k - 1) // 2), norm(cout))
 
     def forward(self, x):
         r = ops.activation(x, 'relu')
-        res = r if self.shortcut is None else self.shortcut[1].apply_to(_conv(self.shortcut[0], r))
-        out = self.deep[2].apply_to(_conv(self.deep[1], r), residual=res)
+        res = r if self.shortcut is None else self.shortcut[1].apply_to(_conv(self.shortcut[0], r, norm=self.shortcut[1]))
+        out = self.deep[2].apply_to(_conv(self.deep[1], r, norm=self.deep[2]), residual=res)
         return out, r
 
 
@@ -52,50 +70,83 @@ class DeconvResnetBlock(nn.Module):
     """relu(x) -> ConvTranspose2d(k4, s2, p1) -> BN  +  shortcut(relu(x)) = [conv1x1 -> BN] -> bilinear x2
     (layer_util.py:173-250, even kernel, num_layers 1)."""
 
-    def __init__(self, cin, cout, stride, k, align_corners):
+    def __init__(self, cin, cout, stride, k, align_corners, norm=BatchNorm2d):
         super().__init__()
         if k % 2 or stride != 2:
             raise NotImplementedError('DeconvResnetBlock: only the even-kernel stride-2 (ConvTranspose2d) form is on the HIP path')
         sc = []
         if cin != cout:
-            sc += [Conv2d(cin, cout, 1, 1, 0), BatchNorm2d(cout)]
+            sc += [Conv2d(cin, cout, 1, 1, 0), norm(cout)]
         sc += [Upsample(align_corners)]
         self.shortcut = nn.Sequential(*sc)
-        self.deep = nn.Sequential(ReLU(), ConvTranspose2d(cin, cout, k, stride, (k - 1) // 2, stride - 2), BatchNorm2d(cout))
+        self.deep = nn.Sequential(ReLU(), ConvTranspose2d(cin, cout, k, stride, (k - 1) // 2, stride - 2), norm(cout))
 
     def forward(self, x):
         r = ops.activation(x, 'relu')
         res = r
         if len(self.shortcut) == 3:
-            res = self.shortcut[1].apply_to(_conv(self.shortcut[0], res))
+            res = self.shortcut[1].apply_to(_conv(self.shortcut[0], res, norm=self.shortcut[1]))
         res = ops.upsample_bilinear2(res, self.shortcut[-1].align_corners)
         d = self.deep[1]
-        y = ops.conv_transpose2d(r, _pw(d.weight), _pw(d.bias), d.stride, d.padding, d.output_padding, 'none', 0.0)
-        return self.deep[2].apply_to(y, residual=res)
+        b, nrm = _pw(d.bias), self.deep[2]
+        if b is not None and hn._DEAD_BIAS_SKIP and (isinstance(nrm, InstanceNorm2d) or nrm.training):
+            d.bias._him_dead_grad = True
+            b = b.detach()
+        y = ops.conv_transpose2d(r, _pw(d.weight), b, d.stride, d.padding, d.output_padding, 'none', 0.0)
+        return nrm.apply_to(y, residual=res)
 
 
 class BNResnetBlock(nn.Module):
     """x + BN(conv3(refpad(ReLU(BN(conv3(refpad(x)))))))   (layer_util.py:333-378 with norm_layer = BatchNorm2d)."""
 
-    def __init__(self, dim):
+    def __init__(self, dim, norm=BatchNorm2d):
         super().__init__()
-        self.conv_block = nn.Sequential(ReflectionPad2d(1), Conv2d(dim, dim, 3), BatchNorm2d(dim), ReLU(),
-                                        ReflectionPad2d(1), Conv2d(dim, dim, 3), BatchNorm2d(dim))
+        self.conv_block = nn.Sequential(ReflectionPad2d(1), Conv2d(dim, dim, 3), norm(dim), ReLU(),
+                                        ReflectionPad2d(1), Conv2d(dim, dim, 3), norm(dim))
 
     def forward(self, x):
         cb = self.conv_block
-        h = cb[2].apply_to(_conv(cb[1], x, 'reflect', 1), 'relu')
-        return cb[6].apply_to(_conv(cb[5], h, 'reflect', 1), residual=x)
+        h = cb[2].apply_to(_conv(cb[1], x, 'reflect', 1, cb[2]), 'relu')
+        return cb[6].apply_to(_conv(cb[5], h, 'reflect', 1, cb[6]), residual=x)
+
+
+class _BiasFreeConv3x3(nn.Module):
+    """conv3x3(..., bias=False, dilation=d, padding=d) parameter holder (reference models/layer_util.py:254-256)."""
+
+    def __init__(self, cin, cout, dilation):
+        super().__init__()
+        import torch
+        self.dilation = dilation
+        self.weight = nn.Parameter(torch.randn(cout, cin, 3, 3) * 0.02)
+
+
+class DilatedResnetBlock(nn.Module):
+    """relu(norm(conv2(relu(norm(conv1(x))))) + x) with bias-free dilated 3x3 convs (reference layer_util.py:259-293;
+    the ReLU comes AFTER the residual add).  State-dict keys conv1.weight / conv2.weight (+ bn1 / bn2 for BatchNorm).
+    Each dilated conv runs as the plain pad-1 conv on the dilation^2 phase images (ops.dilated_conv3x3)."""
+
+    def __init__(self, dim, dilation, norm):
+        super().__init__()
+        self.conv1 = _BiasFreeConv3x3(dim, dim, dilation[0])
+        self.bn1 = norm(dim)
+        self.relu = ReLU()
+        self.conv2 = _BiasFreeConv3x3(dim, dim, dilation[1])
+        self.bn2 = norm(dim)
+
+    def forward(self, x):
+        h = self.bn1.apply_to(ops.dilated_conv3x3(x, _pw(self.conv1.weight), self.conv1.dilation), 'relu')
+        h = self.bn2.apply_to(ops.dilated_conv3x3(h, _pw(self.conv2.weight), self.conv2.dilation), residual=x)
+        return ops.activation(h, 'relu')
 
 
 class MaskTwoStreamConvSwitch_NET(nn.Module):
     def __init__(self, opt):
         super().__init__()
         g = lambda k, d: getattr(opt, k, d)  # noqa: E731
-        if g('norm_layer', 'batch') != 'batch':
-            raise NotImplementedError('box2mask generator: only norm_layer=batch is on the HIP path')
-        if g('use_simpleRes', False) or g('add_dilated_layers', False):
-            raise NotImplementedError('use_simpleRes / add_dilated_layers are not on the HIP path')
+        norm = _norm_factory(g('norm_layer', 'batch'))
+        if g('use_simpleRes', False):
+            raise NotImplementedError('--use_simpleRes (downResBlock_3x3 / upResBlock_3x3) is not on the HIP path; no '
+                                      'shipped recipe uses it')
         self.which_stream = g('which_stream', 'obj_context')
         self.num_layers = g('num_layers', 3)
         label_nc = g('label_nc', 35)
@@ -103,12 +154,16 @@ class MaskTwoStreamConvSwitch_NET(nn.Module):
         k, n_blocks = g('conv_size', 4), g('n_blocks', 6)
         align = bool(g('upsample_align_corners', False))
         dims = [g('conv_dim', 64), 96, 128, 256, 512]      # hard-coded in the reference (:26)
-        enc = [Conv2d(input_nc, dims[0], 7, 2, 3), BatchNorm2d(dims[0]), ReLU()]
+        enc = [Conv2d(input_nc, dims[0], 7, 2, 3), norm(dims[0]), ReLU()]
         for i in range(self.num_layers):
-            enc.append(ConvResnetBlock(dims[i], dims[i + 1], 2, k))
+            enc.append(ConvResnetBlock(dims[i], dims[i + 1], 2, k, norm))
         self.conv_encoder_modules = nn.Sequential(*enc)
         latent = dims[self.num_layers]
-        self.latent_encoder = nn.Sequential(*[BNResnetBlock(latent) for _ in range(int(math.floor(n_blocks / 2)))])
+        lat = []
+        if g('add_dilated_layers', False):     # the ADE recipe (reference MaskTwoStreamConvSwitch_NET.py:103-105)
+            lat += [DilatedResnetBlock(latent, (2, 2), norm), DilatedResnetBlock(latent, (4, 4), norm)]
+        lat += [BNResnetBlock(latent, norm) for _ in range(int(math.floor(n_blocks / 2)))]
+        self.latent_encoder = nn.Sequential(*lat)
 
         def decoder(out_nc, skip):
             layers, od = [], latent
@@ -117,12 +172,12 @@ class MaskTwoStreamConvSwitch_NET(nn.Module):
                 od = dims[self.num_layers - i - 1] if i < self.num_layers else idim // 2
                 if skip and 1 <= i <= self.num_layers:
                     idim *= 2
-                layers.append(DeconvResnetBlock(idim, od, 2, k, align))
+                layers.append(DeconvResnetBlock(idim, od, 2, k, align, norm))
             layers.append(Conv2d(od, out_nc, 3, 1, 1))
             return nn.Sequential(*layers)
 
         def latent_dec():
-            return nn.Sequential(*[BNResnetBlock(latent) for _ in range(int(math.ceil(n_blocks / 2)))])
+            return nn.Sequential(*[BNResnetBlock(latent, norm) for _ in range(int(math.ceil(n_blocks / 2)))])
 
         if 'obj' in self.which_stream:
             self.obj_conv_decoder_modules = decoder(1, False)
@@ -149,7 +204,7 @@ class MaskTwoStreamConvSwitch_NET(nn.Module):
 
     def forward(self, input_var, cls_onehot=None, is_bkg=False):
         e = self.conv_encoder_modules
-        f = e[1].apply_to(_conv(e[0], input_var), 'relu')
+        f = e[1].apply_to(_conv(e[0], input_var, norm=e[1]), 'relu')
         skips = []
         for i in range(3, 3 + self.num_layers):
             f, r = e[i](f)

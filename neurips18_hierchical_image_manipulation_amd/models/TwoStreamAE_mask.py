@@ -52,8 +52,6 @@ class TwoStreamAE_mask(BaseModel):
             raise NotImplementedError('box2mask HIP path: --which_gan patch_multiscale (LSGAN) only')
         if opt.objReconLoss != 'bce':
             raise NotImplementedError('box2mask HIP path: --objReconLoss bce only')
-        if opt.lr_control:
-            raise NotImplementedError('--lr_control reads the losses on the host every step (Discriminator_NET.py:190-211)')
         self.device = pick_device(opt)
         self.use_gan, self.use_output_gate = bool(opt.use_gan), bool(opt.use_output_gate)
         self.netG = MaskTwoStreamConvSwitch_NET(opt).to(self.device)
@@ -116,7 +114,8 @@ class TwoStreamAE_mask(BaseModel):
             m = gate if self.use_output_gate else None
             real_d = self.netD(ops.cat_channels([obj_gt, cond], m, 1))
             fake_d = self.netD(ops.cat_channels([obj_prob.detach(), cond], m, 1))
-            loss_D = 0.5 * self._gan(real_d, True) + 0.5 * self._gan(fake_d, False)
+            self._d_real_loss, self._d_fake_loss = self._gan(real_d, True), self._gan(fake_d, False)
+            loss_D = 0.5 * self._d_real_loss + 0.5 * self._d_fake_loss
             if opt.use_ganFeat_loss:          # returned, never added to loss_G (reference :225-227)
                 with torch.no_grad():
                     fw, dw = 4.0 / (opt.num_layers_D + 1), 1.0 / 2.0
@@ -126,6 +125,12 @@ class TwoStreamAE_mask(BaseModel):
             with frozen_params():
                 loss_G_GAN = self._gan(self.netD(ops.cat_channels([obj_prob, cond], m, 1)), True)
         loss_G = loss_obj + opt.rec_weight * loss_comb + opt.gan_weight * loss_G_GAN
+        if self.use_gan and opt.lr_control:
+            # reference :229-245 with the predicate of Discriminator_NET.py:190-211 evaluated ON THE DEVICE (the
+            # reference reads three losses back to the host every step): loss_G / loss_D are scaled by g_lr / d_lr in
+            # {0, 1}; a "frozen" net still takes its Adam step on zero gradients, exactly as upstream
+            g_lr, d_lr = ops.lr_control(self._d_real_loss, self._d_fake_loss)
+            loss_G, loss_D = loss_G * g_lr, loss_D * d_lr
         self.optimizer.zero_grad()
         if self.reducer_G is not None:
             self.reducer_G.begin()

@@ -8,6 +8,7 @@ sits in between) plus, when a norm is present, one fused InstanceNorm+activation
 """
 import contextlib
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -17,6 +18,9 @@ from . import ops
 
 class _Frozen(object):
     on = False
+
+
+_DEAD_BIAS_SKIP = os.environ.get('HIM_DEAD_BIAS_GRAD') is None     # set HIM_DEAD_BIAS_GRAD=1 to compute them anyway
 
 
 @contextlib.contextmanager
@@ -75,6 +79,10 @@ class InstanceNorm2d(nn.Module):
     def __init__(self, ch, eps=1e-5):
         super().__init__()
         self.ch, self.eps = ch, eps
+
+    def apply_to(self, x, act='none', slope=0.0, residual=None):
+        """act(InstanceNorm2d(x)) [+ residual] -- same call shape as BatchNorm2d.apply_to (box2mask blocks take either)."""
+        return ops.instance_norm(x, residual, act, slope, self.eps)
 
 
 class BatchNorm2d(nn.Module):
@@ -153,6 +161,15 @@ def run_layers(layers, x, final_residual=None):
             slope = getattr(act, 'slope', 0.0) if act is not None else 0.0
             epi = 'none' if norm is not None else aname
             w, b = l.effective_weight(), _pw(l.bias)
+            if b is not None and _DEAD_BIAS_SKIP and (isinstance(norm, InstanceNorm2d) or
+                                                      (isinstance(norm, BatchNorm2d) and norm.training)):
+                # A bias in front of a normalisation that subtracts the plane (batch) mean cancels exactly: its true
+                # gradient is identically zero and what autograd would produce is rounding noise (1e-9 of the net's
+                # gradients; the reference's Adam turns that noise into a random walk of a parameter the output does not
+                # depend on).  The bias still takes part in the forward (same rounding as the reference); its gradient
+                # pass -- a full read of dy per layer -- is skipped and the parameter stays where it is.
+                l.bias._him_dead_grad = True
+                b = b.detach()
             if l.transposed:
                 x = ops.conv_transpose2d(x, w, b, l.stride, l.padding, l.output_padding, epi, slope)
             else:

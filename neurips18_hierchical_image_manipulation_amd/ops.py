@@ -734,6 +734,54 @@ def bce_mean(p, t):
     return _BCEMean.apply(p, t.detach())
 
 
+class _SpaceBatch(torch.autograd.Function):
+    """inverse = 0: (B,C,H,W) -> (B*d*d, C, H/d, W/d) phase images; inverse = 1: back.  A permutation: its adjoint is its
+    inverse."""
+
+    @staticmethod
+    def forward(ctx, x, d, inverse):
+        ctx.set_materialize_grads(False)
+        x = x.contiguous()
+        _chk(x)
+        if inverse:
+            Bd, Cn, Hd, Wd = x.shape
+            B, H, W = Bd // (d * d), Hd * d, Wd * d
+            y = torch.empty((B, Cn, H, W), dtype=torch.float32, device=x.device)
+        else:
+            B, Cn, H, W = x.shape
+            y = torch.empty((B * d * d, Cn, H // d, W // d), dtype=torch.float32, device=x.device)
+        lib.him_space_to_batch(_p(x), _p(y), B, Cn, H, W, d, inverse, _stream())
+        ctx.cfg = (d, inverse)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None
+        d, inverse = ctx.cfg
+        return _SpaceBatch.apply(g, d, 0 if inverse else 1), None, None
+
+
+def dilated_conv3x3(x, w, dilation):
+    """nn.Conv2d(k=3, stride=1, padding=dilation, dilation=dilation, bias=False) (reference conv3x3,
+    models/layer_util.py:254-256) = the plain pad-1 conv on the dilation^2 phase images of x."""
+    d = int(dilation)
+    if d == 1:
+        return conv2d(x, w, None, 1, 1, 'zero', 'none')
+    if x.shape[2] % d or x.shape[3] % d:
+        raise HimError('dilated conv: plane %dx%d is not divisible by the dilation %d' % (x.shape[2], x.shape[3], d))
+    return _SpaceBatch.apply(conv2d(_SpaceBatch.apply(x, d, 0), w, None, 1, 1, 'zero', 'none'), d, 1)
+
+
+def lr_control(loss_d_real, loss_d_fake, margin=0.3):
+    """(g_lr, d_lr) device scalars in {0., 1.} (reference models/Discriminator_NET.py:190-211), no host read-back."""
+    a, b = loss_d_real.detach().reshape(1).contiguous(), loss_d_fake.detach().reshape(1).contiguous()
+    _chk(a, b)
+    out = torch.empty(2, dtype=torch.float32, device=a.device)
+    lib.him_lr_control(_p(a), _p(b), float(margin), _p(out), _stream())
+    return out[0], out[1]
+
+
 # ------------------------------------------------------------------------------------------------
 # pooling
 # ------------------------------------------------------------------------------------------------

@@ -31,12 +31,21 @@ class _Up(nn.Module):
         return F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=self.align)
 
 
+def _norm(kind):
+    """get_norm_layer (layer_util.py:19-26): 'batch' -> BatchNorm2d(affine=True), 'instance' -> InstanceNorm2d(affine=False)"""
+    if kind == 'batch':
+        return nn.BatchNorm2d
+    if kind == 'instance':
+        return lambda ch: nn.InstanceNorm2d(ch, affine=False)
+    raise NotImplementedError(kind)
+
+
 class ConvResnetBlock(nn.Module):   # layer_util.py:128-171 (num_layers = 1)
-    def __init__(self, cin, cout, stride, k):
+    def __init__(self, cin, cout, stride, k, norm=nn.BatchNorm2d):
         super().__init__()
         self.shortcut = None if (cin == cout and stride == 1) else nn.Sequential(nn.Conv2d(cin, cout, 1, stride),
-                                                                                 nn.BatchNorm2d(cout))
-        self.deep = nn.Sequential(nn.ReLU(), nn.Conv2d(cin, cout, k, stride, (k - 1) // 2), nn.BatchNorm2d(cout))
+                                                                                 norm(cout))
+        self.deep = nn.Sequential(nn.ReLU(), nn.Conv2d(cin, cout, k, stride, (k - 1) // 2), norm(cout))
 
     def forward(self, x):
         r = F.relu(x)                      # the in-place ReLU: both paths (and the caller's alias) see relu(x)
@@ -45,17 +54,17 @@ class ConvResnetBlock(nn.Module):   # layer_util.py:128-171 (num_layers = 1)
 
 
 class DeconvResnetBlock(nn.Module):  # layer_util.py:173-250 (even kernel -> ConvTranspose2d, num_layers = 1)
-    def __init__(self, cin, cout, stride, k, align):
+    def __init__(self, cin, cout, stride, k, align, norm=nn.BatchNorm2d):
         super().__init__()
         sc = []
         if cin != cout:
-            sc += [nn.Conv2d(cin, cout, 1), nn.BatchNorm2d(cout)]
+            sc += [nn.Conv2d(cin, cout, 1), norm(cout)]
         if stride > 1:
             sc += [_Up(align)]
         self.shortcut = nn.Sequential(*sc) if sc else None
         assert k % 2 == 0 and stride > 1
         self.deep = nn.Sequential(nn.ReLU(), nn.ConvTranspose2d(cin, cout, k, stride, (k - 1) // 2, stride - 2),
-                                  nn.BatchNorm2d(cout))
+                                  norm(cout))
 
     def forward(self, x):
         r = F.relu(x)
@@ -63,30 +72,51 @@ class DeconvResnetBlock(nn.Module):  # layer_util.py:173-250 (even kernel -> Con
         return self.deep[2](self.deep[1](r)) + res
 
 
-class ResnetBlock(nn.Module):        # layer_util.py:333-378, reflect padding, BatchNorm
-    def __init__(self, dim):
+class ResnetBlock(nn.Module):        # layer_util.py:333-378, reflect padding, BatchNorm / InstanceNorm
+    def __init__(self, dim, norm=nn.BatchNorm2d):
         super().__init__()
-        self.conv_block = nn.Sequential(nn.ReflectionPad2d(1), nn.Conv2d(dim, dim, 3), nn.BatchNorm2d(dim), nn.ReLU(),
-                                        nn.ReflectionPad2d(1), nn.Conv2d(dim, dim, 3), nn.BatchNorm2d(dim))
+        self.conv_block = nn.Sequential(nn.ReflectionPad2d(1), nn.Conv2d(dim, dim, 3), norm(dim), nn.ReLU(),
+                                        nn.ReflectionPad2d(1), nn.Conv2d(dim, dim, 3), norm(dim))
 
     def forward(self, x):
         return x + self.conv_block(x)
 
 
+class DilatedResnetBlock(nn.Module):  # layer_util.py:259-293: bias-free dilated conv3x3 pair, ReLU AFTER the residual add
+    def __init__(self, dim, dilation, norm):
+        super().__init__()
+        self.conv1 = nn.Conv2d(dim, dim, 3, 1, dilation, dilation, bias=False)
+        self.bn1 = norm(dim)
+        self.relu = nn.ReLU()
+        self.conv2 = nn.Conv2d(dim, dim, 3, 1, dilation, dilation, bias=False)
+        self.bn2 = norm(dim)
+
+    def forward(self, x):
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        return self.relu(out + x)
+
+
 class MaskTwoStreamConvSwitchNet(nn.Module):
     def __init__(self, label_nc=35, output_nc=35, conv_dim=64, num_layers=3, conv_size=4, n_blocks=6,
-                 cond_in='ctx_obj', which_stream='obj_context', align_corners=False):
+                 cond_in='ctx_obj', which_stream='obj_context', align_corners=False, norm_layer='batch',
+                 add_dilated_layers=False):
         super().__init__()
+        norm = _norm(norm_layer)
         self.num_layers = num_layers
         self.which_stream = which_stream
         input_nc = label_nc * 2 if cond_in == 'ctx_obj' else label_nc
         dims = [conv_dim, 96, 128, 256, 512]
-        enc = [nn.Conv2d(input_nc, dims[0], 7, 2, 3), nn.BatchNorm2d(dims[0]), nn.ReLU()]
+        enc = [nn.Conv2d(input_nc, dims[0], 7, 2, 3), norm(dims[0]), nn.ReLU()]
         for i in range(num_layers):
-            enc.append(ConvResnetBlock(dims[i], dims[i + 1], 2, conv_size))
+            enc.append(ConvResnetBlock(dims[i], dims[i + 1], 2, conv_size, norm))
         self.conv_encoder_modules = nn.Sequential(*enc)
         latent = dims[num_layers]
-        self.latent_encoder = nn.Sequential(*[ResnetBlock(latent) for _ in range(int(math.floor(n_blocks / 2)))])
+        lat = []
+        if add_dilated_layers:              # MaskTwoStreamConvSwitch_NET.py:103-105 (--add_dilated_layers, the ADE recipe)
+            lat += [DilatedResnetBlock(latent, 2, norm), DilatedResnetBlock(latent, 4, norm)]
+        lat += [ResnetBlock(latent, norm) for _ in range(int(math.floor(n_blocks / 2)))]
+        self.latent_encoder = nn.Sequential(*lat)
 
         def decoder(out_nc, skip):
             layers, od = [], latent
@@ -95,12 +125,12 @@ class MaskTwoStreamConvSwitchNet(nn.Module):
                 od = dims[num_layers - i - 1] if i < num_layers else idim // 2
                 if skip and 1 <= i <= num_layers:
                     idim *= 2
-                layers.append(DeconvResnetBlock(idim, od, 2, conv_size, align_corners))
+                layers.append(DeconvResnetBlock(idim, od, 2, conv_size, align_corners, norm))
             layers.append(nn.Conv2d(od, out_nc, 3, 1, 1))
             return nn.Sequential(*layers)
 
         def latent_dec():
-            return nn.Sequential(*[ResnetBlock(latent) for _ in range(int(math.ceil(n_blocks / 2)))])
+            return nn.Sequential(*[ResnetBlock(latent, norm) for _ in range(int(math.ceil(n_blocks / 2)))])
 
         if 'obj' in which_stream:
             self.obj_conv_decoder_modules = decoder(1, False)
@@ -152,6 +182,16 @@ def encode_input(label_map, mask_ctx_in, mask_in, cls, label_nc):
     return gt, ctx, obj
 
 
+def lr_control(loss_D_real, loss_D_fake, gan_margin=0.3):
+    """Discriminator_NET.py:190-211: (g_lr, d_lr) in {0., 1.}: D pauses while either of its losses is under the margin,
+    G pauses while either is above 1 - margin; if both would pause, both train."""
+    update_d = not (loss_D_real < gan_margin or loss_D_fake < gan_margin)
+    update_g = not (loss_D_real > 1 - gan_margin or loss_D_fake > 1 - gan_margin)
+    if not (update_d or update_g):
+        update_d = update_g = True
+    return float(update_g), float(update_d)
+
+
 class TwoStreamAEMask(object):
     """CPU restatement of the reference trainer with the flags of scripts/train_box2mask_city.sh
     (which_stream obj_context, cond_in ctx_obj, use_gan patch_multiscale, objReconLoss bce, use_output_gate,
@@ -159,12 +199,15 @@ class TwoStreamAEMask(object):
     Adam step, then the D Adam step (:237-248)."""
 
     def __init__(self, label_nc=35, ndf=64, num_layers_D=3, gan_weight=0.1, rec_weight=1.0, lambda_feat=1.0, lr=0.0002,
-                 beta1=0.5, beta2=0.999, use_output_gate=True, use_ganFeat_loss=True):
+                 beta1=0.5, beta2=0.999, use_output_gate=True, use_ganFeat_loss=True, norm_layer='batch',
+                 add_dilated_layers=False, lr_control=False):
         from oracle import ref_cpu
         self.label_nc, self.gan_weight, self.rec_weight, self.lambda_feat = label_nc, gan_weight, rec_weight, lambda_feat
         self.use_output_gate, self.use_ganFeat_loss, self.num_layers_D = use_output_gate, use_ganFeat_loss, num_layers_D
-        self.netG = MaskTwoStreamConvSwitchNet(label_nc, label_nc)
-        self.netD = ref_cpu.MultiscaleDiscriminator(1 + 2 * label_nc, ndf, num_layers_D, num_D=2, norm='batch')
+        self.lr_control = lr_control
+        self.netG = MaskTwoStreamConvSwitchNet(label_nc, label_nc, norm_layer=norm_layer,
+                                               add_dilated_layers=add_dilated_layers)
+        self.netD = ref_cpu.MultiscaleDiscriminator(1 + 2 * label_nc, ndf, num_layers_D, num_D=2, norm=norm_layer)
         self.gan_loss = ref_cpu.gan_loss
         self.optimizer = torch.optim.Adam(self.netG.parameters(), lr=lr, betas=(beta1, beta2))
         self.optimizer_D = torch.optim.Adam(self.netD.parameters(), lr=lr, betas=(beta1, 0.999))
@@ -197,6 +240,9 @@ class TwoStreamAEMask(object):
                     loss_feat = loss_feat + dw * fw * F.l1_loss(fake_d[i][j], real_d[i][j].detach()) * self.lambda_feat
         loss_G_GAN = self.gan_loss(self.netD(torch.cat((fake, dcond), 1)), True)
         loss_G = loss_obj + self.rec_weight * loss_comb + self.gan_weight * loss_G_GAN
+        if self.lr_control:                                    # Discriminator_NET.py:190-211, TwoStreamAE_mask.py:229-245
+            g_lr, d_lr = lr_control(float(loss_D_real.detach()), float(loss_D_fake.detach()))
+            loss_G, loss_D = g_lr * loss_G, d_lr * loss_D       # a frozen net still takes an Adam step on zero gradients
         self.optimizer.zero_grad()
         loss_G.backward()
         self.optimizer.step()

@@ -174,6 +174,8 @@ def box2mask_trainer(**flags):
     sys.modules['models.base_model'] = bm
     if not hasattr(nn, 'NLLLoss2d'):
         nn.NLLLoss2d = nn.NLLLoss
+    # lr_control (Discriminator_NET.py:190-211) indexes its losses with .data[0]; torch >= 0.4 losses are 0-dim tensors
+    _load_patched('Discriminator_NET', py3 + [('.data[0]', '.data.reshape(-1)[0]')])
     T = _load_patched('TwoStreamAE_mask', py3)
     d = dict(label_nc=35, output_nc=35, fineSize=256, num_layers=3, conv_dim=64, conv_size=4, embed_dim=1024, z_dim=512,
              norm_layer='batch', use_dropout=False, skip_start=1, skip_end=3, use_resnetblock=1, num_resnetblocks=1,

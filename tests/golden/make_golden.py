@@ -241,6 +241,91 @@ def golden_box2mask_traj(steps=6):
                         losses=rl.astype(np.float32), loss_names=np.array(ref_mask_cpu.LOSS_NAMES))
 
 
+ADE = dict(label_nc=49, output_nc=49, norm_layer='instance', add_dilated_layers=True)   # scripts/train_box2mask_ade.sh
+
+
+def golden_box2mask_ade():
+    """The ADE recipe of box2mask (scripts/train_box2mask_ade.sh): label_nc 49, InstanceNorm generator and discriminator,
+    two DilatedResnetBlocks (dilation 2 and 4) in front of the latent ResnetBlocks, --lr_control.
+    (1) generator forward + parameter gradients of the REAL reference class at 64x64, batch 2 (8x8 latent planes: the
+        dilation-4 block works on 2x2 phase images), pinned against the oracle restatement;
+    (2) 6 training steps of the REAL trainer with --lr_control (its ``.data[0]`` reads are patched to
+        ``.data.reshape(-1)[0]`` in memory: torch >= 0.4 losses are 0-dim), next to the oracle; the (g_lr, d_lr) decisions
+        of every step are stored."""
+    from oracle import ref_mask_cpu
+    ref = ref_shim.box2mask_generator(**ADE)
+    ora = ref_mask_cpu.MaskTwoStreamConvSwitchNet(49, 49, norm_layer='instance', add_dilated_layers=True)
+    assert list(ref.state_dict().keys()) == list(ora.state_dict().keys()), (
+        set(ref.state_dict().keys()) ^ set(ora.state_dict().keys()))
+    sd = synth.init_state_dict(ora.state_dict(), 31)
+    x = torch.randn(2, 98, 64, 64, generator=torch.Generator().manual_seed(3))
+    gy = [torch.randn(2, 49, 64, 64, generator=torch.Generator().manual_seed(5)),
+          torch.randn(2, 1, 64, 64, generator=torch.Generator().manual_seed(6))]
+    out = dict(x_sum=np.array([x.double().sum().item(), x.double().abs().sum().item()]),
+               gy_sum=np.array([gy[0].double().sum().item(), gy[1].double().sum().item()]))
+    ref.load_state_dict(sd)
+    ora.load_state_dict(sd)
+    ref.train()
+    ora.train()
+    with torch.autograd.graph.allow_mutation_on_saved_tensors():
+        a = ref(x.clone(), None)
+        ((a[1] * gy[0]).sum() + (a[3] * gy[1]).sum()).backward()
+    b = ora(x.clone())
+    ((b[1] * gy[0]).sum() + (b[3] * gy[1]).sum()).backward()
+    for p, q in zip(a, b):
+        assert torch.equal(p, q), (p - q).abs().max()
+    out['ctx_prob'] = a[1].detach().numpy()
+    out['obj_prob'] = a[3].detach().numpy()
+    names, sums = [], []
+    gr = dict(ref.named_parameters())
+    for k, po in ora.named_parameters():
+        gr_k, go_k = gr[k].grad, po.grad
+        scale = float(gr_k.abs().max())
+        if k.endswith('bias'):
+            scale = max(scale, float(gr[k[:-4] + 'weight'].grad.abs().max()))
+        assert float((gr_k - go_k).abs().max()) <= 4e-6 * max(scale, 1e-3), (k, scale, float((gr_k - go_k).abs().max()))
+        names.append(k)
+        sums.append([gr_k.double().sum().item(), gr_k.double().abs().sum().item()])
+    out['grad_names'] = np.array(names)
+    out['grad_sums'] = np.array(sums)
+    np.savez_compressed(os.path.join(HERE, 'box2mask_ade_net.npz'), **out)
+    print('box2mask_ade_net: forward bit-exact, gradients pinned (%d parameters)' % len(names))
+
+    fl = dict(ADE, ndf=16, num_layers_D=3, gan_weight=0.1, lr=0.0002, beta1=0.5, beta2=0.999, lr_control=True)
+    reft = ref_shim.box2mask_trainer(**fl)
+    orat = ref_mask_cpu.TwoStreamAEMask(label_nc=49, ndf=16, num_layers_D=3, gan_weight=0.1, lr=0.0002, beta1=0.5, beta2=0.999,
+                                        norm_layer='instance', add_dilated_layers=True, lr_control=True)
+    assert list(reft.netD.state_dict().keys()) == list(orat.netD.state_dict().keys())
+    sdG = synth.init_state_dict(orat.netG.state_dict(), 31)
+    sdD = synth.init_state_dict(orat.netD.state_dict(), 32)
+    for m in (reft, orat):
+        m.netG.load_state_dict(sdG)
+        m.netD.load_state_dict(sdD)
+    rl, ol, said = [], [], []
+    import io
+    for s in range(6):
+        bt = synth.make_box2mask_batch(s, 0, 2, 64, 64, 49)
+        so, sys.stdout = sys.stdout, io.StringIO()
+        try:
+            with torch.autograd.graph.allow_mutation_on_saved_tensors():
+                r, _ = reft.forward(bt['label'], None, bt['mask_ctx_in'], None, bt['mask_out'], bt['mask_obj_inst'],
+                                    bt['cls'], bt['mask_in'], eval_mode=False)
+            said.append(sys.stdout.getvalue().split('\t')[0].strip())
+        finally:
+            sys.stdout = so
+        rl.append([float(v.detach().reshape(-1)[0]) if torch.is_tensor(v) else float(v) for v in r])
+        o = orat.step(bt)
+        ol.append([o[k] for k in ref_mask_cpu.LOSS_NAMES])
+    rl, ol = np.array(rl, np.float64), np.array(ol, np.float64)
+    rel = np.abs(rl - ol) / np.maximum(np.abs(rl), 1e-12)
+    print('box2mask_ade_traj: lr_control said %s; max rel(oracle vs reference) per step = %s' % (
+        said, ' '.join('%.1e' % v for v in rel.max(1))))
+    assert rel[:3].max() < 2e-6 and rel.max() < 5e-3, rel
+    np.savez_compressed(os.path.join(HERE, 'box2mask_ade_traj.npz'), flags=json.dumps(fl), B=2, H=64, W=64,
+                        losses=rl.astype(np.float32), loss_names=np.array(ref_mask_cpu.LOSS_NAMES),
+                        lr_control_said=np.array(said))
+
+
 TINY = dict(model='pix2pixHD_condImg', netG='global', ngf=8, ndf=8, n_downsample_global=4, n_blocks_global=2,
             num_D=2, n_layers_D=3, label_nc=35, no_instance=True)
 TINY_GATE = dict(TINY, use_output_gate=True, num_D=3)
@@ -275,5 +360,7 @@ if __name__ == '__main__':
     if 'box2mask' in what:
         golden_box2mask_net()
         golden_box2mask_traj()
+    if 'box2mask_ade' in what:
+        golden_box2mask_ade()
     if 'c4' in what:
         trajectory('c4_traj', C4, 4, 256, 256, 3, color=True)   # bs 4 of the bs-16 config keeps it to minutes

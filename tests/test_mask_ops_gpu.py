@@ -138,3 +138,27 @@ def test_bce_mean():
     assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
     (gp,) = torch.autograd.grad(loss, pd)
     assert_close('bce grad', gp, gp_ref)
+
+
+@pytest.mark.parametrize('case', [(2, 16, 8, 8, 16, 2), (2, 32, 8, 12, 16, 4), (1, 256, 32, 32, 256, 2), (3, 8, 6, 6, 8, 1)],
+                         ids=lambda c: 'x'.join(map(str, c)))
+def test_dilated_conv3x3_matches_torch(case):
+    """conv3x3(bias=False, padding=d, dilation=d) of DilatedResnetBlock (reference models/layer_util.py:254-293) through
+    the phase split (space-to-batch -> plain pad-1 conv -> batch-to-space): forward, data and weight gradient."""
+    from neurips18_hierchical_image_manipulation_amd import ops
+    B, Cin, H, W, Cout, d = case
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, Cin, H, W, generator=g).requires_grad_(True)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (Cin * 9) ** -0.5).requires_grad_(True)
+    y_ref = F.conv2d(x, w, None, 1, d, d)
+    gy = torch.randn(y_ref.shape, generator=g)
+    gx_ref, gw_ref = torch.autograd.grad(y_ref, (x, w), gy)
+    xd, wd = x.detach().cuda().requires_grad_(True), w.detach().cuda().requires_grad_(True)
+    y = ops.dilated_conv3x3(xd, wd, d)
+    assert_close('dilated fwd', y, y_ref)
+    gx, gw = torch.autograd.grad(y, (xd, wd), gy.cuda())
+    assert_close('dilated dgrad', gx, gx_ref)
+    assert_close('dilated wgrad', gw, gw_ref)
+    # the phase split is a permutation: inverse(forward(x)) == x bit for bit
+    z = ops._SpaceBatch.apply(ops._SpaceBatch.apply(xd.detach(), d, 0), d, 1) if d > 1 else xd.detach()
+    assert torch.equal(z, xd.detach())
