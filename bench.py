@@ -269,7 +269,10 @@ def cpu_baseline(name, wl, timed=3, budget_s=75.0):
     beside it."""
     from oracle import ref_cpu
     from neurips18_hierchical_image_manipulation_amd import synth
-    cores = torch.get_num_threads()
+    # torch/oneDNN on ALL 128 hardware threads of the GPU box is 8x slower than on 16-32 of them
+    # (tools/cpu_thread_sweep.py: C1 0.8 s/step at 16-32 threads, 2.6 s at 64, 6-8 s at 128): time the baseline at its best
+    cores = min(32, torch.get_num_threads())
+    torch.set_num_threads(cores)
     bs, H, W = wl['bs'], wl['H'], wl['W']
     if name == 'box2mask':
         from oracle import ref_mask_cpu

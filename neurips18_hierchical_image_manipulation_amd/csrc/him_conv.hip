@@ -160,15 +160,18 @@ __global__ __launch_bounds__(WM * WN * 64, (TN == 4 ? 2 : 1)) void gconv_fast_ke
 
   // issue the global loads of tile kt (weights: contiguous float4; gather: one load per element with the channel
   // offset folded into the wave-uniform base pointer -> "global_load v, v_off, s[base]" addressing, no 64-bit VALU)
-#define HIM_LOAD_TILE(kt_, RA0, RA1, RB)                                                                     \
+#define HIM_LOAD_TILE(kt_, RA0, RA1, RB, ROK)                                                                \
   {                                                                                                          \
     const uint32_t kbyte = (uint32_t)(kt_) * (BK * 4);                                                        \
     RA0 = *(const float4*)(Atb + (aoff[0] * 4u + kbyte));                                                    \
     if (A_V4 > 1) RA1 = *(const float4*)(Atb + (aoff[A_V4 - 1] * 4u + kbyte));                               \
-    HIM_GATHER(by, bx, RB)                                                                                   \
+    HIM_GATHER(by, bx, RB, ROK)                                                                              \
   }
-  // one gather pass: tap coordinates once per K-step, then one saddr load per channel
-#define HIM_GATHER(YY, XX, RBC)                                                                        \
+  // one gather pass: tap coordinates once per K-step, then one saddr load per channel.  The loaded values stay RAW
+  // in registers; the padding predicate (one per thread and tile) is applied when the tile is written to LDS a K-step
+  // later -- a select right behind the loads makes the compiler wait for them on the spot (s_waitcnt vmcnt(0) a few
+  // instructions after issue, measured in the round-1 ISA), which exposed the whole memory latency in every K-step.
+#define HIM_GATHER(YY, XX, RBC, ROK)                                                                      \
   {                                                                                                          \
     int iy = (YY) + c_jh * ddy, ix = (XX) + c_jw * ddx;                                                       \
     bool ok = true;                                                                                          \
@@ -197,17 +200,19 @@ __global__ __launch_bounds__(WM * WN * 64, (TN == 4 ? 2 : 1)) void gconv_fast_ke
     gchar_p sp = (gchar_p)srcb + (size_t)(CLAMPC ? min(c0, C2 - 1) : c0) * chan_bytes;                       \
     _Pragma("unroll") for (int i = 0; i < KPT; ++i) {                                                        \
       asm volatile("" : "+s"(sp)); /* keep the wave-uniform base in SGPRs: saddr + 32-bit voffset load */    \
-      const float v = *(gfloat_p)(sp + tapbyte);                                                             \
-      RBC[i] = ok ? v : 0.f;                                                                                 \
+      RBC[i] = *(gfloat_p)(sp + tapbyte);                                                                    \
       sp += (CLAMPC && c0 + i + 1 > C2 - 1) ? 0 : chan_bytes;                                                \
     }                                                                                                        \
+    ROK = ok;                                                                                                \
   }
-#define HIM_STORE_TILE(buf_, RA0, RA1, RB)                                                                    \
+#define HIM_STORE_TILE(buf_, RA0, RA1, RB, ROK)                                                               \
   {                                                                                                          \
     *(float4*)&sA[buf_][arow * LD + akq * 4] = RA0;                                                          \
     if (A_V4 > 1) *(float4*)&sA[buf_][(arow + AROWS) * LD + akq * 4] = RA1;                                  \
+    const bool okst = (PM == 1) || ROK;                                                                      \
     _Pragma("unroll") for (int q = 0; q < KPT / 4; ++q) *(float4*)&sB[buf_][nl * LD + kg * KPT + q * 4] =     \
-        make_float4(RB[q * 4], RB[q * 4 + 1], RB[q * 4 + 2], RB[q * 4 + 3]);                                 \
+        make_float4(okst ? RB[q * 4] : 0.f, okst ? RB[q * 4 + 1] : 0.f, okst ? RB[q * 4 + 2] : 0.f,           \
+                    okst ? RB[q * 4 + 3] : 0.f);                                                             \
   }
   // reduction order: channel block OUTER, filter taps INNER -- the JH*JW taps of a 16-channel block are consecutive
   // K-steps, so the gathered activations are re-read from L1/L2 instead of once per tap from the Infinity Cache
@@ -232,15 +237,16 @@ __global__ __launch_bounds__(WM * WN * 64, (TN == 4 ? 2 : 1)) void gconv_fast_ke
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int l31 = lane & 31, lh = lane >> 5;
-  HIM_LOAD_TILE(0, xa0, xa1, xb)
-  HIM_STORE_TILE(0, xa0, xa1, xb)
+  bool xok = true, yok = true;   // padding predicates of the tiles held in the two register sets
+  HIM_LOAD_TILE(0, xa0, xa1, xb, xok)
+  HIM_STORE_TILE(0, xa0, xa1, xb, xok)
   if (nk > 1) HIM_ADVANCE()
-  HIM_LOAD_TILE(min(1, nk - 1), ya0, ya1, yb)   // tile 1 stays in flight in set Y
+  HIM_LOAD_TILE(min(1, nk - 1), ya0, ya1, yb, yok)   // tile 1 stays in flight in set Y
   __syncthreads();
 
   // one K-step: prefetch tile kt+2 into (LA0,LA1,LB), run the MFMAs of tile kt from LDS buffer kt&1, write tile kt+1
   // (SA0,SA1,SB) into the other buffer.  Past-the-end tiles are clamped re-loads that are never consumed.
-#define HIM_KSTEP(kt_, LA0, LA1, LB, SA0, SA1, SB)                                                           \
+#define HIM_KSTEP(kt_, LA0, LA1, LB, LOK, SA0, SA1, SB, SOK)                                                          \
   {                                                                                                          \
     const int buf = (kt_) & 1;                                                                               \
     if ((kt_) + 2 < nk) HIM_ADVANCE()                                                                        \
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(WM * WN * 64, (TN == 4 ? 2 : 1)) void gconv_fast_ke
       b0[j] = pb[j * 32 * LD / 4];                                                                           \
       b1[j] = pb[j * 32 * LD / 4 + 1];                                                                       \
     }                                                                                                        \
-    HIM_LOAD_TILE(min((kt_) + 2, nk - 1), LA0, LA1, LB)                                                      \
+    HIM_LOAD_TILE(min((kt_) + 2, nk - 1), LA0, LA1, LB, LOK)                                                 \
     HIM_MFMA_STEP(a0[i].x, b0[j].x)                                                                          \
     HIM_MFMA_STEP(a0[i].y, b0[j].y)                                                                          \
     HIM_MFMA_STEP(a0[i].z, b0[j].z)                                                                          \
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(WM * WN * 64, (TN == 4 ? 2 : 1)) void gconv_fast_ke
     HIM_MFMA_STEP(a1[i].y, b1[j].y)                                                                          \
     HIM_MFMA_STEP(a1[i].z, b1[j].z)                                                                          \
     HIM_MFMA_STEP(a1[i].w, b1[j].w)                                                                          \
-    HIM_STORE_TILE(buf ^ 1, SA0, SA1, SB)                                                                    \
+    HIM_STORE_TILE(buf ^ 1, SA0, SA1, SB, SOK)                                                               \
     __syncthreads();                                                                                         \
   }
 #define HIM_MFMA_STEP(AX, BX)                                                                                 \
@@ -273,10 +279,10 @@ __global__ __launch_bounds__(WM * WN * 64, (TN == 4 ? 2 : 1)) void gconv_fast_ke
 
   int kt = 0;
   for (; kt + 1 < nk; kt += 2) {
-    HIM_KSTEP(kt, xa0, xa1, xb, ya0, ya1, yb)
-    HIM_KSTEP(kt + 1, ya0, ya1, yb, xa0, xa1, xb)
+    HIM_KSTEP(kt, xa0, xa1, xb, xok, ya0, ya1, yb, yok)
+    HIM_KSTEP(kt + 1, ya0, ya1, yb, yok, xa0, xa1, xb, xok)
   }
-  if (kt < nk) HIM_KSTEP(kt, xa0, xa1, xb, ya0, ya1, yb)
+  if (kt < nk) HIM_KSTEP(kt, xa0, xa1, xb, xok, ya0, ya1, yb, yok)
 #undef HIM_MFMA_STEP
 #undef HIM_KSTEP
 #undef HIM_ADVANCE
@@ -1621,7 +1627,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradP p) {
 // operand tile per K-step).  Partial results go to tap-major slabs; wgrad_finish_kernel sums the split-K slabs in
 // fixed order and scatters into the reference (Cout,Cin,KH,KW) layout (+= for the gradient arena).
 // =============================================================================================
-template <int TM, int TN, bool REFLECT>
+template <int TM, int TN, bool REFLECT, bool AL4>
 __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WGradP p) {
   constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32, BK = 32, LD = 36;
   constexpr int A_V4 = BM * BK / 4 / 256;  // 4 or 2
@@ -1656,6 +1662,7 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WGradP p) {
 
   float4 ra[A_V4];
   float rb[RB];
+  bool raok[4] = {false, false, false, false}, rbok = false;
   // per-thread cursors of the NEXT tile: A quad position and gather position, as (image, offset in image)
   int ka = kbeg + akq * 4, ba = ka / OHW, spa = ka - ba * OHW;
   int kb = kbeg + kkl, bb = kb / OHW, spb = kb - bb * OHW;
@@ -1663,10 +1670,32 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WGradP p) {
 #define HIM_WLOAD()                                                                                           \
   {                                                                                                           \
     const bool av = ka < kend;                                                                                \
+    if (AL4) raok[0] = raok[1] = raok[2] = raok[3] = av;                                                      \
     const uint32_t abase = av ? ((uint32_t)ba * (uint32_t)p.M * (uint32_t)OHW + (uint32_t)spa) : 0u;            \
-    _Pragma("unroll") for (int i = 0; i < A_V4; ++i) {                                                        \
-      const float4 v = *(const float4*)(dyc + (size_t)(abase + arowoff[i]) * 4);                              \
-      ra[i] = av ? v : make_float4(0.f, 0.f, 0.f, 0.f);                                                       \
+    if (AL4) {                                                                                                \
+      _Pragma("unroll") for (int i = 0; i < A_V4; ++i) {                                                      \
+        ra[i] = *(const float4*)(dyc + (size_t)(abase + arowoff[i]) * 4);                                     \
+      }                                                                                                       \
+    } else { /* plane size not a multiple of 4 (odd PatchGAN planes): a quad may straddle two images */        \
+      uint32_t eo[4];                                                                                         \
+      bool ev[4];                                                                                             \
+      (void)ev;                                                                                               \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
+        int sp_ = spa + j, b_ = ba;                                                                           \
+        const bool wrap = sp_ >= OHW;                                                                         \
+        sp_ -= wrap ? OHW : 0;                                                                                \
+        b_ += wrap ? 1 : 0;                                                                                   \
+        ev[j] = ka + j < kend;                                                                                \
+        eo[j] = ev[j] ? ((uint32_t)b_ * (uint32_t)p.M * (uint32_t)OHW + (uint32_t)sp_) : 0u;                    \
+        raok[j] = ev[j];                                                                                      \
+      }                                                                                                       \
+      _Pragma("unroll") for (int i = 0; i < A_V4; ++i) {                                                      \
+        float q_[4];                                                                                          \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                       \
+          q_[j] = *(const float*)(dyc + (size_t)(eo[j] + arowoff[i]) * 4);                                   \
+        }                                                                                                     \
+        ra[i] = make_float4(q_[0], q_[1], q_[2], q_[3]);                                                      \
+      }                                                                                                       \
     }                                                                                                         \
     const bool bv = kb < kend;                                                                                \
     const int sp = bv ? spb : 0;                                                                              \
@@ -1690,10 +1719,10 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WGradP p) {
     gchar_p sp8 = xbase;                                                                                      \
     _Pragma("unroll") for (int i = 0; i < RB; ++i) {                                                          \
       asm volatile("" : "+s"(sp8));                                                                           \
-      const float v = *(gfloat_p)(sp8 + voff);                                                                \
-      rb[i] = ok ? v : 0.f; /* A is zero beyond kend, so bv needs no select here */                           \
+      rb[i] = *(gfloat_p)(sp8 + voff); /* raw: the padding predicate is applied at the LDS store */          \
       sp8 += step8;                                                                                           \
     }                                                                                                         \
+    rbok = ok; /* A is zero beyond kend, so bv needs no select */                                            \
     ka += BK;                                                                                                 \
     spa += BK;                                                                                                \
     while (spa >= OHW) {                                                                                      \
@@ -1709,8 +1738,11 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WGradP p) {
   }
 #define HIM_WSTORE(buf_)                                                                                       \
   {                                                                                                           \
-    _Pragma("unroll") for (int i = 0; i < A_V4; ++i) *(float4*)&sA[buf_][(arow + 32 * i) * LD + akq * 4] = ra[i]; \
-    _Pragma("unroll") for (int i = 0; i < RB; ++i) sB[buf_][(rg + 8 * i) * LD + kkl] = rb[i];                 \
+    /* padding / tail predicates are applied HERE, a whole K-step of MFMAs after the loads were issued: a select  \
+       right behind a load makes the compiler wait for it on the spot */                                        \
+    _Pragma("unroll") for (int i = 0; i < A_V4; ++i) *(float4*)&sA[buf_][(arow + 32 * i) * LD + akq * 4] =      \
+        make_float4(raok[0] ? ra[i].x : 0.f, raok[1] ? ra[i].y : 0.f, raok[2] ? ra[i].z : 0.f, raok[3] ? ra[i].w : 0.f); \
+    _Pragma("unroll") for (int i = 0; i < RB; ++i) sB[buf_][(rg + 8 * i) * LD + kkl] = rbok ? rb[i] : 0.f;     \
   }
 
   f32x16 acc[TM][TN];
@@ -1795,7 +1827,7 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restri
 static bool wgrad_fast_ok(int M, int C, int OH, int OW) {
   static int force_generic = -1;
   if (force_generic < 0) force_generic = getenv("HIM_GENERIC_CONV") ? 1 : 0;
-  return !force_generic && M > 4 && (C % 64) == 0 && ((OH * OW) % 4) == 0;
+  return !force_generic && M > 4 && (C % 64) == 0 && OH * OW >= 4;   // planes with OH*OW % 4 != 0: scalar dY loads
 }
 static void wgrad_fast_cfg(int M, int C, int Kdim, int KK, int* BM, int* BN, int* splits) {
   *BM = M > 64 ? 128 : 64;
@@ -1965,22 +1997,29 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 }
 
 // Tiny-M weight gradient for "same" odd kernels (the G tanh head conv7x7 64->3): sliding-window, lane-private.
-// One wave = one input channel; its 64 lanes are 64 consecutive output columns and walk down a strip of rows keeping
-// the KSxKS window of x around their pixel in registers (ONE new row of KS loads per step instead of KS*KS gathers),
-// MM*KS*KS private FMA accumulators, a DPP wave reduction once per workgroup.  part[slot][m][c*KK + t].
-// grid (slots, ceil(C/4)); workgroups are persistent over the (image, column strip, row chunk) tasks.
-template <int MM, int KS, bool REFLECT>
+// One wave = one input channel x one BAND of TR filter rows; its 64 lanes are 64 consecutive output columns and walk
+// down a strip of rows keeping the TR x KS window of x around their pixel in registers (ONE new row of KS loads per step
+// instead of KS*KS gathers), MM*TR*KS private FMA accumulators, a DPP wave reduction once per workgroup.
+// The band split (blockIdx.z: filter rows [th0, th0+TR), th0 = min(z*TR, KS-TR); rows a later band recomputes are
+// written by the later band only) keeps the 7x7 / 3-output case at ~160 VGPRs = 3 waves per SIMD -- the un-split
+// kernel needed 278 registers, i.e. ONE wave per SIMD with nothing to hide its load latency behind.
+// part[slot][m][c*KK + t].  grid (slots, ceil(C/4), ceil(KS/TR)); workgroups are persistent over the (image, column
+// strip, row chunk) tasks.
+template <int MM, int KS, int TR, bool REFLECT>
 __global__ __launch_bounds__(256) void wgrad_small_win_kernel(const WGradP p, int nsx, int nyc, int rows_per, int ntasks) {
   constexpr int KK = KS * KS;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int c = blockIdx.y * 4 + wave;
   if (c >= p.C) return;
+  const int th0 = min((int)blockIdx.z * TR, KS - TR);      // first filter row of this band
+  const int own0 = (int)blockIdx.z * TR - th0;             // band rows [own0, TR) are written by this band
   const int H = p.H, W = p.W, HW = H * W, pad = p.pad;
-  float acc[MM][KK];
+  const int padr = pad - th0;                              // row padding as seen by the band
+  float acc[MM][TR * KS];
 #pragma unroll
   for (int m = 0; m < MM; ++m)
 #pragma unroll
-    for (int t = 0; t < KK; ++t) acc[m][t] = 0.f;
+    for (int t = 0; t < TR * KS; ++t) acc[m][t] = 0.f;
   for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
     int q = task;
     const int yc = q % nyc;
@@ -2006,7 +2045,7 @@ __global__ __launch_bounds__(256) void wgrad_small_win_kernel(const WGradP p, in
       cx[k] = min(max(ix, 0), W - 1);
       okc[k] = ok;
     }
-    float win[KS][KS];
+    float win[TR][KS];
 #define HIM_SW_ROW(PY, DST)                                                            \
   {                                                                                    \
     int iy = (PY);                                                                     \
@@ -2024,34 +2063,34 @@ __global__ __launch_bounds__(256) void wgrad_small_win_kernel(const WGradP p, in
     }                                                                                  \
   }
 #pragma unroll
-    for (int r = 0; r < KS; ++r) HIM_SW_ROW(y0 - pad + r, win[r])
-    float gv[MM], gn[MM];   // dy of this row / of the next one (loaded a step ahead: one resident wave pair per SIMD
-#pragma unroll           // cannot hide a load that is consumed right away)
+    for (int r = 0; r < TR; ++r) HIM_SW_ROW(y0 - padr + r, win[r])
+    float gv[MM], gn[MM];   // dy of this row / of the next one (loaded a step ahead)
+#pragma unroll
     for (int m = 0; m < MM; ++m) {
       const float v = g[(size_t)m * HW + y0 * W];
       gn[m] = lane_on ? v : 0.f;
     }
     float nxt[KS], nx2[KS];   // x rows entering the window one / two steps from now
-    HIM_SW_ROW(y0 + 1 + pad, nxt)
-    for (int pyb = y0; pyb < y1; pyb += KS) {
+    HIM_SW_ROW(y0 - padr + TR, nxt)
+    for (int pyb = y0; pyb < y1; pyb += TR) {
 #pragma unroll
-      for (int ph = 0; ph < KS; ++ph) {
+      for (int ph = 0; ph < TR; ++ph) {
         const int py = pyb + ph;
         if (py < y1) {
-          HIM_SW_ROW(py + 2 + pad, nx2)
+          HIM_SW_ROW(py - padr + TR + 1, nx2)
 #pragma unroll
           for (int m = 0; m < MM; ++m) {
             gv[m] = gn[m];
             const float v = g[(size_t)m * HW + min(py + 1, H - 1) * W];
             gn[m] = lane_on ? v : 0.f;
           }
-          // x row (py - pad + th) sits in logical slot th = physical (th + ph) % KS
+          // x row (py - padr + th) sits in logical slot th = physical (th + ph) % TR
 #pragma unroll
-          for (int th = 0; th < KS; ++th)
+          for (int th = 0; th < TR; ++th)
 #pragma unroll
             for (int tw = 0; tw < KS; ++tw)
 #pragma unroll
-              for (int m = 0; m < MM; ++m) acc[m][th * KS + tw] = fmaf(gv[m], win[(th + ph) % KS][tw], acc[m][th * KS + tw]);
+              for (int m = 0; m < MM; ++m) acc[m][th * KS + tw] = fmaf(gv[m], win[(th + ph) % TR][tw], acc[m][th * KS + tw]);
 #pragma unroll
           for (int k = 0; k < KS; ++k) {
             win[ph][k] = nxt[k];
@@ -2066,10 +2105,12 @@ __global__ __launch_bounds__(256) void wgrad_small_win_kernel(const WGradP p, in
 #pragma unroll
   for (int m = 0; m < MM; ++m)
 #pragma unroll
-    for (int t = 0; t < KK; ++t) {
-      const float sm = wave_sum_dpp(acc[m][t]);
-      if (lane == 63) out[(size_t)m * p.Np + t] = sm;
-    }
+    for (int th = 0; th < TR; ++th)
+#pragma unroll
+      for (int tw = 0; tw < KS; ++tw) {
+        const float sm = wave_sum_dpp(acc[m][th * KS + tw]);
+        if (lane == 63 && th >= own0) out[(size_t)m * p.Np + (th0 + th) * KS + tw] = sm;
+      }
 }
 
 static const int SMALL_WIN_SLOTS = 256;
@@ -2093,7 +2134,7 @@ static size_t wgrad_slab_bytes(int M, int C, int KH, int KW, int Kdim, size_t wi
   if (wino_floats) return ((wino_floats * sizeof(float) + 255) / 256) * 256;
   if (small_wgrad_ok(M, KH, KW) || (M <= 4 && KH == KW && KH == 5)) {
     slabs = (size_t)std::max(small_wgrad_slices(C, Kdim), SMALL_WIN_SLOTS) * M * Np * sizeof(float);
-  } else if (wgrad_fast_ok(M, C, 1, 4) && Kdim % 4 == 0) {  /* upper bound; the runner re-checks OH*OW */
+  } else if (wgrad_fast_ok(M, C, 1, 4)) {  /* upper bound; the runner re-checks OH*OW */
     int BM, BN, sp;
     wgrad_fast_cfg(M, C, Kdim, KH * KW, &BM, &BN, &sp);
     slabs = (size_t)sp * M * Np * sizeof(float);
@@ -2175,8 +2216,10 @@ static int run_wgrad(const float* dy, const float* x, float* dw, int M, int C, i
     const bool refl = pad_mode == HIM_PAD_REFLECT;
 #define HIM_SWK(MMv, KSv)                                                                                         \
   if (M == MMv && KH == KSv) {                                                                                    \
-    if (refl) hipLaunchKernelGGL((wgrad_small_win_kernel<MMv, KSv, true>), grid, block, 0, st, p, nsx, nyc, rows_per, ntasks); \
-    else hipLaunchKernelGGL((wgrad_small_win_kernel<MMv, KSv, false>), grid, block, 0, st, p, nsx, nyc, rows_per, ntasks);     \
+    constexpr int TRv = (MMv * KSv * KSv > 90) ? (KSv + 1) / 2 : KSv;  /* band split once the accumulators pass ~90 */ \
+    const dim3 gridz(grid.x, grid.y, cdiv(KSv, TRv));                                                             \
+    if (refl) hipLaunchKernelGGL((wgrad_small_win_kernel<MMv, KSv, TRv, true>), gridz, block, 0, st, p, nsx, nyc, rows_per, ntasks); \
+    else hipLaunchKernelGGL((wgrad_small_win_kernel<MMv, KSv, TRv, false>), gridz, block, 0, st, p, nsx, nyc, rows_per, ntasks);     \
   }
     HIM_SWK(1, 3) HIM_SWK(2, 3) HIM_SWK(3, 3) HIM_SWK(4, 3)
     HIM_SWK(1, 5) HIM_SWK(2, 5) HIM_SWK(3, 5) HIM_SWK(4, 5)
@@ -2227,10 +2270,15 @@ static int run_wgrad(const float* dy, const float* x, float* dw, int M, int C, i
     p.out = (float*)ws;
     dim3 grid(p.Np / fBN, cdiv(M, fBM), fs), block(256);
     const bool refl = pad_mode == HIM_PAD_REFLECT;
-#define HIM_WF(TMv, TNv)                                                                      \
-  {                                                                                           \
-    if (refl) hipLaunchKernelGGL((wgrad_fast_kernel<TMv, TNv, true>), grid, block, 0, st, p);  \
-    else hipLaunchKernelGGL((wgrad_fast_kernel<TMv, TNv, false>), grid, block, 0, st, p);      \
+#define HIM_WF(TMv, TNv)                                                                              \
+  {                                                                                                   \
+    if ((OH * OW) % 4 == 0) {                                                                         \
+      if (refl) hipLaunchKernelGGL((wgrad_fast_kernel<TMv, TNv, true, true>), grid, block, 0, st, p);  \
+      else hipLaunchKernelGGL((wgrad_fast_kernel<TMv, TNv, false, true>), grid, block, 0, st, p);      \
+    } else {                                                                                          \
+      if (refl) hipLaunchKernelGGL((wgrad_fast_kernel<TMv, TNv, true, false>), grid, block, 0, st, p); \
+      else hipLaunchKernelGGL((wgrad_fast_kernel<TMv, TNv, false, false>), grid, block, 0, st, p);     \
+    }                                                                                                 \
   }
     if (fBM == 128 && fBN == 128) HIM_WF(2, 2)
     else if (fBM == 128) HIM_WF(2, 1)

@@ -19,6 +19,9 @@ def pytest_collection_modifyitems(config, items):
     except Exception:
         has_gpu = False
     if has_gpu:
+        # the CPU oracle (torch/oneDNN) is 8x SLOWER on the GPU box's 128 hardware threads than on 16-32 of them
+        # (tools/cpu_thread_sweep.py: C1 step 0.8 s at 16-32 threads, 6-8 s at 128)
+        torch.set_num_threads(min(32, torch.get_num_threads()))
         return
     skip = pytest.mark.skip(reason='no GPU visible')
     for item in items:

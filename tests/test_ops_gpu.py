@@ -59,6 +59,10 @@ CONV_CASES = [
     (2, 64, 32, 32, 96, 1, 2, 0, 'zero', 'none'),        # ConvResnetBlock shortcut: 1x1 stride 2 (empty stride phases)
     (2, 16, 9, 11, 16, 1, 2, 0, 'zero', 'none'),         # 1x1 stride 2 on odd sizes
     (2, 70, 32, 32, 64, 7, 2, 3, 'zero', 'none'),        # box2mask stem conv7 stride 2
+    (3, 128, 8, 10, 256, 4, 1, 2, 'zero', 'none'),       # PatchGAN plane 9x11 = 99 (not a multiple of 4): fast wgrad, scalar dY quads
+    (2, 64, 7, 9, 64, 3, 1, 1, 'reflect', 'none'),       # odd plane 63 with reflect gather in the fast wgrad
+    (1, 8, 20, 70, 2, 7, 1, 3, 'zero', 'none'),          # tiny-M 7x7 wgrad, 2 outputs: filter-row band split (4 + 3 rows)
+    (2, 8, 12, 66, 4, 7, 1, 3, 'reflect', 'none'),       # tiny-M 7x7 wgrad, 4 outputs, reflect, two column strips
 ]
 
 
@@ -355,12 +359,16 @@ def test_winograd_conv3x3_fwd_bwd(case):
     ops = _ops()
     B, Cin, H, W, Cout, pm = case
     tol = 2e-5 if Cin < 512 else 5e-5          # full-size reductions (K = 4608 / 9216): the general op tolerance
+    # full-size shapes: no activation -- among 4M outputs a handful land within rounding of 0, their ReLU decision flips
+    # between two fp32 summation orders and moves the data gradient by O(|gy * w|) there (seen: 1e-2 of max|ref|); the
+    # activation backward itself is covered by the small cases
+    act = 'relu' if Cin < 512 else 'none'
     prev = ops.set_winograd_min_channels(16)
     try:
         x = _rand(B, Cin, H, W, seed=1).requires_grad_(True)
         w = _rand(Cout, Cin, 3, 3, seed=2, scale=(Cin * 9) ** -0.5).requires_grad_(True)
         b = _rand(Cout, seed=3, scale=0.1).requires_grad_(True)
-        y_ref = _ref_conv(x, w, b, 1, 1, pm, 'relu')
+        y_ref = _ref_conv(x, w, b, 1, 1, pm, act)
         gy = _rand(*y_ref.shape, seed=4)
         gx_ref, gw_ref, gb_ref = torch.autograd.grad(y_ref, (x, w, b), gy)
         xd, bd = (t.detach().to(DEV).requires_grad_(True) for t in (x, b))
@@ -368,7 +376,7 @@ def test_winograd_conv3x3_fwd_bwd(case):
             wd = w.detach().to(DEV).requires_grad_(True)
             if as_param:
                 wd = torch.nn.Parameter(wd.detach())
-            y = ops.conv2d(xd, wd, bd, 1, 1, pm, 'relu', 0.2)
+            y = ops.conv2d(xd, wd, bd, 1, 1, pm, act, 0.2)
             assert_close('wino fwd', y, y_ref, rtol=tol)
             gx, gw, gb = torch.autograd.grad(y, (xd, wd, bd), gy.to(DEV))
             assert_close('wino dgrad', gx, gx_ref, rtol=tol)
