@@ -220,6 +220,13 @@ int him_add(const float* a, const float* b, float* out, size_t n, void* stream);
  * [c0, c0+n) of a (B,Ctot,H,W) destination so torch.cat never materialises.
  * ------------------------------------------------------------------------------------------- */
 int him_onehot(const float* label, float* dst, int B, int label_nc, int Ctot, int c0, int hw, void* stream);
+/* Compact inputs: label / instance maps travel as uint8 ids (1 byte per pixel over PCIe instead of the
+ * float maps of data/segmentation_dataset.py:82) and are widened on the device; get_masked_image of
+ * data/base_dataset.py:342-357 for a whole batch: bbox[b] = (wmin, hmin, wmax, hmax) floats on the device;
+ * mask (B,1,H,W), masked_object = mask*image, masked_context = (1-mask)*image + mask*cls2fill (any output may be NULL). */
+int him_u8_to_f32(const unsigned char* src, float* dst, size_t n, void* stream);
+int him_masked_image(const float* image, const float* bbox, float* mask, float* masked_object, float* masked_context,
+                     int B, int C, int H, int W, float cls2fill, void* stream);
 int him_edges(const float* inst, float* dst, int B, int H, int W, int Ctot, int c0, void* stream);
 /* per-image masked mean colour, times noise (B,3) (NULL = 1), clamped to [-1,1]  -> emb (B,3) */
 int him_masked_mean(const float* image, const float* obj_mask, const float* noise, float* emb, int B,

@@ -82,6 +82,8 @@ _SIGS = {
     'him_act_bwd': (c_int, [P, P, P, c_size_t, c_int, c_float, P]),
     'him_add': (c_int, [P, P, P, c_size_t, P]),
     'him_onehot': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'him_u8_to_f32': (c_int, [P, P, c_size_t, P]),
+    'him_masked_image': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     'him_edges': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'him_masked_mean': (c_int, [P, P, P, P, c_int, c_int, P]),
     'him_tile_embed': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),

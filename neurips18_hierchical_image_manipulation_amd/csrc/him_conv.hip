@@ -25,352 +25,7 @@
 
 namespace him {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-#define PAD_DFOLD 2  // internal pad mode of the fast kernel (see gconv_fast_kernel), never part of the C ABI
-typedef const __attribute__((address_space(1))) char* gchar_p;    // explicit global address space: keeps
-typedef const __attribute__((address_space(1))) float* gfloat_p;  // global_load (not flat_load) after asm laundering
-
-// ==============================================================================================
-// gconv
-// ==============================================================================================
-struct GPhase {
-  const float* A;  // [M][K] row-major
-  int K;           // C2*JH*JW
-  int JH, JW;
-  FastDiv fJHJW, fJW;
-  int NA, NC;      // output sub-grid of this phase
-  int oy0, ox0;    // dest origin (dest y = oy0 + oys*a)
-  int offy, offx;  // source origin (src y = a*sy + jh*dy + offy)
-  // fast path: weights regrouped tap-major, channel-padded: At[m][(jh*JW + jw)*C2p + c2]
-  const float* At;
-  int C2p;
-};
-
-struct GConvP {
-  const float* src;   // [B][C2][SH][SW]
-  float* dst;         // [B][M][DH][DW]
-  const float* bias;  // [M] or null
-  int M, C2, B, SH, SW, DH, DW;
-  int oys, oxs, sy, sx, dy, dx;
-  int pad_mode, act;
-  float slope;
-  int nphase;
-  int fast;  // 1: ph[].At valid -> gconv_fast_kernel
-  float* kpart;       // fast path split-K: [ksplit] slabs shaped like dst (raw sums; bias/act in gconv_splitk_finish)
-  int ksplit;
-  int kno_finish;     // the caller sums the split-K slabs itself (reflection fold)
-  float* small_part;  // tiny-M path: [nsplit][M][Ntot] partial sums when the channels are split over grid.y
-  int small_nsplit;
-  int wbatch;         // fast path, batched weights (Winograd): image b reads the panel At + b*wbatch floats; needs
-                      // plane % BN == 0 so that a tile never straddles two images
-  GPhase ph[4];
-};
-
-// =============================================================================================
-// gconv, fast path (C2 >= 16): the reduction index runs TAP-MAJOR, k' = (jh*JW + jw)*C2p + c2, so one K-step of
-// 16 holds 16 channels of ONE filter tap.  The gather address is then (per-thread tap offset, computed once per
-// K-step) + (wave-uniform channel offset folded into the scalar base) = one global_load per element, and the
-// weight tile is plain contiguous float4s.  LDS rows are [row][16 k + 4 pad]; with the k <-> (lane>>5) pairing
-// k = 8*(lane>>5) + kp each lane's 8 operands of a K-step are two aligned ds_read_b128 (conflict-free at stride 20
-// dwords), and the tile writes are ds_write_b128 as well.  ~2 non-MFMA instructions per MFMA instead of ~19.
-// =============================================================================================
-// PM: 0 zero padding, 1 reflection gather (forward of a reflect-padded conv), 2 = PAD_DFOLD: data gradient of a
-// reflect-pad-1 3x3 stride-1 conv read from the border-extended gradient built by reflect_extend_kernel (below).
-template <int WM, int WN, int TM, int TN, int PM, bool CLAMPC>
-__global__ __launch_bounds__(WM * WN * 64, (TN == 4 ? 2 : 1)) void gconv_fast_kernel(const GConvP p) {
-  constexpr int NT = WM * WN * 64;  // 4 waves (one per SIMD) or 8 waves (two per SIMD: they cover each other's LDS/barrier bubbles)
-  constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 16, LD = 20;
-  constexpr int A_V4 = BM * BK / 4 / NT;  // float4 loads per thread for the weight tile
-  constexpr int AROWS = NT / 4;           // weight-tile rows covered per pass
-  constexpr int KPT = BK * BN / NT;       // consecutive channels per thread in the gathered tile (8 or 4)
-  static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
-  static_assert((A_V4 == 1 || A_V4 == 2) && (KPT == 4 || KPT == 8 || KPT == 16), "tile shape");
-  __shared__ __attribute__((aligned(16))) float sA[2][BM * LD];
-  __shared__ __attribute__((aligned(16))) float sB[2][BN * LD];
-
-  const GPhase& ph = p.ph[blockIdx.z];
-  const int plane = ph.NA * ph.NC;
-  const int Ntot = p.B * plane;
-  // XCD-aware tile order: workgroup L runs on XCD L % 8 (observed dispatch; speed only, never correctness), so give
-  // each XCD a CONTIGUOUS run of m-major tiles: its 32 CUs then share one weight panel through their private L2.
-  int m0, n0;
-  {
-    const int nmt = (p.M + BM - 1) / BM, nnt = gridDim.x / nmt;
-    const int total = nmt * nnt, L = blockIdx.x;
-    const int q = total >> 3, r = total & 7, xcd = L & 7, slot = L >> 3;
-    const int T = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    if (p.wbatch) {  // image-major: one XCD works through whole (panel, image) pairs
-      const int ntp = plane / BN, per = nmt * ntp;
-      const int img = T / per, rem = T - img * per;
-      const int mt = rem / ntp;
-      m0 = mt * BM;
-      n0 = img * plane + (rem - mt * ntp) * BN;
-    } else {
-      const int mt = T / nnt;
-      m0 = mt * BM;
-      n0 = (T - mt * nnt) * BN;
-    }
-  }
-  if (n0 >= Ntot) return;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const float* __restrict__ At = ph.At + (p.wbatch ? (size_t)(n0 / plane) * p.wbatch : 0);
-  const float* __restrict__ src = p.src;
-  const int C2 = p.C2, C2p = ph.C2p, CB = C2p / BK;
-  const int JW = ph.JW, JH = ph.JH;
-  const int nk_all = JH * JW * CB;
-  const uint32_t Kp = (uint32_t)nk_all * BK;
-  // split-K (grid.y): this workgroup reduces K-steps [kt0, kt0 + nk); two half-K workgroups per CU run out of phase
-  // and cover each other's LDS/barrier bubbles when the launch has only ~one output tile per CU
-  const int ksplit = gridDim.y;
-  const int kt0 = (int)(((long long)nk_all * blockIdx.y) / ksplit);
-  const int nk = (int)(((long long)nk_all * (blockIdx.y + 1)) / ksplit) - kt0;
-
-  // weight tile: thread -> (row = t/4 + AROWS i, k quad = t%4)
-  const int arow = t >> 2, akq = t & 3;
-  uint32_t aoff[A_V4];
-#pragma unroll
-  for (int i = 0; i < A_V4; ++i) aoff[i] = (uint32_t)min(m0 + arow + i * AROWS, p.M - 1) * Kp + akq * 4;
-
-  // gathered tile: thread -> (column nl, channel group kg)
-  const int nl = t % BN;
-  const int kg = __builtin_amdgcn_readfirstlane(t / BN);
-  const int n = min(n0 + nl, Ntot - 1);
-  const int b = n / plane;
-  const int rr = n - b * plane;
-  const int a = rr / ph.NC;
-  const int c = rr - a * ph.NC;
-  const int by = a * p.sy + ph.offy, bx = c * p.sx + ph.offx;
-  const int SH = p.SH, SW = p.SW;
-  const uint32_t SHSW = (uint32_t)SH * SW;
-  const uint32_t boff = (uint32_t)b * C2 * SHSW;
-  const int ddy = p.dy, ddx = p.dx;
-  // Two register sets (X, Y): tile kt+2 is in flight into one while tile kt+1 (landed an iteration ago) is written to
-  // LDS from the other -> two full MFMA blocks (~4k cycles) of cover for HBM/MALL latency.
-  float4 xa0, xa1, ya0, ya1;
-  float xb[KPT], yb[KPT];
-  xa1 = ya1 = make_float4(0.f, 0.f, 0.f, 0.f);
-  // wave-uniform cursor of the tile being loaded: (channel block, tap row, tap col), starting at K-step kt0
-  int c_cb = kt0 / (JH * JW);
-  int c_jh = (kt0 - c_cb * JH * JW) / JW;
-  int c_jw = kt0 - c_cb * JH * JW - c_jh * JW;
-  const char* __restrict__ Atb = (const char*)At + (size_t)kt0 * (BK * 4);
-  const char* __restrict__ srcb = (const char*)src;
-  const size_t chan_bytes = (size_t)SHSW * 4;
-
-  // issue the global loads of tile kt (weights: contiguous float4; gather: one load per element with the channel
-  // offset folded into the wave-uniform base pointer -> "global_load v, v_off, s[base]" addressing, no 64-bit VALU)
-#define HIM_LOAD_TILE(kt_, RA0, RA1, RB, ROK)                                                                \
-  {                                                                                                          \
-    const uint32_t kbyte = (uint32_t)(kt_) * (BK * 4);                                                        \
-    RA0 = *(const float4*)(Atb + (aoff[0] * 4u + kbyte));                                                    \
-    if (A_V4 > 1) RA1 = *(const float4*)(Atb + (aoff[A_V4 - 1] * 4u + kbyte));                               \
-    HIM_GATHER(by, bx, RB, ROK)                                                                              \
-  }
-  // one gather pass: tap coordinates once per K-step, then one saddr load per channel.  The loaded values stay RAW
-  // in registers; the padding predicate (one per thread and tile) is applied when the tile is written to LDS a K-step
-  // later -- a select right behind the loads makes the compiler wait for them on the spot (s_waitcnt vmcnt(0) a few
-  // instructions after issue, measured in the round-1 ISA), which exposed the whole memory latency in every K-step.
-#define HIM_GATHER(YY, XX, RBC, ROK)                                                                      \
-  {                                                                                                          \
-    int iy = (YY) + c_jh * ddy, ix = (XX) + c_jw * ddx;                                                       \
-    bool ok = true;                                                                                          \
-    if (PM == 2) {                                                                                           \
-      const int Hh = SH - 2, Ww = SW - 2; /* rows/cols Hh, Hh+1 / Ww, Ww+1 hold the pre-summed mirror pairs */ \
-      ok = iy >= 0 && iy < Hh && ix >= 0 && ix < Ww;                                                          \
-      iy = (c_jh == 0 && iy == 2) ? Hh : iy;                                                                 \
-      iy = (c_jh == 2 && iy == Hh - 3) ? Hh + 1 : iy;                                                        \
-      ix = (c_jw == 0 && ix == 2) ? Ww : ix;                                                                 \
-      ix = (c_jw == 2 && ix == Ww - 3) ? Ww + 1 : ix;                                                        \
-      iy = min(max(iy, 0), SH - 1);                                                                          \
-      ix = min(max(ix, 0), SW - 1);                                                                          \
-    } else if (PM == 1) {                                                                                    \
-      iy = iy < 0 ? -iy : iy;                                                                                \
-      iy = iy >= SH ? 2 * (SH - 1) - iy : iy;                                                                \
-      ix = ix < 0 ? -ix : ix;                                                                                \
-      ix = ix >= SW ? 2 * (SW - 1) - ix : ix;                                                                \
-    } else {                                                                                                 \
-      const int cy = min(max(iy, 0), SH - 1), cx = min(max(ix, 0), SW - 1);                                  \
-      ok = (cy == iy) && (cx == ix);                                                                         \
-      iy = cy;                                                                                               \
-      ix = cx;                                                                                               \
-    }                                                                                                        \
-    const uint32_t tapbyte = (boff + (uint32_t)iy * (uint32_t)SW + (uint32_t)ix) * 4u;                        \
-    const int c0 = c_cb * BK + kg * KPT;                                                                     \
-    gchar_p sp = (gchar_p)srcb + (size_t)(CLAMPC ? min(c0, C2 - 1) : c0) * chan_bytes;                       \
-    _Pragma("unroll") for (int i = 0; i < KPT; ++i) {                                                        \
-      asm volatile("" : "+s"(sp)); /* keep the wave-uniform base in SGPRs: saddr + 32-bit voffset load */    \
-      RBC[i] = *(gfloat_p)(sp + tapbyte);                                                                    \
-      sp += (CLAMPC && c0 + i + 1 > C2 - 1) ? 0 : chan_bytes;                                                \
-    }                                                                                                        \
-    ROK = ok;                                                                                                \
-  }
-#define HIM_STORE_TILE(buf_, RA0, RA1, RB, ROK)                                                               \
-  {                                                                                                          \
-    *(float4*)&sA[buf_][arow * LD + akq * 4] = RA0;                                                          \
-    if (A_V4 > 1) *(float4*)&sA[buf_][(arow + AROWS) * LD + akq * 4] = RA1;                                  \
-    const bool okst = (PM == 1) || ROK;                                                                      \
-    _Pragma("unroll") for (int q = 0; q < KPT / 4; ++q) *(float4*)&sB[buf_][nl * LD + kg * KPT + q * 4] =     \
-        make_float4(okst ? RB[q * 4] : 0.f, okst ? RB[q * 4 + 1] : 0.f, okst ? RB[q * 4 + 2] : 0.f,           \
-                    okst ? RB[q * 4 + 3] : 0.f);                                                             \
-  }
-  // reduction order: channel block OUTER, filter taps INNER -- the JH*JW taps of a 16-channel block are consecutive
-  // K-steps, so the gathered activations are re-read from L1/L2 instead of once per tap from the Infinity Cache
-  // (tap-outer measured 1.2 GB of L2-side fetch per ResnetBlock launch = 9x the input per XCD).
-#define HIM_ADVANCE()                \
-  {                                  \
-    ++c_jw;                          \
-    const bool w1 = c_jw == JW;      \
-    c_jw = w1 ? 0 : c_jw;            \
-    c_jh += w1 ? 1 : 0;              \
-    const bool w2 = c_jh == JH;      \
-    c_jh = w2 ? 0 : c_jh;            \
-    c_cb += w2 ? 1 : 0;              \
-  }
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int l31 = lane & 31, lh = lane >> 5;
-  bool xok = true, yok = true;   // padding predicates of the tiles held in the two register sets
-  HIM_LOAD_TILE(0, xa0, xa1, xb, xok)
-  HIM_STORE_TILE(0, xa0, xa1, xb, xok)
-  if (nk > 1) HIM_ADVANCE()
-  HIM_LOAD_TILE(min(1, nk - 1), ya0, ya1, yb, yok)   // tile 1 stays in flight in set Y
-  __syncthreads();
-
-  // one K-step: prefetch tile kt+2 into (LA0,LA1,LB), run the MFMAs of tile kt from LDS buffer kt&1, write tile kt+1
-  // (SA0,SA1,SB) into the other buffer.  Past-the-end tiles are clamped re-loads that are never consumed.
-#define HIM_KSTEP(kt_, LA0, LA1, LB, LOK, SA0, SA1, SB, SOK)                                                          \
-  {                                                                                                          \
-    const int buf = (kt_) & 1;                                                                               \
-    if ((kt_) + 2 < nk) HIM_ADVANCE()                                                                        \
-    const float4* __restrict__ pa = (const float4*)&sA[buf][(wm * TM * 32 + l31) * LD + lh * 8];            \
-    const float4* __restrict__ pb = (const float4*)&sB[buf][(wn * TN * 32 + l31) * LD + lh * 8];            \
-    float4 a0[TM], a1[TM], b0[TN], b1[TN];                                                                   \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                         \
-      a0[i] = pa[i * 32 * LD / 4];                                                                           \
-      a1[i] = pa[i * 32 * LD / 4 + 1];                                                                       \
-    }                                                                                                        \
-    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                         \
-      b0[j] = pb[j * 32 * LD / 4];                                                                           \
-      b1[j] = pb[j * 32 * LD / 4 + 1];                                                                       \
-    }                                                                                                        \
-    HIM_LOAD_TILE(min((kt_) + 2, nk - 1), LA0, LA1, LB, LOK)                                                 \
-    HIM_MFMA_STEP(a0[i].x, b0[j].x)                                                                          \
-    HIM_MFMA_STEP(a0[i].y, b0[j].y)                                                                          \
-    HIM_MFMA_STEP(a0[i].z, b0[j].z)                                                                          \
-    HIM_MFMA_STEP(a0[i].w, b0[j].w)                                                                          \
-    HIM_MFMA_STEP(a1[i].x, b1[j].x)                                                                          \
-    HIM_MFMA_STEP(a1[i].y, b1[j].y)                                                                          \
-    HIM_MFMA_STEP(a1[i].z, b1[j].z)                                                                          \
-    HIM_MFMA_STEP(a1[i].w, b1[j].w)                                                                          \
-    HIM_STORE_TILE(buf ^ 1, SA0, SA1, SB, SOK)                                                               \
-    __syncthreads();                                                                                         \
-  }
-#define HIM_MFMA_STEP(AX, BX)                                                                                 \
-  _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] =   \
-      __builtin_amdgcn_mfma_f32_32x32x2f32(AX, BX, acc[i][j], 0, 0, 0);
-
-  int kt = 0;
-  for (; kt + 1 < nk; kt += 2) {
-    HIM_KSTEP(kt, xa0, xa1, xb, xok, ya0, ya1, yb, yok)
-    HIM_KSTEP(kt + 1, ya0, ya1, yb, yok, xa0, xa1, xb, xok)
-  }
-  if (kt < nk) HIM_KSTEP(kt, xa0, xa1, xb, xok, ya0, ya1, yb, yok)
-#undef HIM_MFMA_STEP
-#undef HIM_KSTEP
-#undef HIM_ADVANCE
-#undef HIM_LOAD_TILE
-#undef HIM_GATHER
-#undef HIM_STORE_TILE
-
-
-  const int act = p.act;
-  const float slope = p.slope;
-  const bool partial = ksplit > 1;
-  float* __restrict__ dstbase = partial ? p.kpart + (size_t)blockIdx.y * p.B * p.M * p.DH * p.DW : p.dst;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int nn = n0 + wn * TN * 32 + j * 32 + l31;
-    if (nn >= Ntot) continue;
-    const int bb = nn / plane;
-    const int r2 = nn - bb * plane;
-    const int aa = r2 / ph.NC, cc = r2 - aa * ph.NC;
-    const int oy = ph.oy0 + p.oys * aa, ox = ph.ox0 + p.oxs * cc;
-    float* __restrict__ out = dstbase + ((size_t)bb * p.M * p.DH + oy) * p.DW + ox;
-    const size_t mstride = (size_t)p.DH * p.DW;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m < p.M) {
-          float v = acc[i][j][r];
-          if (!partial) {
-            if (p.bias) v += p.bias[m];
-            v = apply_act(v, act, slope);
-          }
-          out[(size_t)m * mstride] = v;
-        }
-      }
-    }
-  }
-}
-
-// dst = act(sum_z kpart[z] + bias[channel])  (fixed order)
-__global__ void gconv_splitk_finish_kernel(const float* __restrict__ part, float* __restrict__ dst,
-                                           const float* __restrict__ bias, long long n, int ksplit, int M, int plane,
-                                           int act, float slope) {
-  if ((n & 3) == 0 && (plane & 3) == 0) {
-    const float4* __restrict__ p4 = (const float4*)part;
-    float4* __restrict__ d4 = (float4*)dst;
-    const long long n4 = n >> 2;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
-         i += (long long)gridDim.x * blockDim.x) {
-      float4 v = p4[i];
-      for (int z = 1; z < ksplit; ++z) {
-        const float4 w = p4[(size_t)z * n4 + i];
-        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
-      }
-      const float bb = bias ? bias[(int)(((i << 2) / plane) % M)] : 0.f;
-      v.x = apply_act(v.x + bb, act, slope);
-      v.y = apply_act(v.y + bb, act, slope);
-      v.z = apply_act(v.z + bb, act, slope);
-      v.w = apply_act(v.w + bb, act, slope);
-      d4[i] = v;
-    }
-    return;
-  }
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (long long)gridDim.x * blockDim.x) {
-    float v = 0.f;
-    for (int z = 0; z < ksplit; ++z) v += part[(size_t)z * n + i];
-    if (bias) v += bias[(int)((i / plane) % M)];
-    dst[i] = apply_act(v, act, slope);
-  }
-}
-
-template <int WM, int WN, int TM, int TN>
-static void launch_fast_cfg(const GConvP& p, dim3 grid, hipStream_t st) {
-  const bool clampc = (p.C2 % 16) != 0;
-  const dim3 blk(WM * WN * 64);
-  if (p.pad_mode == PAD_DFOLD) {
-    if (clampc) hipLaunchKernelGGL((gconv_fast_kernel<WM, WN, TM, TN, 2, true>), grid, blk, 0, st, p);
-    else hipLaunchKernelGGL((gconv_fast_kernel<WM, WN, TM, TN, 2, false>), grid, blk, 0, st, p);
-  } else if (p.pad_mode == HIM_PAD_REFLECT) {
-    if (clampc) hipLaunchKernelGGL((gconv_fast_kernel<WM, WN, TM, TN, 1, true>), grid, blk, 0, st, p);
-    else hipLaunchKernelGGL((gconv_fast_kernel<WM, WN, TM, TN, 1, false>), grid, blk, 0, st, p);
-  } else {
-    if (clampc) hipLaunchKernelGGL((gconv_fast_kernel<WM, WN, TM, TN, 0, true>), grid, blk, 0, st, p);
-    else hipLaunchKernelGGL((gconv_fast_kernel<WM, WN, TM, TN, 0, false>), grid, blk, 0, st, p);
-  }
-}
+#include "him_gconv_fast.inc"
 
 // ---- weight regrouping for the fast path: out[m][cb][jh][jw][c16] = W[base + m*sm + (16cb+c16)*sc + jh*sh + jw*sw]
 struct WT2Phase {
@@ -824,6 +479,9 @@ static int launch_gconv(const GConvP& p, hipStream_t st) {
   if (maxN == 0 || p.M <= 0) return HIM_OK;
   if (launch_gconv_small(p, maxN, st)) return check_launch("gconv_small");
   if (p.fast) {
+    // the fast kernel gathers through a buffer resource: 31-bit byte offsets (larger tensors: split the batch)
+    if ((unsigned long long)p.B * p.C2 * p.SH * p.SW * 4ull >= (1ull << 31))
+      return fail(HIM_E_UNSUPPORTED, "conv: source tensor of %llu bytes >= 2 GiB", (unsigned long long)p.B * p.C2 * p.SH * p.SW * 4ull);
     static int tile_override = -2;
     if (tile_override == -2) tile_override = getenv("HIM_GCONV_TILE") ? atoi(getenv("HIM_GCONV_TILE")) : -1;
     const int ks = p.ksplit > 1 ? p.ksplit : 1;
@@ -1656,44 +1314,45 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WGradP p) {
   // gathered tile: thread -> (k = t%32, row group rg = t/32; rows rg + 8 i)
   const int kkl = t & 31, rg = t >> 5;
 
-  const char* __restrict__ dyc = (const char*)p.dy;
-  gchar_p xbase = (gchar_p)p.x + (size_t)(ci0) * HW * 4;
-  const size_t step8 = (size_t)8 * HW * 4;
+  // Both operands are read through BUFFER resources: an invalid element (K tail beyond kend, zero-padding tap) gets
+  // voffset 0x80000000 and the range check returns 0.0 -- no select sits between a load and its ds_write, so nothing
+  // makes the compiler wait for a load before the K-step's MFMAs have run (run_wgrad guarantees both tensors < 2 GiB).
+  const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.dy, 0, (int)((uint32_t)p.B * (uint32_t)p.M * (uint32_t)OHW * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.x, 0, (int)((uint32_t)p.B * (uint32_t)C * (uint32_t)HW * 4u), 0x00020000);
+  const uint32_t xbase = (uint32_t)ci0 * (uint32_t)HW * 4u;   // wave-uniform: first channel of the tile
+  const uint32_t step8 = 8u * (uint32_t)HW * 4u;
 
   float4 ra[A_V4];
   float rb[RB];
-  bool raok[4] = {false, false, false, false}, rbok = false;
   // per-thread cursors of the NEXT tile: A quad position and gather position, as (image, offset in image)
   int ka = kbeg + akq * 4, ba = ka / OHW, spa = ka - ba * OHW;
   int kb = kbeg + kkl, bb = kb / OHW, spb = kb - bb * OHW;
 
 #define HIM_WLOAD()                                                                                           \
   {                                                                                                           \
-    const bool av = ka < kend;                                                                                \
-    if (AL4) raok[0] = raok[1] = raok[2] = raok[3] = av;                                                      \
-    const uint32_t abase = av ? ((uint32_t)ba * (uint32_t)p.M * (uint32_t)OHW + (uint32_t)spa) : 0u;            \
     if (AL4) {                                                                                                \
+      const bool av = ka < kend;                                                                              \
+      const uint32_t abase = (uint32_t)ba * (uint32_t)p.M * (uint32_t)OHW + (uint32_t)spa;                     \
       _Pragma("unroll") for (int i = 0; i < A_V4; ++i) {                                                      \
-        ra[i] = *(const float4*)(dyc + (size_t)(abase + arowoff[i]) * 4);                                     \
+        ra[i] = __builtin_bit_cast(                                                                            \
+            float4, __builtin_amdgcn_raw_buffer_load_b128(rdy, av ? (abase + arowoff[i]) * 4u : 0x80000000u, 0, 0)); \
       }                                                                                                       \
     } else { /* plane size not a multiple of 4 (odd PatchGAN planes): a quad may straddle two images */        \
       uint32_t eo[4];                                                                                         \
-      bool ev[4];                                                                                             \
-      (void)ev;                                                                                               \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
         int sp_ = spa + j, b_ = ba;                                                                           \
         const bool wrap = sp_ >= OHW;                                                                         \
         sp_ -= wrap ? OHW : 0;                                                                                \
         b_ += wrap ? 1 : 0;                                                                                   \
-        ev[j] = ka + j < kend;                                                                                \
-        eo[j] = ev[j] ? ((uint32_t)b_ * (uint32_t)p.M * (uint32_t)OHW + (uint32_t)sp_) : 0u;                    \
-        raok[j] = ev[j];                                                                                      \
+        eo[j] = (ka + j < kend) ? ((uint32_t)b_ * (uint32_t)p.M * (uint32_t)OHW + (uint32_t)sp_) * 4u : 0x80000000u; \
       }                                                                                                       \
       _Pragma("unroll") for (int i = 0; i < A_V4; ++i) {                                                      \
         float q_[4];                                                                                          \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                       \
-          q_[j] = *(const float*)(dyc + (size_t)(eo[j] + arowoff[i]) * 4);                                   \
-        }                                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                         \
+          q_[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(                              \
+              rdy, eo[j] == 0x80000000u ? eo[j] : eo[j] + arowoff[i] * 4u, 0, 0));                             \
         ra[i] = make_float4(q_[0], q_[1], q_[2], q_[3]);                                                      \
       }                                                                                                       \
     }                                                                                                         \
@@ -1702,27 +1361,22 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WGradP p) {
     const int oh = (int)fdiv((uint32_t)sp, p.fOW);                                                            \
     const int ow = sp - oh * p.OW;                                                                            \
     int ih = oh * stride + dh, iw = ow * stride + dw;                                                         \
-    bool ok = true;                                                                                           \
+    bool ok = bv;                                                                                             \
     if (REFLECT) {                                                                                            \
       ih = ih < 0 ? -ih : ih;                                                                                 \
       ih = ih >= H ? 2 * (H - 1) - ih : ih;                                                                   \
       iw = iw < 0 ? -iw : iw;                                                                                 \
       iw = iw >= W ? 2 * (W - 1) - iw : iw;                                                                   \
     } else {                                                                                                  \
-      const int ch = min(max(ih, 0), H - 1), cw = min(max(iw, 0), W - 1);                                     \
-      ok = (ch == ih) && (cw == iw);                                                                          \
-      ih = ch;                                                                                                \
-      iw = cw;                                                                                                \
+      ok = ok && ih >= 0 && ih < H && iw >= 0 && iw < W;                                                      \
     }                                                                                                         \
-    const uint32_t voff = ((uint32_t)(bv ? bb : 0) * (uint32_t)C * (uint32_t)HW + (uint32_t)rg * (uint32_t)HW + \
-                           (uint32_t)ih * (uint32_t)W + (uint32_t)iw) * 4u;                                    \
-    gchar_p sp8 = xbase;                                                                                      \
+    const uint32_t voff = ok ? ((uint32_t)bb * (uint32_t)C * (uint32_t)HW + (uint32_t)rg * (uint32_t)HW +      \
+                                (uint32_t)ih * (uint32_t)W + (uint32_t)iw) * 4u : 0x80000000u;                 \
+    uint32_t so8 = xbase;                                                                                     \
     _Pragma("unroll") for (int i = 0; i < RB; ++i) {                                                          \
-      asm volatile("" : "+s"(sp8));                                                                           \
-      rb[i] = *(gfloat_p)(sp8 + voff); /* raw: the padding predicate is applied at the LDS store */          \
-      sp8 += step8;                                                                                           \
+      rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, voff, so8, 0));              \
+      so8 += step8;                                                                                           \
     }                                                                                                         \
-    rbok = ok; /* A is zero beyond kend, so bv needs no select */                                            \
     ka += BK;                                                                                                 \
     spa += BK;                                                                                                \
     while (spa >= OHW) {                                                                                      \
@@ -1738,11 +1392,8 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WGradP p) {
   }
 #define HIM_WSTORE(buf_)                                                                                       \
   {                                                                                                           \
-    /* padding / tail predicates are applied HERE, a whole K-step of MFMAs after the loads were issued: a select  \
-       right behind a load makes the compiler wait for it on the spot */                                        \
-    _Pragma("unroll") for (int i = 0; i < A_V4; ++i) *(float4*)&sA[buf_][(arow + 32 * i) * LD + akq * 4] =      \
-        make_float4(raok[0] ? ra[i].x : 0.f, raok[1] ? ra[i].y : 0.f, raok[2] ? ra[i].z : 0.f, raok[3] ? ra[i].w : 0.f); \
-    _Pragma("unroll") for (int i = 0; i < RB; ++i) sB[buf_][(rg + 8 * i) * LD + kkl] = rbok ? rb[i] : 0.f;     \
+    _Pragma("unroll") for (int i = 0; i < A_V4; ++i) *(float4*)&sA[buf_][(arow + 32 * i) * LD + akq * 4] = ra[i]; \
+    _Pragma("unroll") for (int i = 0; i < RB; ++i) sB[buf_][(rg + 8 * i) * LD + kkl] = rb[i];                 \
   }
 
   f32x16 acc[TM][TN];
@@ -1782,6 +1433,22 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WGradP p) {
     HIM_WM(3, x) HIM_WM(3, y) HIM_WM(3, z) HIM_WM(3, w)
 #undef HIM_WM
     HIM_WSTORE(buf ^ 1)
+    {
+      // K-step instruction order pinned with sched_group_barrier (as in gconv_fast_kernel): the 16 LDS operand reads,
+      // then the MFMA stream with the next tile's buffer loads dripped in, the LDS writes only after all but 6 MFMAs
+      // -- without it the compiler hoists the writes (and the s_waitcnt on the loads just issued) to the top.
+      constexpr int NV = (AL4 ? A_V4 : 4 * A_V4) + RB, NM = 16 * TM * TN, PER = (NM - 10) / NV;
+      __builtin_amdgcn_sched_group_barrier(0x100, 4 * (TM + TN), 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+#pragma unroll
+      for (int q_ = 0; q_ < NV; ++q_) {
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, NM - 2 - PER * NV - 6, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, A_V4 + RB, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+    }
     __syncthreads();
   }
 #undef HIM_WLOAD
@@ -2258,7 +1925,10 @@ static int run_wgrad(const float* dy, const float* x, float* dw, int M, int C, i
                        (const float*)ws, dw, n, slices, accumulate);
     return check_launch("slab_reduce");
   }
-  if (wgrad_fast_ok(M, C, OH, OW)) {
+  // the fast kernel reads both operands through buffer resources (31-bit byte offsets)
+  const bool fits31 = (unsigned long long)B * M * OH * OW * 4ull < (1ull << 31) &&
+                      (unsigned long long)B * C * H * W * 4ull < (1ull << 31);
+  if (wgrad_fast_ok(M, C, OH, OW) && fits31) {
     int fBM, fBN, fs;
     wgrad_fast_cfg(M, C, p.Kdim, KH * KW, &fBM, &fBN, &fs);
     const size_t need = (size_t)fs * M * p.Np * sizeof(float);

@@ -48,6 +48,35 @@ __global__ void onehot_kernel(const float* __restrict__ label, float* __restrict
   }
 }
 
+// compact label maps: uint8 ids (as stored on disk / sent over PCIe) -> the float id map the kernels read
+__global__ void u8_to_f32_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst, size_t n) {
+  GS_LOOP(i, n) dst[i] = (float)src[i];
+}
+
+// get_masked_image (reference data/base_dataset.py:342-357) for a batch: bbox[b] = (wmin, hmin, wmax, hmax) as floats;
+// mask = 1 inside the box (empty unless hmax > hmin and wmax > wmin), obj = mask * image,
+// ctx = (1 - mask) * image + mask * cls2fill.  Any of the three outputs may be NULL.
+__global__ void masked_image_kernel(const float* __restrict__ image, const float* __restrict__ bbox,
+                                    float* __restrict__ mask, float* __restrict__ obj, float* __restrict__ ctx, int B,
+                                    int C, int H, int W, float cls2fill) {
+  const long long total = (long long)B * C * H * W;
+  GS_LOOP(i, total) {
+    const int x = (int)(i % W);
+    long long r = i / W;
+    const int y = (int)(r % H);
+    r /= H;
+    const int c = (int)(r % C), b = (int)(r / C);
+    const int wmin = (int)bbox[b * 4 + 0], hmin = (int)bbox[b * 4 + 1], wmax = (int)bbox[b * 4 + 2],
+              hmax = (int)bbox[b * 4 + 3];
+    // python slice semantics of masked_tensor[0, hmin:hmax, wmin:wmax] for the non-negative boxes the samplers emit
+    const bool in = hmax > hmin && wmax > wmin && y >= hmin && y < hmax && x >= wmin && x < wmax;
+    const float m = in ? 1.f : 0.f, v = image[i];
+    if (mask && c == 0) mask[((size_t)b * H + y) * W + x] = m;
+    if (obj) obj[i] = m * v;
+    if (ctx) ctx[i] = (1.f - m) * v + m * cls2fill;
+  }
+}
+
 __global__ void edges_kernel(const float* __restrict__ t, float* __restrict__ dst, int B, int H, int W, int Ctot,
                              int c0) {
   const long long total = (long long)B * H * W;
@@ -262,6 +291,18 @@ int him_scale(float* p, size_t n, float s, void* stream) {
   if (!n) return HIM_OK;
   hipLaunchKernelGGL(scale_kernel, gs_grid(n), dim3(256), 0, ST, p, n, s);
   return check_launch("scale");
+}
+int him_u8_to_f32(const unsigned char* src, float* dst, size_t n, void* stream) {
+  if (!n) return HIM_OK;
+  hipLaunchKernelGGL(u8_to_f32_kernel, gs_grid(n), dim3(256), 0, ST, src, dst, n);
+  return check_launch("u8_to_f32");
+}
+int him_masked_image(const float* image, const float* bbox, float* mask, float* masked_object, float* masked_context,
+                     int B, int C, int H, int W, float cls2fill, void* stream) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return fail(HIM_E_INVALID, "masked_image: bad shape");
+  hipLaunchKernelGGL(masked_image_kernel, gs_grid((size_t)B * C * H * W), dim3(256), 0, ST, image, bbox, mask,
+                     masked_object, masked_context, B, C, H, W, cls2fill);
+  return check_launch("masked_image");
 }
 int him_onehot(const float* label, float* dst, int B, int label_nc, int Ctot, int c0, int hw, void* stream) {
   if (c0 < 0 || c0 + label_nc > Ctot) return fail(HIM_E_INVALID, "onehot: channel slice out of range");

@@ -150,6 +150,9 @@ class Pix2PixHDModel_condImg(BaseModel):
         if t is None:
             return None
         t = t.detach()
+        if t.dtype == torch.uint8:
+            # compact id maps (label / instance): 1 byte per pixel over PCIe, widened to float ids on the device
+            return ops.widen_u8(t.to(self.device, non_blocking=True))
         if t.device != self.device or t.dtype != torch.float32:
             t = t.to(self.device, torch.float32, non_blocking=True)
         return t.contiguous()

@@ -1009,6 +1009,31 @@ def slice_channels(x, c0, n):
     return out
 
 
+def widen_u8(t):
+    """uint8 id map (any shape) on the device -> float32 ids (what every kernel of the path reads)."""
+    if not t.is_cuda or t.dtype != torch.uint8:
+        raise HimError('widen_u8 needs a uint8 GPU tensor')
+    t = t.contiguous()
+    out = torch.empty(t.shape, dtype=torch.float32, device=t.device)
+    lib.him_u8_to_f32(t.data_ptr(), out.data_ptr(), t.numel(), _stream())
+    return out
+
+
+def get_masked_image(image, bbox, cls2fill=0.0):
+    """Batched, on-device ``get_masked_image`` (reference data/base_dataset.py:342-357): ``image`` (B,C,H,W), ``bbox``
+    (B,4) = (wmin, hmin, wmax, hmax) -> (mask (B,1,H,W), mask*image, (1-mask)*image + mask*cls2fill)."""
+    image = image.contiguous()
+    bbox = bbox.to(device=image.device, dtype=torch.float32).contiguous()
+    _chk(image, bbox)
+    B, Cn, H, W = image.shape
+    if tuple(bbox.shape) != (B, 4):
+        raise HimError('get_masked_image: bbox must be (B, 4), got %s' % (tuple(bbox.shape),))
+    mask = torch.empty((B, 1, H, W), dtype=torch.float32, device=image.device)
+    obj, ctx = torch.empty_like(image), torch.empty_like(image)
+    lib.him_masked_image(_p(image), _p(bbox), _p(mask), _p(obj), _p(ctx), B, Cn, H, W, float(cls2fill), _stream())
+    return mask, obj, ctx
+
+
 def masked_mean_color(image, obj_mask, noise=None):
     _chk(image, obj_mask, noise)
     B, _, H, W = image.shape

