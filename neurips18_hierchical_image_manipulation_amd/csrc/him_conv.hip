@@ -26,6 +26,7 @@
 namespace him {
 
 #include "him_gconv_fast.inc"
+#include "him_wino_fused.inc"
 
 // ---- weight regrouping for the fast path: out[m][cb][jh][jw][c16] = W[base + m*sm + (16cb+c16)*sc + jh*sh + jw*sw]
 struct WT2Phase {
@@ -2095,7 +2096,31 @@ static int fast_ksplit(int M, long long N, int nk) {
 static bool wino_fwd_ok(const HimConv2d* d) {
   return wino_shape_ok(d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad, d->H, d->W);
 }
+// The fused Winograd kernel (him_wino_fused.inc: transforms inside the GEMM kernel) takes the 3x3 stride-1 pad-1 layers
+// BELOW the channel threshold of the separate-transform pipeline: 128..511 reduction channels (VGG conv3_x / conv4_1,
+// the 256-channel box2mask ResnetBlocks).  Measured against the direct MFMA kernel (tools/micro/wino_micro): 158 vs 131
+// TFLOP/s direct-form equivalent at 256->256, 142 vs 131 at 128->128, slower at 64 channels; above 512 channels the
+// separate-transform pipeline (190 TFLOP/s equivalent) stays ahead.
+static int wino_fused_min_c() {
+  static int v = -2;
+  if (v == -2) v = getenv("HIM_NO_WINO_FUSED") ? 0 : (getenv("HIM_WINO_FUSED_MIN_C") ? atoi(getenv("HIM_WINO_FUSED_MIN_C")) : 128);
+  return v;
+}
+static bool wino_fused_ok(int Co, int Ci, int KH, int KW, int stride, int pad, int B, int H, int W) {
+  const int mc = wino_fused_min_c();
+  return mc > 0 && Ci >= mc && Co >= 64 && !wino_shape_ok(Co, Ci, KH, KW, stride, pad, H, W) &&
+         wino_fused_shape_ok(Co, Ci, KH, KW, stride, pad, B, H, W);
+}
+static bool wino_fused_fwd_ok(const HimConv2d* d) {
+  return wino_fused_ok(d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad, d->B, d->H, d->W);
+}
+// data gradient of a ZERO-padded 3x3 stride-1 conv = the same convolution with the flipped / transposed filter
+static bool wino_fused_dgrad_ok(const HimConv2d* d) {
+  return d->pad_mode == HIM_PAD_ZERO && d->OH == d->H && d->OW == d->W &&
+         wino_fused_ok(d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad, d->B, d->H, d->W);
+}
 static size_t fprop_ws_bytes(const HimConv2d* d) {
+  if (wino_fused_fwd_ok(d)) return wino_fused_panel_floats(d->Cout, d->Cin) * sizeof(float) + 256;
   if (wino_fwd_ok(d))
     return ((size_t)16 * d->Cout * d->Cin + wino_conv_floats(d->B, d->Cin, d->Cout, d->OH, d->OW)) * sizeof(float) + 256;
   if (small_split_ok(d)) return (size_t)SMALL_NSPLIT * d->Cout * d->B * d->OH * d->OW * sizeof(float) + 256;
@@ -2107,12 +2132,25 @@ static size_t fprop_ws_bytes(const HimConv2d* d) {
 // floats of the regrouped weight panel the forward kernel reads (0: it reads the raw weights)
 static size_t fprop_panel_floats(const HimConv2d* d) {
   if (small_split_ok(d) || d->Cout <= 4 || !use_fast(d->Cout, d->Cin)) return 0;
+  if (wino_fused_fwd_ok(d)) return wino_fused_panel_floats(d->Cout, d->Cin);
   if (wino_fwd_ok(d)) return (size_t)16 * d->Cout * d->Cin;
   return (size_t)d->Cout * d->KH * d->KW * pad16(d->Cin);
 }
 // panel == nullptr: regroup the weights into the workspace on every call; build_only: write the panel to ws and return
 static int run_fprop(const HimConv2d* d, const float* x, const float* w, const float* bias, float* y, void* ws,
                      size_t ws_bytes, hipStream_t st, const float* panel = nullptr, bool build_only = false) {
+  if (wino_fused_fwd_ok(d)) {
+    if (!panel) {
+      const size_t need = wino_fused_panel_floats(d->Cout, d->Cin) * sizeof(float);
+      if (!ws || ws_bytes < need) return fail(HIM_E_WORKSPACE, "conv fwd needs %zu ws bytes, got %zu", need, ws_bytes);
+      hipLaunchKernelGGL((wino_fused_weight_kernel<0>), dim3(cdiv(d->Cin, 256), d->Cout), dim3(256), 0, st, w, (float*)ws,
+                         d->Cout, d->Cin);
+      int rc = check_launch("wino_fused_weight");
+      if (rc || build_only) return rc;
+    }
+    return run_wino_fused(d->B, d->Cin, d->H, d->W, d->Cout, d->pad_mode == HIM_PAD_REFLECT, x,
+                          panel ? panel : (const float*)ws, bias, d->act, d->slope, y, st);
+  }
   if (wino_fwd_ok(d)) {
     const size_t need = build_only ? fprop_panel_floats(d) * sizeof(float) : fprop_ws_bytes(d);
     if (!ws || ws_bytes < need) return fail(HIM_E_WORKSPACE, "conv fwd needs %zu ws bytes, got %zu", need, ws_bytes);
@@ -2203,6 +2241,7 @@ static int dgrad_ksplit(const HimConv2d* d) {
   return fast_ksplit(d->Cin, N, d->KH * d->KW * (pad16(d->Cout) / 16));
 }
 static size_t dgrad_ws_bytes(const HimConv2d* d) {
+  if (wino_fused_dgrad_ok(d)) return wino_fused_panel_floats(d->Cin, d->Cout) * sizeof(float) + 256;
   if (wino_dgrad_ok(d)) return wino_dgrad_floats(d) * sizeof(float) + 256;
   size_t n = (size_t)d->Cin * pad16(d->Cout) * d->KH * d->KW + 64;
   const size_t outn = (size_t)d->B * d->Cin * (d->H + 2 * d->pad) * (d->W + 2 * d->pad);
@@ -2213,6 +2252,7 @@ static size_t dgrad_ws_bytes(const HimConv2d* d) {
   return n * sizeof(float) + 256;
 }
 static size_t dgrad_panel_floats(const HimConv2d* d) {
+  if (wino_fused_dgrad_ok(d)) return wino_fused_panel_floats(d->Cin, d->Cout);
   if (wino_dgrad_ok(d)) return (size_t)16 * d->Cin * d->Cout;
   return (size_t)d->Cin * (use_fast(d->Cin, d->Cout) ? pad16(d->Cout) : d->Cout) * d->KH * d->KW;
 }
@@ -2222,6 +2262,16 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
                      bool build_only = false) {
   const size_t need = build_only ? dgrad_panel_floats(d) * sizeof(float) : dgrad_ws_bytes(d);
   if (!ws || ws_bytes < need) return fail(HIM_E_WORKSPACE, "dgrad needs %zu ws bytes, got %zu", need, ws_bytes);
+  if (wino_fused_dgrad_ok(d)) {   // zero-padded 3x3 stride-1: the convolution of gy with the flipped / transposed filter
+    if (!panel) {
+      hipLaunchKernelGGL((wino_fused_weight_kernel<1>), dim3(cdiv(d->Cout, 256), d->Cin), dim3(256), 0, st, w, (float*)ws,
+                         d->Cin, d->Cout);
+      int rcu = check_launch("wino_fused_weight");
+      if (rcu || build_only) return rcu;
+    }
+    return run_wino_fused(d->B, d->Cout, d->OH, d->OW, d->Cin, false, gy, panel ? panel : (const float*)ws, bias, act, slope,
+                          out, st);
+  }
   if (wino_dgrad_ok(d) && panel && (bias || act != HIM_ACT_NONE))
     return fail(HIM_E_UNSUPPORTED, "dgrad: Winograd panel with a fused bias/activation epilogue");
   if (wino_dgrad_ok(d) && (build_only || (!bias && act == HIM_ACT_NONE))) {

@@ -206,7 +206,7 @@ def _panel(w, d, kind, is_deconv):
         key = (kind, d.stride, d.pad, d.out_pad)
     else:
         key = (kind, d.stride, d.pad, d.pad_mode, d.H >= 2 and d.W >= 2, d.OH == d.H and d.OW == d.W,
-               d.B * d.OH * d.OW < 131072)
+               d.B * d.OH * d.OW < 131072, d.B * d.Cin * d.H * d.W < (1 << 29), d.B * d.Cout * d.H * d.W < (1 << 29))
     e = cache.get(key)
     if e is None:
         e = cache[key] = _Panel()

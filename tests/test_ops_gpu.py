@@ -63,6 +63,10 @@ CONV_CASES = [
     (2, 64, 7, 9, 64, 3, 1, 1, 'reflect', 'none'),       # odd plane 63 with reflect gather in the fast wgrad
     (1, 8, 20, 70, 2, 7, 1, 3, 'zero', 'none'),          # tiny-M 7x7 wgrad, 2 outputs: filter-row band split (4 + 3 rows)
     (2, 8, 12, 66, 4, 7, 1, 3, 'reflect', 'none'),       # tiny-M 7x7 wgrad, 4 outputs, reflect, two column strips
+    (2, 128, 16, 32, 128, 3, 1, 1, 'zero', 'relu'),      # fused Winograd kernel: VGG conv2_2-like (fwd + zero-pad dgrad)
+    (3, 256, 9, 13, 192, 3, 1, 1, 'zero', 'none'),       # fused Winograd: odd plane (partial 8x8 tile blocks), Cout 192
+    (2, 136, 18, 20, 64, 3, 1, 1, 'reflect', 'none'),    # fused Winograd forward with reflection (dgrad: direct form)
+    (1, 256, 2, 2, 256, 3, 1, 1, 'reflect', 'none'),     # fused Winograd: a single 2x2 tile, both borders in one patch
 ]
 
 
