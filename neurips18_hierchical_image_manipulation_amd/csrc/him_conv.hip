@@ -2097,18 +2097,30 @@ static bool wino_fwd_ok(const HimConv2d* d) {
   return wino_shape_ok(d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad, d->H, d->W);
 }
 // The fused Winograd kernel (him_wino_fused.inc: transforms inside the GEMM kernel) takes the 3x3 stride-1 pad-1 layers
-// BELOW the channel threshold of the separate-transform pipeline: 128..511 reduction channels (VGG conv3_x / conv4_1,
-// the 256-channel box2mask ResnetBlocks).  Measured against the direct MFMA kernel (tools/micro/wino_micro): 158 vs 131
-// TFLOP/s direct-form equivalent at 256->256, 142 vs 131 at 128->128, slower at 64 channels; above 512 channels the
-// separate-transform pipeline (190 TFLOP/s equivalent) stays ahead.
+// with 64..512 reduction channels and a multiple of 64 output channels in the FORWARD direction (zero or reflection
+// padding) and the data gradient of ZERO-padded layers: all VGG convs but conv1_1, the box2mask ResnetBlocks.
+// Measured against the alternatives (tools/conv_bench.py / tools/micro/wino_micro, TFLOP/s direct-form equivalent):
+// 64->64 150 vs 116 (direct MFMA kernel), 128->128 189 vs 131, 256->256 203 vs 131, 512->512 220 vs 194
+// (separate-transform pipeline, which needs two more launches and 4x the activation in HBM).  The separate-transform
+// pipeline keeps the 1024-channel ResnetBlock stack (see wino_fused_max_c), the data gradient of reflection-padded
+// layers (border fold) and the weight gradient.
 static int wino_fused_min_c() {
   static int v = -2;
-  if (v == -2) v = getenv("HIM_NO_WINO_FUSED") ? 0 : (getenv("HIM_WINO_FUSED_MIN_C") ? atoi(getenv("HIM_WINO_FUSED_MIN_C")) : 128);
+  if (v == -2) v = getenv("HIM_NO_WINO_FUSED") ? 0 : (getenv("HIM_WINO_FUSED_MIN_C") ? atoi(getenv("HIM_WINO_FUSED_MIN_C")) : 64);
+  return v;
+}
+// Upper end of the fused kernel's channel range.  Inside the training step (weight panels streamed from HBM, 67 MB per
+// 1024-channel layer) the ResnetBlock forward is faster on the separate-transform pipeline: 10.4 vs 11.8 ms generator
+// forward, 121.4 vs 118.9 images/s (A/B with HIM_WINO_FUSED_MAX_C) -- although the isolated kernel, whose panel stays in
+// the Infinity Cache between launches, measures 197 vs 188 TFLOP/s equivalent.
+static int wino_fused_max_c() {
+  static int v = -2;
+  if (v == -2) v = getenv("HIM_WINO_FUSED_MAX_C") ? atoi(getenv("HIM_WINO_FUSED_MAX_C")) : 512;
   return v;
 }
 static bool wino_fused_ok(int Co, int Ci, int KH, int KW, int stride, int pad, int B, int H, int W) {
   const int mc = wino_fused_min_c();
-  return mc > 0 && Ci >= mc && Co >= 64 && !wino_shape_ok(Co, Ci, KH, KW, stride, pad, H, W) &&
+  return mc > 0 && Ci >= mc && Ci <= wino_fused_max_c() && Co >= 64 &&
          wino_fused_shape_ok(Co, Ci, KH, KW, stride, pad, B, H, W);
 }
 static bool wino_fused_fwd_ok(const HimConv2d* d) {

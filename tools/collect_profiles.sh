@@ -1,0 +1,27 @@
+#!/bin/bash
+# Runs ON the GPU box (gpurun): kernel traces + PMC passes behind the numbers quoted in DESIGN.md / bench.py.
+# Usage: bash tools/collect_profiles.sh <tag>      -> gpurun_out/<tag>/...   (copy the summaries into profiles/)
+set -u
+TAG=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+# 1. the bench command under the kernel trace
+rocprofv3 --kernel-trace -d $OUT/bench_trace -o r -- python $ROOT/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-roofline > $OUT/bench_under_trace.log 2>&1
+python $ROOT/tools/prof_summary.py $OUT/bench_trace > $OUT/${TAG}_bench_kernel_stats.txt 2>&1
+python $ROOT/tools/prof_summary.py $OUT/bench_trace --by-grid > $OUT/${TAG}_bench_kernel_stats_by_grid.txt 2>&1
+python $ROOT/tools/stream_view.py $OUT/bench_trace > $OUT/${TAG}_bench_stream_view.txt 2>&1
+python $ROOT/tools/timeline.py $OUT/bench_trace > $OUT/${TAG}_bench_timeline.txt 2>&1
+rm -rf $OUT/bench_trace
+# 2. the dominant launch on its own: kernel trace with stats, then one PMC group per pass
+rocprofv3 --kernel-trace --stats -d $OUT/gemm_trace -o r -- python $ROOT/tools/gemm_bench.py 20 > $OUT/gemm_under_trace.log 2>&1
+python $ROOT/tools/prof_summary.py $OUT/gemm_trace > $OUT/${TAG}_gemm_bench_kernel_stats.txt 2>&1
+rm -rf $OUT/gemm_trace
+for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_INST_LDS"; do
+  d=$OUT/pmc_$(echo $grp | cut -d' ' -f1)
+  rocprofv3 --pmc $grp --kernel-trace -f csv -d $d -- python $ROOT/tools/gemm_bench.py 10 > $d.log 2>&1
+done
+python $ROOT/tools/pmc_collect.py gconv_fast_kernel 1024 $OUT/${TAG}_pmc_dominant_kernel.json $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_TCC_HIT_sum $OUT/pmc_SQ_WAVE_CYCLES > $OUT/pmc_collect.log 2>&1
+rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_TCC_HIT_sum $OUT/pmc_SQ_WAVE_CYCLES
+cd $ROOT
