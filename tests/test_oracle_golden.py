@@ -90,3 +90,38 @@ def test_box2mask_generator_oracle_matches_reference_golden(mode):
     for got, key in ((out[1], 'ctx_prob_'), (out[3], 'obj_prob_')):
         ref = torch.from_numpy(g[key + mode])
         assert float((got - ref).abs().max()) <= 1e-5 * max(float(ref.abs().max()), 1.0)
+
+
+def test_box2mask_ade_oracle_matches_reference_golden():
+    """The ADE recipe's oracle (InstanceNorm, DilatedResnetBlocks, label_nc 49, lr_control) against the fixtures generated
+    from the REAL reference: generator forward (box2mask_ade_net.npz) and the first training steps with --lr_control
+    (box2mask_ade_traj.npz)."""
+    from oracle import ref_mask_cpu
+    g = load_golden('box2mask_ade_net')
+    ora = ref_mask_cpu.MaskTwoStreamConvSwitchNet(49, 49, norm_layer='instance', add_dilated_layers=True)
+    ora.load_state_dict(synth.init_state_dict(ora.state_dict(), 31))
+    ora.train()
+    x = torch.randn(2, 98, 64, 64, generator=torch.Generator().manual_seed(3))
+    assert abs(x.double().sum().item() - g['x_sum'][0]) < 1e-6
+    out = ora(x)
+    for got, key in ((out[1], 'ctx_prob'), (out[3], 'obj_prob')):
+        ref = torch.from_numpy(g[key])
+        assert float((got - ref).abs().max()) <= 1e-5 * max(float(ref.abs().max()), 1.0)
+    t = load_golden('box2mask_ade_traj')
+    fl = json.loads(str(t['flags']))
+    tr = ref_mask_cpu.TwoStreamAEMask(**{k: v for k, v in fl.items() if k != 'output_nc'})
+    tr.netG.load_state_dict(synth.init_state_dict(tr.netG.state_dict(), 31))
+    tr.netD.load_state_dict(synth.init_state_dict(tr.netD.state_dict(), 32))
+    for s in range(2):
+        o = tr.step(synth.make_box2mask_batch(s, 0, 2, 64, 64, 49))
+        got = np.array([o[k] for k in ref_mask_cpu.LOSS_NAMES])
+        np.testing.assert_allclose(got, t['losses'][s], rtol=5e-6, atol=1e-7)
+
+
+def test_lr_control_rule_restatement():
+    """oracle lr_control (reference models/Discriminator_NET.py:190-211): the three reachable outcomes."""
+    from oracle import ref_mask_cpu
+    assert ref_mask_cpu.lr_control(0.5, 0.5) == (1.0, 1.0)
+    assert ref_mask_cpu.lr_control(0.1, 0.5) == (1.0, 0.0)      # D pauses: one of its losses is under the margin
+    assert ref_mask_cpu.lr_control(0.9, 0.5) == (0.0, 1.0)      # G pauses: D is losing
+    assert ref_mask_cpu.lr_control(0.1, 0.9) == (1.0, 1.0)      # both would pause -> both train
