@@ -333,8 +333,7 @@ def main():
 
     # synthetic batches, resident in HBM before the timed region (4 distinct batches per rank, cycled; seeded by rank)
     if args.workload == 'box2mask':
-        batches = [{k: (v.to(device) if k != 'cls' else v) for k, v in synth.make_box2mask_batch(s, rank, bs, H, W).items()}
-                   for s in range(4)]
+        batches = [{k: v.to(device) for k, v in synth.make_box2mask_batch(s, rank, bs, H, W).items()} for s in range(4)]
 
         def step(i):
             b = batches[i % 4]

@@ -136,6 +136,9 @@ int him_bce_mean_bwd(const float* p, const float* t, size_t n, const float* g, f
  *   lr_control: models/Discriminator_NET.py:190-211 on device scalars, out2 = {g_lr, d_lr} (no host read-back). */
 int him_space_to_batch(const float* x, float* y, int B, int C, int H, int W, int d, int inverse, void* stream);
 int him_lr_control(const float* loss_d_real, const float* loss_d_fake, float margin, float* out2, void* stream);
+/* box2mask condition, object half (models/TwoStreamAE_mask.py:127-152): dst[b][c0+c][px] = (c == cls[b]) ? mask[b][px] : 0
+ * for c in [0, NC); cls = one class id per sample as a float on the device. */
+int him_class_mask(const float* mask, const float* cls, float* dst, int B, int NC, int Ctot, int c0, int hw, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * One-hot stems: conv over [one-hot(label) | dense channels] evaluated from the label ids.  `label` is the

@@ -76,6 +76,7 @@ _SIGS = {
     'him_bce_mean_fwd': (c_int, [P, P, c_size_t, P, P, c_size_t, P]),
     'him_space_to_batch': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'him_lr_control': (c_int, [P, P, c_float, P, P]),
+    'him_class_mask': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'him_bce_mean_bwd': (c_int, [P, P, c_size_t, P, P, P]),
     'him_instnorm_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_float, c_int, c_float, P]),
     'him_instnorm_bwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_float, P]),

@@ -451,6 +451,20 @@ __global__ __launch_bounds__(256) void space_batch_kernel(const float* __restric
   }
 }
 
+// box2mask condition, object half (reference TwoStreamAE_mask.encode_input :127-152): the box mask goes into the channel
+// of the object's class, every other of the NC channels is zero:  dst[b][c0 + c][px] = (c == cls[b]) ? mask[b][px] : 0.
+// cls: one class id per sample as a float, ON THE DEVICE (no host read-back, no per-sample launches).
+__global__ void class_mask_kernel(const float* __restrict__ mask, const float* __restrict__ cls, float* __restrict__ dst,
+                                  int B, int NC, int Ctot, int c0, int hw) {
+  const long long total = (long long)B * NC * hw;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int px = (int)(i % hw);
+    const long long r = i / hw;
+    const int c = (int)(r % NC), b = (int)(r / NC);
+    dst[((size_t)b * Ctot + c0 + c) * hw + px] = (c == (int)cls[b]) ? mask[(size_t)b * hw + px] : 0.f;
+  }
+}
+
 // lr_control (reference models/Discriminator_NET.py:190-211) evaluated on the device: out2 = {g_lr, d_lr} in {0, 1}
 __global__ void lr_control_kernel(const float* __restrict__ d_real, const float* __restrict__ d_fake, float margin,
                                   float* __restrict__ out2) {
@@ -570,6 +584,11 @@ int him_space_to_batch(const float* x, float* y, int B, int C, int H, int W, int
   if (H % d || W % d) return fail(HIM_E_UNSUPPORTED, "space_to_batch: %dx%d not divisible by dilation %d", H, W, d);
   hipLaunchKernelGGL(space_batch_kernel, gs_grid((size_t)B * C * H * W), dim3(256), 0, ST, x, y, B, C, H, W, d, inverse);
   return check_launch("space_to_batch");
+}
+int him_class_mask(const float* mask, const float* cls, float* dst, int B, int NC, int Ctot, int c0, int hw, void* stream) {
+  if (B <= 0 || NC <= 0 || hw <= 0 || c0 < 0 || c0 + NC > Ctot) return fail(HIM_E_INVALID, "class_mask: bad shape");
+  hipLaunchKernelGGL(class_mask_kernel, gs_grid((size_t)B * NC * hw), dim3(256), 0, ST, mask, cls, dst, B, NC, Ctot, c0, hw);
+  return check_launch("class_mask");
 }
 int him_lr_control(const float* loss_d_real, const float* loss_d_fake, float margin, float* out2, void* stream) {
   hipLaunchKernelGGL(lr_control_kernel, dim3(1), dim3(1), 0, ST, loss_d_real, loss_d_fake, margin, out2);

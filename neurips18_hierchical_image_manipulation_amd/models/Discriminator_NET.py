@@ -1,5 +1,8 @@
 """Multi-scale PatchGAN on the HIP layer executor (reference ``models/Discriminator_NET.py:11-118``,
 getIntermFeat=True; keys ``scale<i>_layer<j>.0.{weight,bias}``)."""
+import os
+
+import torch
 import torch.nn as nn
 
 from ..nn import Conv2d, InstanceNorm2d, BatchNorm2d, LeakyReLU, FusedSequential, AvgPool3s2
@@ -30,14 +33,55 @@ class MultiscaleDiscriminator(nn.Module):
                 setattr(self, 'scale%d_layer%d' % (i, j), FusedSequential(*b))
         self.downsample = AvgPool3s2()
 
+    def _scale(self, i, x):
+        feats, h = [], x
+        for j in range(self.n_layers + 2):
+            h = getattr(self, 'scale%d_layer%d' % (self.num_D - 1 - i, j))(h)   # :51 index reversal
+            feats.append(h)
+        return feats
+
     def forward(self, input):
+        if _SCALE_STREAMS and input.is_cuda and self.num_D > 1:
+            return self._forward_streams(input)
         result, x = [], input
         for i in range(self.num_D):
-            feats, h = [], x
-            for j in range(self.n_layers + 2):
-                h = getattr(self, 'scale%d_layer%d' % (self.num_D - 1 - i, j))(h)   # :51 index reversal
-                feats.append(h)
-            result.append(feats)
+            result.append(self._scale(i, x))
             if i != self.num_D - 1:
                 x = self.downsample(x)
         return result
+
+    def _forward_streams(self, input):
+        """The scales are independent given their (pooled) inputs: scales 1.. run on streams of their own next to scale 0
+        (their launches have few tiles -- 1/4, 1/16 of the pixels -- and leave most of the chip idle when run alone).
+        Autograd replays every node on the stream its forward ran on, so the backward overlaps the same way."""
+        dev = input.device
+        main = torch.cuda.current_stream(dev)
+        xs = [input]
+        for i in range(1, self.num_D):
+            xs.append(self.downsample(xs[-1]))
+        result = [None] * self.num_D
+        streams = []
+        for i in range(self.num_D - 1, 0, -1):      # smallest first: they start while scale 0 is being enqueued
+            st = _scale_stream(dev, i)
+            st.wait_stream(main)
+            xs[i].record_stream(st)
+            with torch.cuda.stream(st):
+                result[i] = self._scale(i, xs[i])
+            for t in result[i]:
+                t.record_stream(main)
+            streams.append(st)
+        result[0] = self._scale(0, xs[0])
+        for st in streams:
+            main.wait_stream(st)
+        return result
+
+
+_SCALE_STREAMS = os.environ.get('HIM_D_SCALE_STREAMS', '0') != '0'
+_STREAMS = {}
+
+
+def _scale_stream(device, i):
+    s = _STREAMS.get((device, i))
+    if s is None:
+        s = _STREAMS[(device, i)] = torch.cuda.Stream(device=device)
+    return s

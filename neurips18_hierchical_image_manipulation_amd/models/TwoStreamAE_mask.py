@@ -79,12 +79,14 @@ class TwoStreamAE_mask(BaseModel):
         nc = self.opt.label_nc
         ctx, box = self._dev(mask_ctx_in), self._dev(mask_in)
         B, _, H, W = ctx.shape
-        cond = torch.zeros((B, 2 * nc, H, W), dtype=torch.float32, device=self.device)
+        cond = torch.empty((B, 2 * nc, H, W), dtype=torch.float32, device=self.device)
         from .._cabi import lib
-        lib.him_onehot(ctx.data_ptr(), cond.data_ptr(), B, nc, 2 * nc, nc, H * W, torch.cuda.current_stream().cuda_stream)
-        ids = [int(c) for c in cls.reshape(-1).tolist()]
-        for b, c in enumerate(ids):
-            cond[b, c].copy_(box[b, 0])
+        st = torch.cuda.current_stream().cuda_stream
+        # class ids travel to the device once (B floats, asynchronous); both halves are written by one kernel each --
+        # no host read-back of cls, no per-sample copies, no zero fill
+        cls_dev = cls.reshape(-1).to(self.device, torch.float32, non_blocking=True).contiguous()
+        lib.him_class_mask(box.data_ptr(), cls_dev.data_ptr(), cond.data_ptr(), B, nc, 2 * nc, 0, H * W, st)
+        lib.him_onehot(ctx.data_ptr(), cond.data_ptr(), B, nc, 2 * nc, nc, H * W, st)
         return cond
 
     def _gan(self, preds, real):

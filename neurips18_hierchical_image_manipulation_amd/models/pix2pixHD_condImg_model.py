@@ -18,6 +18,7 @@ from ..optim import FusedAdam
 from .base_model import BaseModel
 
 NULLVAL = 0.0
+_VGG_STREAM = os.environ.get('HIM_VGG_STREAM', '1') != '0'
 
 
 class ImagePool(object):
@@ -237,6 +238,18 @@ class Pix2PixHDModel_condImg(BaseModel):
         if self.isTrain:
             self._wait_d_update()          # the previous step's D exchange + Adam (own stream) end before D is read here
             self._d_update_pending = False
+        # VGG(fake) is independent of the discriminator passes on the fake image: it runs on a stream of its own next to
+        # them (the small PatchGAN scales leave most of the chip idle); autograd replays its backward on that stream too.
+        vgg_side = None
+        if not opt.no_vgg_loss and _VGG_STREAM:
+            main_s = torch.cuda.current_stream(self.device)
+            vs = ops._vgg_stream(self.device)
+            vs.wait_stream(main_s)
+            fake_image.record_stream(vs)
+            real_image.record_stream(vs)
+            with torch.cuda.stream(vs):
+                vgg_side = self.criterionVGG(fake_image, real_image, ahead['y_vgg'] if ahead is not None else None)
+            vgg_side.record_stream(main_s)
 
         # Fake detection and loss / real detection and loss / GAN loss (:218-233).  The reference runs the discriminator
         # on the fake image twice -- once detached (loss_D_fake) and once attached (loss_G_GAN + feature matching) --
@@ -276,7 +289,10 @@ class Pix2PixHDModel_condImg(BaseModel):
             loss_G_GAN_Feat = loss_G_GAN_Feat + ops.l1_weighted_sum(pairs, [w] * len(pairs))
 
         loss_G_VGG = torch.zeros(1, device=self.device)
-        if not opt.no_vgg_loss:
+        if vgg_side is not None:
+            torch.cuda.current_stream(self.device).wait_stream(ops._vgg_stream(self.device))
+            loss_G_VGG = vgg_side * opt.lambda_feat
+        elif not opt.no_vgg_loss:
             loss_G_VGG = self.criterionVGG(fake_image, real_image,
                                            ahead['y_vgg'] if ahead is not None else None) * opt.lambda_feat
         if opt.lambda_rec > 0:

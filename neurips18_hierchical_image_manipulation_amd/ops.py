@@ -75,6 +75,17 @@ def _opt_stream(device):
     return s
 
 
+_VGGS = {}
+
+
+def _vgg_stream(device):
+    """Stream of the VGG(fake) forward / backward (next to the discriminator passes on the fake image)."""
+    s = _VGGS.get(device)
+    if s is None:
+        s = _VGGS[device] = torch.cuda.Stream(device=device)
+    return s
+
+
 _DOPT = {}
 
 

@@ -23,6 +23,7 @@ sys.path.insert(0, %r); sys.path.insert(0, %r)
 from oracle import ref_cpu
 from neurips18_hierchical_image_manipulation_amd import synth
 tag, threads, pert = sys.argv[1], int(sys.argv[2]), float(sys.argv[3])
+pseed = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 torch.set_num_threads(threads)
 g = np.load(%r + '/' + tag + '.npz'); flags = json.loads(str(g['flags']))
 B, H, W = int(g['B']), int(g['H']), int(g['W']); color = bool(int(g['color']))
@@ -31,7 +32,7 @@ om.netG.load_state_dict(synth.init_state_dict(om.netG.state_dict(), 1))
 om.netD.load_state_dict(synth.init_state_dict(om.netD.state_dict(), 2))
 om.vgg.load_state_dict(synth.init_state_dict(om.vgg.state_dict(), 3, 'vgg'))
 if pert:
-    gen = torch.Generator().manual_seed(0)
+    gen = torch.Generator().manual_seed(pseed)
     with torch.no_grad():
         for p in list(om.netG.parameters()) + list(om.netD.parameters()):
             p.mul_(1 + pert * torch.randn(p.shape, generator=gen))
@@ -44,8 +45,8 @@ print('RESULT ' + json.dumps(rel))
 ''' % (ROOT, os.path.join(ROOT, 'tests'), HERE)
 
 
-def run(tag, threads, pert=0.0):
-    out = subprocess.run([sys.executable, '-c', WORKER, tag, str(threads), str(pert)], stdout=subprocess.PIPE,
+def run(tag, threads, pert=0.0, pseed=0):
+    out = subprocess.run([sys.executable, '-c', WORKER, tag, str(threads), str(pert), str(pseed)], stdout=subprocess.PIPE,
                          stderr=subprocess.DEVNULL, text=True, check=True).stdout
     line = [l for l in out.splitlines() if l.startswith('RESULT ')][-1]
     return json.loads(line[7:])
@@ -77,5 +78,11 @@ if __name__ == '__main__':
             if name not in res:
                 res[name] = run(tag, 8, pv)
                 print(name, ' '.join('%.1e' % x for x in res[name]), flush=True)
+            if pv == 1e-6:                       # two more draws of the same-size perturbation
+                for sd in (1, 2):
+                    nm = '%s_s%d' % (name, sd)
+                    if nm not in res:
+                        res[nm] = run(tag, 8, pv, sd)
+                        print(nm, ' '.join('%.1e' % x for x in res[nm]), flush=True)
         with open(out_path, 'w') as f:
             json.dump(res, f, indent=1)
