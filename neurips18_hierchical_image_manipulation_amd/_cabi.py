@@ -84,6 +84,10 @@ _SIGS = {
     'him_add': (c_int, [P, P, P, c_size_t, P]),
     'him_onehot': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'him_u8_to_f32': (c_int, [P, P, c_size_t, P]),
+    'him_data_nearest': (c_int, [P, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, P]),
+    'him_data_bicubic_h': (c_int, [P, P, P, P, P, P, P, c_int, P, c_int, c_int, c_int, P]),
+    'him_data_bicubic_v': (c_int, [P, c_int, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, P]),
+    'him_data_region_masks': (c_int, [P, P, c_int, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
     'him_masked_image': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     'him_edges': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'him_masked_mean': (c_int, [P, P, P, P, c_int, c_int, P]),

@@ -36,7 +36,8 @@ TRAIN_FLAGS = [
     ('use_soft_mask', 'flag', False),
 ]
 # additions of this build (absent in the reference)
-BUILD_FLAGS = [('vgg_weights', str, ''), ('verbose', 'flag', False), ('color_noise', 'flag', False)]
+BUILD_FLAGS = [('vgg_weights', str, ''), ('verbose', 'flag', False), ('color_noise', 'flag', False),
+               ('compact_labels', 'flag', False)]   # loader: label ids as uint8 (the trainers widen them on the device)
 
 
 class MaskToImageOptions(object):

@@ -53,6 +53,55 @@ def install():
         return m
 
     tvm.vgg19 = vgg19
+
+    # torchvision.transforms is absent from the image; the reference's loader (data/base_dataset.py:236-268) uses four
+    # of its classes.  Restated from torchvision's documented behaviour (0.2 ... 0.20 agree on these): Compose applies
+    # in order, Lambda calls, ToTensor = HWC bytes -> CHW float / 255 (integer-mode images keep their integers),
+    # Normalize = (t - mean) / std per channel.
+    import numpy as _np
+
+    class Compose(object):
+        def __init__(self, transforms):
+            self.transforms = transforms
+
+        def __call__(self, x):
+            for t in self.transforms:
+                x = t(x)
+            return x
+
+    class Lambda(object):
+        def __init__(self, lambd):
+            self.lambd = lambd
+
+        def __call__(self, x):
+            return self.lambd(x)
+
+    class ToTensor(object):
+        def __call__(self, pic):
+            if pic.mode in ('I', 'I;16'):
+                a = _np.array(pic, _np.int32)        # torchvision: int32 / int16; ids below 32768 agree
+            elif pic.mode == 'F':
+                a = _np.array(pic, _np.float32)
+            elif pic.mode == '1':
+                a = 255 * _np.array(pic, _np.uint8)
+            else:
+                a = _np.array(pic, _np.uint8)
+            if a.ndim == 2:
+                a = a[:, :, None]
+            t = torch.from_numpy(_np.ascontiguousarray(a.transpose(2, 0, 1)))
+            return t.float().div(255) if t.dtype == torch.uint8 else t
+
+    class Normalize(object):
+        def __init__(self, mean, std):
+            self.mean, self.std = mean, std
+
+        def __call__(self, t):
+            t = t.clone()
+            for c in range(t.size(0)):
+                t[c].sub_(self.mean[c]).div_(self.std[c])
+            return t
+
+    tvt.Compose, tvt.Lambda, tvt.ToTensor, tvt.Normalize = Compose, Lambda, ToTensor, Normalize
     tv.models, tv.transforms = tvm, tvt
     sys.modules.update({'torchvision': tv, 'torchvision.models': tvm, 'torchvision.transforms': tvt})
     torch.Tensor.cuda = lambda s, *a, **k: s

@@ -1,0 +1,194 @@
+"""Loader path on the device: the pixel kernels against Pillow, whole samples against dictionaries the
+reference's CityscapeDataset / ADE20KDataset returned for the same files and seeds (tests/golden/data_pipeline.npz,
+made by tests/golden/make_golden_data.py), batching, the two-stage loader, and a loader batch driving a trainer."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+import data_fixture as fx
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def _opt(root, name, fine, extra=()):
+    from neurips18_hierchical_image_manipulation_amd.options import MaskToImageTrainOptions
+    return MaskToImageTrainOptions().parse(save=False, default_args=fx.loader_argv(root, name, fine, extra))
+
+
+@pytest.mark.parametrize('seed', range(4))
+def test_resize_kernels_equal_pillow(seed):
+    """Bytes, not tolerances: NEAREST and antialiased BICUBIC, down- and up-scaling, ragged batch, flips."""
+    from neurips18_hierchical_image_manipulation_amd.data import device as dv
+    rng = np.random.RandomState(seed)
+    for ow, oh in ((96, 96), (64, 48), (256, 256), (33, 70)):
+        B = 5
+        sizes = [(int(rng.randint(3, 600)), int(rng.randint(3, 600))) for _ in range(B)]
+        sizes[0] = (oh, ow)                                  # one window already at the target size
+        flips = [bool(rng.randint(2)) for _ in range(B)]
+        photos = [rng.randint(0, 256, (h, w, 3)).astype(np.uint8) for h, w in sizes]
+        got = dv.resize_photos(photos, oh, ow, flips, normalize=True).cpu()
+        raw = dv.resize_photos(photos, oh, ow, flips, normalize=False).cpu()
+        for b in range(B):
+            im = Image.fromarray(photos[b]).resize((ow, oh), Image.BICUBIC)
+            if flips[b]:
+                im = im.transpose(Image.FLIP_LEFT_RIGHT)
+            t = torch.from_numpy(np.asarray(im).transpose(2, 0, 1).copy()).float().div(255)
+            assert torch.equal(raw[b], t), (seed, ow, oh, b, sizes[b])
+            assert torch.equal(got[b], (t - 0.5) / 0.5)
+        for dtype, out in ((np.uint8, 'float'), (np.uint8, 'unit'), (np.uint8, 'uint8'), (np.uint16, 'int32'),
+                           (np.int32, 'int32')):
+            hi = 256 if dtype == np.uint8 else 40000
+            maps = [rng.randint(0, hi, (h, w)).astype(dtype) for h, w in sizes]
+            got = dv.resize_maps(maps, oh, ow, flips, out).cpu()
+            for b in range(B):
+                im = Image.fromarray(maps[b]).resize((ow, oh), Image.NEAREST)
+                if flips[b]:
+                    im = im.transpose(Image.FLIP_LEFT_RIGHT)
+                ref = torch.from_numpy(np.asarray(im).astype(np.int64))
+                if out == 'unit':
+                    assert torch.equal(got[b, 0], ref.float().div(255))
+                else:
+                    assert torch.equal(got[b, 0].long(), ref), (seed, out, b)
+
+
+def test_region_masks_equal_reference_formula():
+    from neurips18_hierchical_image_manipulation_amd.data import device as dv
+    g = torch.Generator().manual_seed(0)
+    B, H, W = 6, 40, 56
+    label = torch.randint(0, 35, (B, 1, H, W), generator=g).float()
+    inst = torch.randint(0, 5, (B, 1, H, W), generator=g).int()
+    bin_ = [[3, 4, 30, 20], [0, 0, 56, 40], [10, 10, 10, 30], [50, 30, 70, 60], [5, 6, 4, 9], [0, 39, 56, 40]]
+    bout = [[1, 2, 40, 30], [0, 0, 56, 40], [8, 8, 12, 32], [40, 20, 56, 40], [0, 0, 0, 0], [2, 2, 3, 3]]
+    fill = [7, 34, 0, 3, 9, 11]
+    ids = [2, None, 0, 4, 1, None]
+    outs = dv.region_masks(label.cuda(), inst.cuda(), bin_, bout, fill, ids)
+    for b in range(B):
+        def masked(box, cls):
+            m = torch.zeros(1, H, W)
+            w0, h0, w1, h1 = box
+            if h1 > h0 and w1 > w0:
+                m[0, h0:h1, w0:w1] = 1
+            return m, m * label[b], (1 - m) * label[b] + m * cls
+        mi, oi, ci = masked(bin_[b], fill[b])
+        mo, oo, _ = masked(bout[b], 0)
+        mm = (inst[b] == ids[b]).float() if ids[b] is not None else torch.zeros(1, H, W)
+        for got, ref in zip(outs, (mi, oi, ci, mo, oo, mm)):
+            assert torch.equal(got[b].cpu(), ref)
+    no_inst = dv.region_masks(label.cuda(), None, bin_, bout, fill, [None] * B)
+    assert float(no_inst[5].abs().sum()) == 0
+
+
+CASES = [('city96', 'city', 96, ['--contextMargin', '3.0', '--min_box_size', '16', '--max_box_size', '96'], (100, 200)),
+         ('ade64', 'ade', 64, ['--contextMargin', '2.0', '--min_box_size', '16', '--max_box_size', '64',
+                               '--prob_bg', '0.5'], (300, 400)),
+         ('city_scale_width', 'city', 96, ['--resize_or_crop', 'scale_width', '--loadSize', '128',
+                                           '--min_box_size', '16', '--max_box_size', '96'], (500,))]
+
+
+@pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
+def test_samples_equal_reference_dataset(case, tmp_path):
+    """``dataset[i]`` under the same ``random`` / ``numpy.random`` seeds as the reference run: every tensor of the
+    dictionary identical (label / instance / masks / boxes / class exactly, the photograph bit for bit too)."""
+    from neurips18_hierchical_image_manipulation_amd.data.data_loader import CreateDataLoader
+    name, setname, fine, extra, seeds = case
+    gold = np.load(os.path.join(GOLD, 'data_pipeline.npz'))
+    root = str(tmp_path / setname)
+    fx.write_dataset(root, setname)
+    dataset = CreateDataLoader(_opt(root, setname, fine, extra)).dataset
+    assert len(dataset) == 4
+    checked = 0
+    for seed0 in seeds:
+        for idx in range(4):
+            random.seed(seed0 + idx)
+            np.random.seed(seed0 + idx)
+            item = dataset[idx]
+            prefix = '%s/%d/%d/' % (name, seed0, idx)
+            keys = [k[len(prefix):] for k in gold.files if k.startswith(prefix)]
+            assert keys and set(keys) == {k for k, v in item.items() if torch.is_tensor(v)}
+            for k in keys:
+                ref = torch.from_numpy(gold[prefix + k])
+                got = item[k].cpu()
+                assert got.shape == ref.shape and got.dtype == ref.dtype, (prefix, k, got.dtype, ref.dtype)
+                assert torch.equal(got, ref), (prefix, k, float((got.double() - ref.double()).abs().max()))
+                checked += 1
+            assert item['label_path'].endswith('sample_%02d.png' % idx)
+    assert checked >= 12
+
+
+def test_batches_equal_stacked_samples_and_loader_runs(tmp_path):
+    """assemble(records) == the samples one by one; the two-stage loader (worker processes for the host stage, device
+    stage one batch ahead on its own stream) yields the same batches as the in-process one."""
+    from neurips18_hierchical_image_manipulation_amd.data.data_loader import CreateDataLoader
+    root = str(tmp_path / 'city')
+    fx.write_dataset(root, 'city')
+    extra = ['--contextMargin', '3.0', '--min_box_size', '16', '--max_box_size', '96']
+    loader = CreateDataLoader(_opt(root, 'city', 64, extra))
+    ds = loader.dataset
+    assert len(loader) == 4
+    random.seed(5)
+    np.random.seed(5)
+    recs = [ds.host_record(i) for i in range(4)]
+    batch = ds.assemble(recs)
+    for i in range(4):
+        one = ds.assemble([recs[i]])
+        for k, v in batch.items():
+            if torch.is_tensor(v):
+                assert torch.equal(v[i], one[k][0]), k
+            else:
+                assert v[i] == one[k][0]
+    assert batch['label'].shape == (4, 1, 64, 64) and batch['image'].shape == (4, 3, 64, 64)
+    assert batch['cls'].shape == (4, 1) and batch['cls'].dtype == torch.int64
+    assert batch['input_bbox'].shape == (4, 4) and batch['input_bbox'].dtype == torch.int64
+    assert batch['label'].is_cuda and batch['mask_in'].is_cuda
+
+    random.seed(9)
+    np.random.seed(9)
+    serial = [b for b in loader.load_data()]
+    assert len(serial) == 2 and all(b['label'].shape[0] == 2 for b in serial)
+    random.seed(9)
+    np.random.seed(9)
+    again = [b for b in loader.load_data()]
+    for a, b in zip(serial, again):
+        for k, v in a.items():
+            assert torch.equal(v, b[k]) if torch.is_tensor(v) else v == b[k]
+
+    workers = CreateDataLoader(_opt(root, 'city', 64, extra + ['--nThreads', '2']))
+    seen = 0
+    for b in workers.load_data():
+        assert b['image'].is_cuda and b['image'].shape == (2, 3, 64, 64)
+        assert float(b['image'].abs().max()) <= 1.0 and float(b['mask_in'].max()) <= 1.0
+        assert b['label_path'][0].endswith('.png')
+        seen += 1
+    assert seen == 2
+
+    compact = CreateDataLoader(_opt(root, 'city', 64, extra + ['--compact_labels']))
+    random.seed(5)
+    np.random.seed(5)
+    cb = compact.dataset.assemble([compact.dataset.host_record(i) for i in range(4)])
+    assert cb['label'].dtype == torch.uint8 and torch.equal(cb['label'].float(), batch['label'])
+    assert torch.equal(cb['mask_context_in'], batch['mask_context_in'])
+
+
+def test_loader_batch_drives_the_trainer(tmp_path):
+    """train_mask2image.py:56-66 with this loader: the dictionary of a batch goes straight into the model."""
+    from neurips18_hierchical_image_manipulation_amd.data.data_loader import CreateDataLoader
+    from neurips18_hierchical_image_manipulation_amd.models.models import create_model
+    root = str(tmp_path / 'city')
+    fx.write_dataset(root, 'city')
+    opt = _opt(root, 'city', 64, ['--contextMargin', '3.0', '--min_box_size', '16', '--max_box_size', '96',
+                                  '--ngf', '8', '--ndf', '8', '--n_downsample_global', '2', '--n_blocks_global', '2',
+                                  '--num_D', '2', '--no_vgg_loss', '--checkpoints_dir', str(tmp_path / 'ck')])
+    model = create_model(opt)
+    steps = 0
+    for epoch in range(2):
+        for data in CreateDataLoader(opt).load_data():
+            losses = model.optimize_parameters(data)
+            vals = [float(v) for v in losses.values()]
+            assert all(np.isfinite(vals)), vals
+            steps += 1
+    assert steps == 4
