@@ -416,6 +416,140 @@ __global__ void gconv_small_finish_kernel(const GConvP p) {
   }
 }
 
+// =============================================================================================
+// Few output channels (M <= 4), KSxKS, stride 1, "same" geometry on a large plane: the generator's last layer
+// (7x7, 64 -> 3, reflection padding) and the data gradient of VGG conv1_1 (3x3, 64 -> 3).  Three outputs cannot feed an
+// MFMA tile, so this is VALU work -- but the one-position-per-thread kernel above issues one global load per MM FMAs
+// and is load-issue bound (34 TFLOP/s on the 7x7, 9 on the 3x3).  Here a workgroup owns a 16x64 output tile, stages the
+// (16+KS-1) x (64+KS-1) input patch of one channel in LDS (next channel's patch prefetched into registers, two LDS
+// buffers, one barrier per channel) and every thread keeps 4 adjacent pixels x MM outputs in registers: one LDS row
+// segment of 4+KS-1 floats (two / three wide ds_reads) feeds 4*KS*MM FMAs; the weights are wave-uniform scalar loads.
+// =============================================================================================
+// FLIP: the data-gradient form (taps walk backwards: src = out + P - j), i.e. the same patch with the tap index mirrored.
+template <int MM, int KS, bool REFLECT, bool FLIP>
+__global__ __launch_bounds__(256) void gconv_fewout_tiled_kernel(const GConvP p) {
+  constexpr int TH = 16, TW = 64, P = KS / 2;
+  constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
+  constexpr int RS = (PW + 3) & ~3;          // row stride: 16-byte aligned rows
+  constexpr int NLD = (PH * PW + 255) / 256;  // patch elements per thread
+  __shared__ __attribute__((aligned(16))) float tile[2][PH * RS];
+  const GPhase& ph = p.ph[0];
+  const int H = p.SH, W = p.SW, C = p.C2, K = ph.K;
+  const int tiles_x = (W + TW - 1) / TW;
+  const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x, b = blockIdx.y;
+  const int y0 = by * TH, x0 = bx * TW;
+  const int tid = threadIdx.x, ty = tid >> 4, tx = (tid & 15) * 4;
+  const float* __restrict__ A = ph.A;
+  const float* __restrict__ src = p.src + (size_t)b * C * H * W;
+
+  int off[NLD], lds_at[NLD];
+#pragma unroll
+  for (int k = 0; k < NLD; ++k) {
+    const int i = tid + k * 256;
+    const int r = i / PW, c = i - r * PW;
+    int iy = y0 - P + r, ix = x0 - P + c;
+    bool ok = i < PH * PW;
+    if (REFLECT) {
+      iy = iy < 0 ? -iy : iy;
+      iy = iy >= H ? 2 * (H - 1) - iy : iy;
+      ix = ix < 0 ? -ix : ix;
+      ix = ix >= W ? 2 * (W - 1) - ix : ix;
+      ok = ok && iy >= 0 && iy < H && ix >= 0 && ix < W;   // beyond one reflection: outside every needed output
+    } else {
+      ok = ok && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    }
+    off[k] = ok ? iy * W + ix : -1;
+    lds_at[k] = i < PH * PW ? r * RS + c : -1;
+  }
+  float pre[NLD];
+#pragma unroll
+  for (int k = 0; k < NLD; ++k) pre[k] = off[k] >= 0 ? src[off[k]] : 0.f;
+
+  float acc[MM][4];
+#pragma unroll
+  for (int m = 0; m < MM; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[m][q] = 0.f;
+
+  for (int c = 0; c < C; ++c) {
+    float* __restrict__ t = tile[c & 1];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k)
+      if (lds_at[k] >= 0) t[lds_at[k]] = pre[k];
+    __syncthreads();   // one barrier per channel: the buffer written next (c+1) was last read in iteration c-1
+    if (c + 1 < C) {
+      const float* __restrict__ pl = src + (size_t)(c + 1) * H * W;
+#pragma unroll
+      for (int k = 0; k < NLD; ++k) pre[k] = off[k] >= 0 ? pl[off[k]] : 0.f;
+    }
+    const float* __restrict__ Ac = A + c * KS * KS;
+#pragma unroll 1   // one tap row at a time: its KS*MM weights fit the scalar registers (all KS*KS*MM at once spill)
+    for (int jh = 0; jh < KS; ++jh) {
+      const float* __restrict__ row = t + (ty + (FLIP ? KS - 1 - jh : jh)) * RS + tx;
+      float v[4 + KS - 1 + 1];
+      *(float4*)&v[0] = *(const float4*)&row[0];
+      if (KS == 3) {
+        *(float2*)&v[4] = *(const float2*)&row[4];
+      } else {
+        *(float4*)&v[4] = *(const float4*)&row[4];
+        *(float2*)&v[8] = *(const float2*)&row[8];
+      }
+#pragma unroll
+      for (int jw = 0; jw < KS; ++jw)
+#pragma unroll
+        for (int m = 0; m < MM; ++m) {
+          const float w = Ac[(size_t)m * K + jh * KS + jw];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[m][q] = fmaf(w, v[q + (FLIP ? KS - 1 - jw : jw)], acc[m][q]);
+        }
+    }
+  }
+  const int oy = y0 + ty, ox = x0 + tx;
+  if (oy >= H) return;
+#pragma unroll
+  for (int m = 0; m < MM; ++m) {
+    float o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = apply_act(acc[m][q] + (p.bias ? p.bias[m] : 0.f), p.act, p.slope);
+    float* __restrict__ out = p.dst + (((size_t)b * p.M + m) * p.DH + oy) * p.DW + ox;
+    if (ox + 3 < W && (W & 3) == 0) {
+      *(float4*)out = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (ox + q < W) out[q] = o[q];
+    }
+  }
+}
+
+template <int MM, int KS>
+static void launch_fewout_tiled(const GConvP& p, hipStream_t st) {
+  dim3 grid(cdiv(p.SW, 64) * cdiv(p.SH, 16), p.B, 1);
+  if (p.dy < 0)     // data gradient of a zero-padded layer (reflection gradients go through the fold kernels)
+    hipLaunchKernelGGL((gconv_fewout_tiled_kernel<MM, KS, false, true>), grid, dim3(256), 0, st, p);
+  else if (p.pad_mode == HIM_PAD_REFLECT)
+    hipLaunchKernelGGL((gconv_fewout_tiled_kernel<MM, KS, true, false>), grid, dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((gconv_fewout_tiled_kernel<MM, KS, false, false>), grid, dim3(256), 0, st, p);
+}
+
+// "same"-geometry stride-1 layer on a plane big enough to fill the chip with 16x64 tiles
+static bool fewout_tiled_ok(const GConvP& p) {
+  static const bool off = getenv("HIM_NO_FEWOUT_TILED") != nullptr;
+  if (off || p.nphase != 1 || p.M < 2 || p.M > 4) return false;
+  const GPhase& ph = p.ph[0];
+  const int ks = ph.JH;
+  if (ph.JW != ks || (ks != 3 && ks != 7)) return false;
+  if (p.sy != 1 || p.sx != 1 || p.oys != 1 || p.oxs != 1 || ph.oy0 != 0 || ph.ox0 != 0) return false;
+  const bool fwd = p.dy == 1 && p.dx == 1 && ph.offy == -(ks / 2) && ph.offx == -(ks / 2);
+  const bool bwd = p.dy == -1 && p.dx == -1 && ph.offy == ks / 2 && ph.offx == ks / 2 && p.pad_mode == HIM_PAD_ZERO;
+  if (!fwd && !bwd) return false;
+  if (ph.NA != p.SH || ph.NC != p.SW || p.DH != p.SH || p.DW != p.SW) return false;
+  if (p.SH <= ks / 2 || p.SW <= ks / 2) return false;                 // a single reflection must suffice
+  if (p.C2 < 8 || p.B > 65535) return false;
+  return (long long)p.B * cdiv(p.SW, 64) * cdiv(p.SH, 16) >= 512;      // enough tiles for 256 CUs
+}
+
 template <int MM, int TJ>
 static void launch_small_cfg(const GConvP& p, long long maxN, hipStream_t st) {
   const bool split = maxN < 256 * 512 && p.C2 >= 64;  // too few positions to fill 256 CUs: split the channels
@@ -442,6 +576,16 @@ static bool launch_gconv_small(const GConvP& p, long long maxN, hipStream_t st) 
   for (int i = 0; i < p.nphase; ++i)
     if (p.ph[i].JH > 8 || p.ph[i].JW > 8) return false;
   const int tj = (same && p.ph[0].JH == p.ph[0].JW) ? p.ph[0].JH : 0;
+  if (fewout_tiled_ok(p)) {
+    switch (p.M * 10 + tj) {
+      case 23: launch_fewout_tiled<2, 3>(p, st); return true;
+      case 33: launch_fewout_tiled<3, 3>(p, st); return true;
+      case 43: launch_fewout_tiled<4, 3>(p, st); return true;
+      case 27: launch_fewout_tiled<2, 7>(p, st); return true;
+      case 37: launch_fewout_tiled<3, 7>(p, st); return true;
+      case 47: launch_fewout_tiled<4, 7>(p, st); return true;
+    }
+  }
 #define HIM_SMALL(MMv)                                      \
   case MMv:                                                 \
     if (tj == 7) launch_small_cfg<MMv, 7>(p, maxN, st);      \

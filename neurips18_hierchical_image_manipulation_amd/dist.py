@@ -115,8 +115,14 @@ class GradReducer(object):
         if self.on_gpu:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
+            # a bucket can hold gradients written on two streams (conv weight gradients on the side stream, BatchNorm
+            # gamma / beta on the main one): the exchange waits for the triggering stream AND the side stream
+            from .ops import _SIDE
+            side = _SIDE.get(self.flat.device)
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
+                if side is not None:
+                    self.comm_stream.wait_stream(side)
                 if dist.get_backend(self.group) == 'nccl':       # RCCL: averaging collective
                     dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group)
                 else:                                            # gloo on device tensors (tests): no AVG op

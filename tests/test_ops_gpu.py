@@ -67,6 +67,11 @@ CONV_CASES = [
     (3, 256, 9, 13, 192, 3, 1, 1, 'zero', 'none'),       # fused Winograd: odd plane (partial 8x8 tile blocks), Cout 192
     (2, 136, 18, 20, 64, 3, 1, 1, 'reflect', 'none'),    # fused Winograd forward with reflection (dgrad: direct form)
     (1, 256, 2, 2, 256, 3, 1, 1, 'reflect', 'none'),     # fused Winograd: a single 2x2 tile, both borders in one patch
+    (8, 24, 128, 256, 3, 7, 1, 3, 'reflect', 'tanh'),    # LDS-tiled few-output kernel: G head form (512 tiles of 16x64)
+    (40, 16, 40, 70, 3, 7, 1, 3, 'reflect', 'none'),     # tiled few-output kernel, ragged tiles on both axes (W = 70, H = 40)
+    (36, 3, 40, 66, 16, 3, 1, 1, 'zero', 'relu'),        # tiled few-output kernel as the DATA GRADIENT of a 3 -> 16 3x3 layer (flipped taps), ragged
+    (8, 2, 130, 250, 8, 3, 1, 1, 'zero', 'none'),        # the same with 2 input channels, W % 4 != 0 (scalar stores)
+    (34, 12, 33, 65, 4, 3, 1, 1, 'zero', 'none'),        # tiled few-output forward, 4 outputs, 3x3 zero padding, odd plane
 ]
 
 

@@ -13,6 +13,7 @@ python $ROOT/tools/prof_summary.py $OUT/bench_trace > $OUT/${TAG}_bench_kernel_s
 python $ROOT/tools/prof_summary.py $OUT/bench_trace --by-grid > $OUT/${TAG}_bench_kernel_stats_by_grid.txt 2>&1
 python $ROOT/tools/stream_view.py $OUT/bench_trace > $OUT/${TAG}_bench_stream_view.txt 2>&1
 python $ROOT/tools/timeline.py $OUT/bench_trace > $OUT/${TAG}_bench_timeline.txt 2>&1
+for f in $(find $OUT/bench_trace -name "*.db" -size -30M); do cp $f $OUT/bench_trace.db; done
 rm -rf $OUT/bench_trace
 # 2. the dominant launch on its own: kernel trace with stats, then one PMC group per pass
 rocprofv3 --kernel-trace --stats -d $OUT/gemm_trace -o r -- python $ROOT/tools/gemm_bench.py 20 > $OUT/gemm_under_trace.log 2>&1
