@@ -6,6 +6,7 @@ import torch
 import torch.nn as nn
 
 from ..nn import Conv2d, InstanceNorm2d, BatchNorm2d, LeakyReLU, FusedSequential, AvgPool3s2
+from .layer_util import weights_init
 
 
 class MultiscaleDiscriminator(nn.Module):
@@ -32,6 +33,7 @@ class MultiscaleDiscriminator(nn.Module):
             for j, b in enumerate(blocks):
                 setattr(self, 'scale%d_layer%d' % (i, j), FusedSequential(*b))
         self.downsample = AvgPool3s2()
+        self.apply(weights_init)        # reference :34 (conv N(0, .02); BatchNorm weight N(1, .02), bias 0)
 
     def _scale(self, i, x):
         feats, h = [], x

@@ -18,6 +18,7 @@ from ..nn import frozen_params
 from ..optim import FusedAdam
 from .base_model import BaseModel
 from .Discriminator_NET import MultiscaleDiscriminator
+from .layer_util import torch_default_init
 from .MaskTwoStreamConvSwitch_NET import MaskTwoStreamConvSwitch_NET
 from .pix2pixHD_condImg_model import pick_device
 
@@ -54,7 +55,7 @@ class TwoStreamAE_mask(BaseModel):
             raise NotImplementedError('box2mask HIP path: --objReconLoss bce only')
         self.device = pick_device(opt)
         self.use_gan, self.use_output_gate = bool(opt.use_gan), bool(opt.use_output_gate)
-        self.netG = MaskTwoStreamConvSwitch_NET(opt).to(self.device)
+        self.netG = torch_default_init(MaskTwoStreamConvSwitch_NET(opt)).to(self.device)   # never weights_init'ed upstream
         self.loss_names = ['G_Recon_comb', 'G_Recon_obj', 'KL_loss', 'loss_G_GAN', 'loss_D_GAN', 'loss_G_GAN_Feat']
         self.reducer_G = self.reducer_D = None     # set by dist.attach_data_parallel (one process per GPU)
         if self.isTrain:

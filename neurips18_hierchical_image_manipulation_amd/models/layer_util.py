@@ -6,10 +6,32 @@ import torch.nn as nn
 from ..nn import Conv2d, InstanceNorm2d, ReLU, MaxPool, ResnetBlock, FusedSequential  # noqa: F401
 
 
-def weights_init(m, conv_sigma=0.02):
-    if m.__class__.__name__.find('Conv') != -1 and hasattr(m, 'weight'):
-        with torch.no_grad():
+def weights_init(m, conv_sigma=0.02, bnorm_sigma=0.02):
+    """reference :9-16: conv weights ~ N(0, conv_sigma); BatchNorm2d weight ~ N(1, bnorm_sigma), bias 0.  Applied by the
+    reference to the pix2pixHD generator / discriminator and to every discriminator class (``self.apply(weights_init)``)."""
+    name = m.__class__.__name__
+    with torch.no_grad():
+        if name.find('Conv') != -1 and hasattr(m, 'weight'):
             m.weight.normal_(0.0, conv_sigma)
+        elif name.find('BatchNorm2d') != -1:
+            m.weight.normal_(1.0, bnorm_sigma)
+            m.bias.fill_(0)
+
+
+def torch_default_init(net):
+    """The reference never calls ``weights_init`` on the box2mask generator (models/TwoStreamAE_mask.py builds
+    MaskTwoStreamConvSwitch_NET and uses it as constructed), so its layers keep ``torch.nn``'s construction-time
+    initialisation: conv / transposed-conv weights ~ U(+-1/sqrt(fan_in)) (kaiming_uniform with a = sqrt(5)), fan_in =
+    weight.size(1) * k * k, biases from the same bound; BatchNorm weight 1, bias 0."""
+    import math
+    with torch.no_grad():
+        for m in net.modules():
+            if m.__class__.__name__ in ('Conv2d', 'ConvTranspose2d') and hasattr(m, 'weight'):
+                bound = 1.0 / math.sqrt(m.weight.shape[1] * m.weight.shape[2] * m.weight.shape[3])
+                m.weight.uniform_(-bound, bound)
+                if m.bias is not None:
+                    m.bias.uniform_(-bound, bound)
+    return net
 
 
 def get_norm_layer(norm_type='instance'):
