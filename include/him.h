@@ -192,6 +192,11 @@ int him_conv2d_fwd_panel(const HimConv2d* d, const float* x, const void* panel, 
                          void* ws, size_t ws_bytes, void* stream);
 int him_conv2d_bwd_data_panel(const HimConv2d* d, const float* dy, const void* panel, float* dx, void* ws,
                               size_t ws_bytes, void* stream);
+/* Data gradient GATED by the ReLU that produced this layer's input x: dx[i] = x[i] > 0 ? dgrad(dy)[i] : 0  -- the
+ * activation backward of the PREVIOUS layer (models/layer_util.py:380-411 Vgg19: conv -> ReLU -> conv chains) done in
+ * this launch's epilogue instead of a separate pass over dx.  `panel` (him_conv2d_panel_build, kind BWD_DATA) or `w`. */
+int him_conv2d_bwd_data_gated(const HimConv2d* d, const float* dy, const float* w, const void* panel, const float* x,
+                              float* dx, void* ws, size_t ws_bytes, void* stream);
 size_t him_deconv2d_panel_bytes(const HimDeconv2d* d, int kind);
 int him_deconv2d_panel_build(const HimDeconv2d* d, int kind, const float* w, void* panel, size_t panel_bytes,
                              void* stream);
@@ -255,6 +260,8 @@ int him_avgpool3s2_bwd(const float* dy, float* dx, int planes, int H, int W, int
  * (models/Pix2Pix_NET.py:134). bwd routes to the first maximum in row-major window order. */
 int him_maxpool_fwd(const float* x, float* y, int planes, int H, int W, int k, void* stream);
 int him_maxpool_bwd(const float* x, const float* dy, float* dx, int planes, int H, int W, int k, void* stream);
+/* the same for a pool that follows a ReLU whose backward is folded in: windows with a non-positive maximum pass nothing */
+int him_maxpool_relu_bwd(const float* x, const float* dy, float* dx, int planes, int H, int W, int k, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Losses: models/losses.py:40-50 (LSGAN MSE vs a constant), nn.L1Loss pairs of
@@ -265,6 +272,8 @@ int him_maxpool_bwd(const float* x, const float* dy, float* dx, int planes, int 
 size_t him_reduce_ws(size_t n);
 int him_l1_mean_fwd(const float* a, const float* b, size_t n, float* out, void* ws, size_t ws_bytes,
                     void* stream);
+/* him_l1_mean_bwd: `accumulate` bit 0 = add into da, bit 1 = gate by a > 0 (a is a ReLU output whose activation
+ * backward is folded into this pass) */
 int him_l1_mean_bwd(const float* a, const float* b, size_t n, const float* g, float* da, int accumulate,
                     void* stream);
 int him_mse_const_fwd(const float* x, size_t n, float target, float* out, void* ws, size_t ws_bytes,

@@ -56,6 +56,7 @@ _SIGS = {
     'him_conv2d_panel_build': (c_int, [_CONV, c_int, P, P, c_size_t, P]),
     'him_conv2d_fwd_panel': (c_int, [_CONV, P, P, P, P, P, c_size_t, P]),
     'him_conv2d_bwd_data_panel': (c_int, [_CONV, P, P, P, P, c_size_t, P]),
+    'him_conv2d_bwd_data_gated': (c_int, [_CONV, P, P, P, P, P, P, c_size_t, P]),
     'him_deconv2d_panel_bytes': (c_size_t, [_DECONV, c_int]),
     'him_deconv2d_panel_build': (c_int, [_DECONV, c_int, P, P, c_size_t, P]),
     'him_deconv2d_fwd_panel': (c_int, [_DECONV, P, P, P, P, P, c_size_t, P]),
@@ -98,6 +99,7 @@ _SIGS = {
     'him_avgpool3s2_bwd': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'him_maxpool_fwd': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     'him_maxpool_bwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    'him_maxpool_relu_bwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     'him_reduce_ws': (c_size_t, [c_size_t]),
     'him_l1_mean_fwd': (c_int, [P, P, c_size_t, P, P, c_size_t, P]),
     'him_l1_mean_bwd': (c_int, [P, P, c_size_t, P, P, c_int, P]),

@@ -2394,7 +2394,7 @@ static size_t dgrad_panel_floats(const HimConv2d* d) {
 // panel == nullptr: regroup the weights into the workspace on every call; build_only: write the panel to ws and return
 static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float* out, const float* bias, int act,
                      float slope, void* ws, size_t ws_bytes, hipStream_t st, const float* panel = nullptr,
-                     bool build_only = false) {
+                     bool build_only = false, const float* relu_mask = nullptr, bool* mask_done = nullptr) {
   const size_t need = build_only ? dgrad_panel_floats(d) * sizeof(float) : dgrad_ws_bytes(d);
   if (!ws || ws_bytes < need) return fail(HIM_E_WORKSPACE, "dgrad needs %zu ws bytes, got %zu", need, ws_bytes);
   if (wino_fused_dgrad_ok(d)) {   // zero-padded 3x3 stride-1: the convolution of gy with the flipped / transposed filter
@@ -2404,8 +2404,9 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
       int rcu = check_launch("wino_fused_weight");
       if (rcu || build_only) return rcu;
     }
+    if (mask_done) *mask_done = relu_mask != nullptr;   // the gate rides in this kernel's epilogue
     return run_wino_fused(d->B, d->Cout, d->OH, d->OW, d->Cin, false, gy, panel ? panel : (const float*)ws, bias, act, slope,
-                          out, st);
+                          out, st, relu_mask);
   }
   if (wino_dgrad_ok(d) && panel && (bias || act != HIM_ACT_NONE))
     return fail(HIM_E_UNSUPPORTED, "dgrad: Winograd panel with a fused bias/activation epilogue");
@@ -2959,6 +2960,29 @@ int him_conv2d_bwd_data_panel(const HimConv2d* d, const float* dy, const void* p
   if (!panel) return fail(HIM_E_INVALID, "conv bwd_data: null panel");
   return run_dgrad(d, dy, nullptr, dx, nullptr, HIM_ACT_NONE, 0.f, ws, ws_bytes, (hipStream_t)stream,
                    (const float*)panel);
+}
+
+// dx = dgrad(dy) gated by the ReLU that produced this layer's input: dx[i] = x[i] > 0 ? dx[i] : 0.  Fused into the
+// epilogue where the layer runs the fused Winograd kernel; one elementwise pass behind the other kernels.
+__global__ void relu_gate_kernel(const float* __restrict__ x, float* __restrict__ dx, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dx[i] = x[i] > 0.f ? dx[i] : 0.f;
+}
+
+int him_conv2d_bwd_data_gated(const HimConv2d* d, const float* dy, const float* w, const void* panel, const float* x,
+                              float* dx, void* ws, size_t ws_bytes, void* stream) {
+  int rc = check_conv(d);
+  if (rc) return rc;
+  if (!x) return fail(HIM_E_INVALID, "conv bwd_data_gated: null input tensor");
+  if (!w && !panel) return fail(HIM_E_INVALID, "conv bwd_data_gated: neither weights nor a panel");
+  bool done = false;
+  rc = run_dgrad(d, dy, panel ? nullptr : w, dx, nullptr, HIM_ACT_NONE, 0.f, ws, ws_bytes, (hipStream_t)stream,
+                 (const float*)panel, false, x, &done);
+  if (rc || done) return rc;
+  const size_t n = (size_t)d->B * d->Cin * d->H * d->W;
+  hipLaunchKernelGGL(relu_gate_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 8192)), dim3(256), 0,
+                     (hipStream_t)stream, x, dx, n);
+  return check_launch("relu_gate");
 }
 
 size_t him_conv2d_bwd_weight_ws(const HimConv2d* d) {

@@ -228,8 +228,10 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
   }
 }
 // one thread per OUTPUT window: zero-fill the window then route the gradient to the first maximum
+// relu_gate: x is a ReLU output whose own activation backward is folded in here: a window whose maximum is not positive
+// passes no gradient (the ReLU derivative at the selected element is 0)
 __global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
-                                   int planes, int H, int W, int k) {
+                                   int planes, int H, int W, int k, int relu_gate) {
   const int OH = H / k, OW = W / k;
   const long long total = (long long)planes * OH * OW;
   GS_LOOP(i, total) {
@@ -249,7 +251,7 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __r
           am = a * W + b;
         }
       }
-    const float g = dy[i];
+    const float g = (relu_gate && !(m > 0.f)) ? 0.f : dy[i];
     for (int a = 0; a < k; ++a)
       for (int b = 0; b < k; ++b) dx[base + a * W + b] = (a * W + b) == am ? g : 0.f;
   }
@@ -360,7 +362,8 @@ int him_maxpool_fwd(const float* x, float* y, int planes, int H, int W, int k, v
                      planes, H, W, k);
   return check_launch("maxpool_fwd");
 }
-int him_maxpool_bwd(const float* x, const float* dy, float* dx, int planes, int H, int W, int k, void* stream) {
+static int maxpool_bwd_impl(const float* x, const float* dy, float* dx, int planes, int H, int W, int k, int relu_gate,
+                            void* stream) {
   if (k <= 0 || H / k <= 0 || W / k <= 0) return fail(HIM_E_INVALID, "maxpool: bad k");
   if (H % k || W % k) {
     hipLaunchKernelGGL(zero_tail_kernel, gs_grid((long long)planes * H * W), dim3(256), 0, ST, dx, planes, H, W, k);
@@ -368,8 +371,14 @@ int him_maxpool_bwd(const float* x, const float* dy, float* dx, int planes, int 
     if (rc) return rc;
   }
   hipLaunchKernelGGL(maxpool_bwd_kernel, gs_grid((long long)planes * (H / k) * (W / k)), dim3(256), 0, ST, x, dy, dx,
-                     planes, H, W, k);
+                     planes, H, W, k, relu_gate);
   return check_launch("maxpool_bwd");
+}
+int him_maxpool_bwd(const float* x, const float* dy, float* dx, int planes, int H, int W, int k, void* stream) {
+  return maxpool_bwd_impl(x, dy, dx, planes, H, W, k, 0, stream);
+}
+int him_maxpool_relu_bwd(const float* x, const float* dy, float* dx, int planes, int H, int W, int k, void* stream) {
+  return maxpool_bwd_impl(x, dy, dx, planes, H, W, k, 1, stream);
 }
 
 }  // extern "C"

@@ -55,8 +55,9 @@ __global__ void l1_bwd_kernel(const float* __restrict__ a, const float* __restri
   const float gs = g[0] * inv_n;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const float d = a[i] - b[i];
-    const float v = d > 0.f ? gs : (d < 0.f ? -gs : 0.f);
-    da[i] = accumulate ? da[i] + v : v;
+    float v = d > 0.f ? gs : (d < 0.f ? -gs : 0.f);
+    if ((accumulate & 2) && !(a[i] > 0.f)) v = 0.f;   // a is a ReLU output: its activation backward folded in
+    da[i] = (accumulate & 1) ? da[i] + v : v;
   }
 }
 __global__ void mse_bwd_kernel(const float* __restrict__ x, size_t n, float target, const float* __restrict__ g,

@@ -80,9 +80,16 @@ class Vgg19(nn.Module):
                         mapped[dst] = sd[src]
         self.load_state_dict(mapped)
 
-    def forward(self, X):
+    def forward(self, X, gated=False):
+        """[relu1_1, relu2_1, relu3_1, relu4_1, relu5_1].  ``gated`` (used by VGGLoss only, which owns every consumer of
+        the five outputs): each ReLU's backward is applied by whoever produces the gradient of its output -- the next
+        conv's data-gradient epilogue, the pool's backward, the L1 backward -- so no stand-alone activation-backward pass
+        runs over the 13 feature maps.  The caller MUST gate the gradients it sends into the outputs
+        (``ops.l1_weighted_sum(..., gate_relu=True)``)."""
+        from ..nn import run_layers
         out, h = [], X
+        state = {'prev_relu': False} if gated else None
         for k in range(5):
-            h = getattr(self, 'slice%d' % (k + 1))(h)
+            h = run_layers(list(getattr(self, 'slice%d' % (k + 1))), h, relu_gated=state)
             out.append(h)
         return out

@@ -1,4 +1,5 @@
 """GANLoss / VGGLoss of the reference's ``models/losses.py`` on fused HIP reductions."""
+import os
 import torch.nn as nn
 
 from .. import ops
@@ -25,6 +26,10 @@ class GANLoss(nn.Module):
         return ops.mse_const(input[-1], t)
 
 
+# ReLU backward of the VGG chain folded into the kernels that produce the gradients (see Vgg19.forward); 0 = separate passes
+_GATED = os.environ.get('HIM_VGG_GATED', '1') != '0'
+
+
 class VGGLoss(nn.Module):
     def __init__(self, gpu_ids=None, normalize=False):
         super().__init__()
@@ -40,7 +45,8 @@ class VGGLoss(nn.Module):
             return self.vgg(y)
 
     def forward(self, x, y, y_vgg=None):
-        x_vgg = self.vgg(x)
+        gated = _GATED and x.requires_grad
+        x_vgg = self.vgg(x, gated=gated)
         if y_vgg is None:
             y_vgg = self.target_features(y)
-        return ops.l1_weighted_sum(list(zip(x_vgg, y_vgg)), self.weights)
+        return ops.l1_weighted_sum(list(zip(x_vgg, y_vgg)), self.weights, gate_relu=gated)

@@ -132,9 +132,12 @@ class Tanh(nn.Module):
 _ACTS = (ReLU, LeakyReLU, Tanh)
 
 
-def run_layers(layers, x, final_residual=None):
+def run_layers(layers, x, final_residual=None, relu_gated=None):
     """Execute a list of marker layers / sub-modules on x with the fusion described in the module docstring.
-    ``final_residual`` is added by the LAST InstanceNorm of the list (ResnetBlock tail)."""
+    ``final_residual`` is added by the LAST InstanceNorm of the list (ResnetBlock tail).
+    ``relu_gated`` (a dict carrying ``prev_relu`` across calls): the list is a conv -> ReLU [-> MaxPool] chain whose
+    caller gates every gradient it feeds back into the chain's outputs (VGGLoss); each ReLU backward then rides in the
+    kernel that produces the gradient (next conv's data gradient / the pool's backward) instead of its own pass."""
     layers = list(layers)
     n, i = len(layers), 0
     last_norm = max([j for j, l in enumerate(layers) if isinstance(l, (InstanceNorm2d, BatchNorm2d))], default=-1)
@@ -175,7 +178,14 @@ def run_layers(layers, x, final_residual=None):
             else:
                 if pad_mode == 'reflect' and l.padding != 0:
                     raise ValueError('reflect pad + conv padding')
-                x = ops.conv2d(x, w, b, l.stride, rpad if pad_mode == 'reflect' else l.padding, pad_mode, epi, slope)
+                if relu_gated is not None and norm is None and epi == 'relu':
+                    x = ops.conv2d(x, w, b, l.stride, rpad if pad_mode == 'reflect' else l.padding, pad_mode, epi, slope,
+                                   grad_premasked=True, gate_dx=relu_gated.get('prev_relu', False))
+                    relu_gated['prev_relu'] = True
+                else:
+                    if relu_gated is not None:
+                        raise ValueError('relu_gated chains hold conv -> ReLU [-> MaxPool] only')
+                    x = ops.conv2d(x, w, b, l.stride, rpad if pad_mode == 'reflect' else l.padding, pad_mode, epi, slope)
             if norm is not None:
                 res = final_residual if (final_residual is not None and norm_idx == last_norm) else None
                 if res is not None and act is not None:
@@ -193,6 +203,12 @@ def run_layers(layers, x, final_residual=None):
             i += 1
         elif isinstance(l, _ACTS):
             raise ValueError('stand-alone activation is not on the hot path')
+        elif relu_gated is not None:
+            if not isinstance(l, MaxPool) or not relu_gated.get('prev_relu', False):
+                raise ValueError('relu_gated chains hold conv -> ReLU [-> MaxPool] only')
+            x = ops.maxpool(x, l.k, relu_gate=True)
+            relu_gated['prev_relu'] = False     # the pool's output gradient needs no gate
+            i += 1
         else:
             x = l(x)
             i += 1

@@ -266,11 +266,14 @@ _WINO_GEN = 0
 
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, pad_mode, act, slope):
+    def forward(ctx, x, w, b, stride, pad, pad_mode, act, slope, premasked=False, gate_dx=False):
         ctx.set_materialize_grads(False)   # an undefined gradient stays None: backward returns early
         x = x.contiguous()
         _chk(x, w, b)
         d = _conv_desc(x, w, stride, pad, pad_mode, act, slope)
+        if premasked and act != ACT_RELU:
+            raise HimError('conv2d: only a ReLU gate can be applied by the producers of the output gradient')
+        ctx.premasked, ctx.gate_dx = bool(premasked), bool(gate_dx)
         y = torch.empty((d.B, d.Cout, d.OH, d.OW), dtype=torch.float32, device=x.device)
         nb = lib.him_conv2d_fwd_ws(ctypes.byref(d))
         ws = _ws(nb, x)
@@ -290,11 +293,11 @@ class _Conv2d(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         if dy is None:
-            return (None,) * 8
+            return (None,) * 10
         d, x, w, b = ctx.d, ctx.x, ctx.w, ctx.b
         dy = dy.contiguous()
         st = _stream()
-        if d.act != ACT_NONE:
+        if d.act != ACT_NONE and not ctx.premasked:
             dz = torch.empty_like(dy)
             lib.him_act_bwd(_p(ctx.saved_tensors[0]), _p(dy), _p(dz), dy.numel(), d.act, d.slope, st)
         else:
@@ -319,7 +322,10 @@ class _Conv2d(torch.autograd.Function):
             nb = lib.him_conv2d_bwd_data_ws(ctypes.byref(d))
             ws = _ws(nb, x)
             pan = _panel(w, d, PANEL_BWD_DATA, False)
-            if pan:
+            if ctx.gate_dx:     # x is a ReLU output whose consumers apply its gate: dx = (x > 0) * dgrad
+                lib.him_conv2d_bwd_data_gated(ctypes.byref(d), _p(dz), 0 if pan else _p(w), pan or 0, _p(x), _p(dx),
+                                              _p(ws), nb, st)
+            elif pan:
                 lib.him_conv2d_bwd_data_panel(ctypes.byref(d), _p(dz), pan, _p(dx), _p(ws), nb, st)
             else:
                 lib.him_conv2d_bwd_data(ctypes.byref(d), _p(dz), _p(w), _p(dx), _p(ws), nb, st)
@@ -341,7 +347,7 @@ class _Conv2d(torch.autograd.Function):
                 dw = torch.empty_like(w) if need_w else None
                 db = torch.empty_like(b) if need_b else None
                 lib.him_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dz), _p(dw), _p(db), 0, _p(ws), nb, st)
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
 class _OneHotConv2d(torch.autograd.Function):
@@ -409,8 +415,13 @@ def mark_onehot(x, label, n_onehot):
     return x
 
 
-def conv2d(x, w, b=None, stride=1, pad=0, pad_mode='zero', act='none', slope=0.2):
-    """act(conv2d(pad(x), w) + b); pad_mode 'reflect' == nn.ReflectionPad2d(pad) + Conv2d(padding=0)."""
+def conv2d(x, w, b=None, stride=1, pad=0, pad_mode='zero', act='none', slope=0.2, grad_premasked=False, gate_dx=False):
+    """act(conv2d(pad(x), w) + b); pad_mode 'reflect' == nn.ReflectionPad2d(pad) + Conv2d(padding=0).
+
+    ReLU chains (VGG) can move every activation backward into the kernel that PRODUCES the gradient: with
+    ``grad_premasked`` the caller guarantees that every consumer of this layer's output multiplies the gradient it
+    sends back by (output > 0) -- this layer then skips its own ReLU backward pass; ``gate_dx`` makes this layer such a
+    consumer for its input (dx = (x > 0) * dgrad, in the data-gradient kernel's epilogue)."""
     oh = getattr(x, '_him_onehot', None) if _ONEHOT_ON else None
     if oh is not None and stride == 1 and not x.requires_grad:
         label, n_onehot = oh
@@ -419,7 +430,7 @@ def conv2d(x, w, b=None, stride=1, pad=0, pad_mode='zero', act='none', slope=0.2
         if lib.him_conv2d_onehot_fwd_ws(ctypes.byref(d), n_onehot):
             return _OneHotConv2d.apply(x, label, n_onehot, w, b, pad, pm, ACTS[act], float(slope))
     return _Conv2d.apply(x, w, b, stride, pad, PAD_REFLECT if pad_mode == 'reflect' else PAD_ZERO, ACTS[act],
-                         float(slope))
+                         float(slope), bool(grad_premasked), bool(gate_dx))
 
 
 class _Deconv2d(torch.autograd.Function):
@@ -831,30 +842,33 @@ def avgpool3s2(x):
 
 class _MaxPool(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, k):
+    def forward(ctx, x, k, relu_gate=False):
         ctx.set_materialize_grads(False)   # an undefined gradient stays None: backward returns early
         x = x.contiguous()
         _chk(x)
         B, Cn, H, W = x.shape
         y = torch.empty((B, Cn, H // k, W // k), dtype=torch.float32, device=x.device)
         lib.him_maxpool_fwd(_p(x), _p(y), B * Cn, H, W, k, _stream())
-        ctx.x, ctx.k = x, k
+        ctx.x, ctx.k, ctx.relu_gate = x, k, bool(relu_gate)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         if dy is None:
-            return None, None
+            return None, None, None
         x, k = ctx.x, ctx.k
         B, Cn, H, W = x.shape
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        lib.him_maxpool_bwd(_p(x), _p(dy), _p(dx), B * Cn, H, W, k, _stream())
-        return dx, None
+        (lib.him_maxpool_relu_bwd if ctx.relu_gate else lib.him_maxpool_bwd)(_p(x), _p(dy), _p(dx), B * Cn, H, W, k,
+                                                                            _stream())
+        return dx, None, None
 
 
-def maxpool(x, k):
-    return _MaxPool.apply(x, int(k))
+def maxpool(x, k, relu_gate=False):
+    """``relu_gate``: x is the output of a ReLU layer that was told its gradient arrives gated (conv2d's
+    ``grad_premasked``): the pool's backward applies (x > 0) to what it routes."""
+    return _MaxPool.apply(x, int(k), bool(relu_gate))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1093,8 +1107,9 @@ class _L1WeightedSum(torch.autograd.Function):
     ``loss = loss + w * l1(...) * lambda`` scalar kernels (3 launches forward + 2 backward per term)."""
 
     @staticmethod
-    def forward(ctx, wvec, *tensors):
+    def forward(ctx, wvec, gate, *tensors):
         ctx.set_materialize_grads(False)
+        ctx.gate = bool(gate)
         n = len(tensors) // 2
         a_s = [t.contiguous() for t in tensors[:n]]
         b_s = [t.contiguous() for t in tensors[n:]]
@@ -1113,31 +1128,32 @@ class _L1WeightedSum(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         if g is None:
-            return (None,) * (1 + 2 * len(ctx.a_s))
+            return (None,) * (2 + 2 * len(ctx.a_s))
         gw = (g * ctx.wvec).contiguous()
         st = _stream()
         grads = []
         for i, (a, b) in enumerate(zip(ctx.a_s, ctx.b_s)):
-            if ctx.needs_input_grad[1 + i]:
+            if ctx.needs_input_grad[2 + i]:
                 da = torch.empty_like(a)
-                lib.him_l1_mean_bwd(_p(a), _p(b), a.numel(), gw.data_ptr() + 4 * i, _p(da), 0, st)
+                lib.him_l1_mean_bwd(_p(a), _p(b), a.numel(), gw.data_ptr() + 4 * i, _p(da), 2 if ctx.gate else 0, st)
                 grads.append(da)
             else:
                 grads.append(None)
-        return (None,) + tuple(grads) + (None,) * len(ctx.b_s)
+        return (None, None) + tuple(grads) + (None,) * len(ctx.b_s)
 
 
 _WVEC_CACHE = {}
 
 
-def l1_weighted_sum(pairs, weights):
-    """sum_i weights[i] * nn.L1Loss()(a_i, b_i.detach()) for pairs = [(a_i, b_i), ...]."""
+def l1_weighted_sum(pairs, weights, gate_relu=False):
+    """sum_i weights[i] * nn.L1Loss()(a_i, b_i.detach()) for pairs = [(a_i, b_i), ...].  ``gate_relu``: every a_i is the
+    output of a ReLU layer built with ``grad_premasked`` -- the gradients sent back carry the (a_i > 0) gate."""
     dev = pairs[0][0].device
     key = (dev, tuple(float(w) for w in weights))
     wvec = _WVEC_CACHE.get(key)
     if wvec is None:
         wvec = _WVEC_CACHE[key] = torch.tensor(key[1], dtype=torch.float32, device=dev)
-    return _L1WeightedSum.apply(wvec, *([a for a, _ in pairs] + [b.detach() for _, b in pairs]))
+    return _L1WeightedSum.apply(wvec, bool(gate_relu), *([a for a, _ in pairs] + [b.detach() for _, b in pairs]))
 
 
 class _MSEConst(torch.autograd.Function):

@@ -465,3 +465,68 @@ def test_compact_inputs_uint8_labels_and_device_masked_image():
         buf, n_label, n_cond = ops.encode_channels(lab, None, img.to(DEV), m.to(DEV), 35, False)
         bufs.append(buf)
     assert torch.equal(bufs[0], bufs[1]) and bufs[0].shape[1] == 38
+
+
+@pytest.mark.parametrize('shape', [(2, 3, 64, 96), (1, 3, 48, 80)], ids=str)
+def test_vgg_loss_gated_relu_backward_is_identical(shape):
+    """VGGLoss with every ReLU backward folded into the gradient PRODUCERS (next conv's data-gradient epilogue -- the fused
+    Winograd kernel's gate or the gate pass behind the other kernels --, the pool's backward, the L1 backward) against the
+    plain form with one activation-backward pass per layer: same loss, bit-identical image gradient; and both against the
+    CPU restatement of the reference's VGGLoss."""
+    from neurips18_hierchical_image_manipulation_amd.models import losses
+    from oracle import ref_cpu
+    torch.manual_seed(3)
+    crit = losses.VGGLoss().to(DEV)
+    x = _rand(*shape, seed=11)
+    y = _rand(*shape, seed=12)
+    got = {}
+    for gated in (True, False):
+        losses._GATED = gated
+        try:
+            xd = x.to(DEV).requires_grad_(True)
+            loss = crit(xd, y.to(DEV))
+            (gx,) = torch.autograd.grad(loss, xd)
+            got[gated] = (float(loss), gx.cpu())
+        finally:
+            losses._GATED = True
+    assert got[True][0] == got[False][0]
+    assert torch.equal(got[True][1], got[False][1])
+    vgg = ref_cpu.Vgg19()
+    vgg.load_state_dict({k: v.cpu() for k, v in crit.vgg.state_dict().items()})
+    xr = x.clone().requires_grad_(True)
+    lr = ref_cpu.vgg_loss(vgg, xr, y)
+    (gr,) = torch.autograd.grad(lr, xr)
+    assert abs(got[True][0] - float(lr)) <= 1e-5 * abs(float(lr))
+    # 13 fp32 layers deep with sign() / argmax / ReLU decisions on the way: single elements flip, the field agrees
+    rel = float((got[True][1].double() - gr.double()).norm() / gr.double().norm())
+    assert rel < 2e-2, rel
+
+
+def test_gated_ops_match_plain_ops():
+    """The three gate carriers one by one against 'plain op, then ReLU mask'."""
+    ops = _ops()
+    # data gradient with the gate (fused-Winograd shape and a direct-form shape)
+    for (B, C, H, W, Co, k, p) in ((2, 64, 16, 24, 64, 3, 1), (2, 24, 9, 11, 40, 3, 1), (1, 16, 12, 12, 8, 4, 2)):
+        x = torch.relu(_rand(B, C, H, W, seed=5)).to(DEV).requires_grad_(True)
+        w = _rand(Co, C, k, k, seed=6, scale=0.1).to(DEV)
+        gy = None
+        outs = []
+        for gate in (True, False):
+            y = ops.conv2d(x, w, None, 1, p, 'zero', 'none', 0.0, gate_dx=gate)
+            gy = _rand(*y.shape, seed=7).to(DEV) if gy is None else gy
+            (gx,) = torch.autograd.grad(y, x, gy)
+            outs.append(gx)
+        assert torch.equal(outs[0], outs[1] * (x.detach() > 0)), (B, C, H, W, Co, k)
+    # pool
+    x = torch.relu(_rand(2, 5, 12, 16, seed=8)).to(DEV).requires_grad_(True)
+    x.data[:, :, :4] = 0                                       # whole windows of zeros
+    gy = _rand(2, 5, 6, 8, seed=9).to(DEV)
+    (g1,) = torch.autograd.grad(ops.maxpool(x, 2, relu_gate=True), x, gy)
+    (g0,) = torch.autograd.grad(ops.maxpool(x, 2), x, gy)
+    assert torch.equal(g1, g0 * (x.detach() > 0)) and float(g0[:, :, :4].abs().sum()) > 0
+    # L1
+    a = torch.relu(_rand(2, 3, 8, 8, seed=10)).to(DEV).requires_grad_(True)
+    b = _rand(2, 3, 8, 8, seed=11).to(DEV)
+    (g1,) = torch.autograd.grad(ops.l1_weighted_sum([(a, b)], [0.5], gate_relu=True), a)
+    (g0,) = torch.autograd.grad(ops.l1_weighted_sum([(a, b)], [0.5]), a)
+    assert torch.equal(g1, g0 * (a.detach() > 0))
