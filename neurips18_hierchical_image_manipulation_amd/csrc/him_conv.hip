@@ -550,6 +550,100 @@ static bool fewout_tiled_ok(const GConvP& p) {
   return (long long)p.B * cdiv(p.SW, 64) * cdiv(p.SH, 16) >= 512;      // enough tiles for 256 CUs
 }
 
+// =============================================================================================
+// The mirror case: few REDUCTION channels (C2 <= 4), many outputs -- the data gradient of the generator's 7x7 head
+// (3 -> 64 on the reflection-padded 262x518 plane, followed by the fold) and of any 3x3 / 7x7 layer with <= 4 outputs.
+// K = C2*KS*KS = 147 is too ragged for the tap-major MFMA gather (30 TFLOP/s); same tiling as above with the roles
+// swapped: the patch of all C2 channels sits in LDS once, every thread keeps 4 pixels x 16 outputs in registers
+// (grid.z walks the groups of 16 outputs) and the 16 weights of a tap are scalar loads.
+// Geometry: src y = a + offy + (FLIP ? -jh : jh), zero outside the source plane; output plane NA x NC.
+// =============================================================================================
+template <int KS, bool FLIP>
+__global__ __launch_bounds__(256) void gconv_fewin_tiled_kernel(const GConvP p) {
+  constexpr int TH = 16, TW = 64, MG = 16, MAXC = 4;
+  constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
+  constexpr int RS = (PW + 3) & ~3;
+  __shared__ __attribute__((aligned(16))) float tile[MAXC][PH * RS];
+  const GPhase& ph = p.ph[0];
+  const int H = p.SH, W = p.SW, C = p.C2, K = ph.K, OHt = ph.NA, OWt = ph.NC;
+  const int tiles_x = (OWt + TW - 1) / TW;
+  const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x, b = blockIdx.y, m0 = blockIdx.z * MG;
+  const int y0 = by * TH, x0 = bx * TW;
+  const int tid = threadIdx.x, ty = tid >> 4, tx = (tid & 15) * 4;
+  const int py0 = y0 + ph.offy - (FLIP ? KS - 1 : 0), px0 = x0 + ph.offx - (FLIP ? KS - 1 : 0);
+  const float* __restrict__ src = p.src + (size_t)b * C * H * W;
+  for (int i = tid; i < C * PH * PW; i += 256) {
+    const int c = i / (PH * PW), r2 = i - c * PH * PW, r = r2 / PW, cc = r2 - r * PW;
+    const int iy = py0 + r, ix = px0 + cc;
+    tile[c][r * RS + cc] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? src[((size_t)c * H + iy) * W + ix] : 0.f;
+  }
+  __syncthreads();
+  float acc[MG][4];
+#pragma unroll
+  for (int m = 0; m < MG; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[m][q] = 0.f;
+  const float* __restrict__ A = ph.A + (size_t)m0 * K;
+  for (int c = 0; c < C; ++c) {
+#pragma unroll 1
+    for (int jh = 0; jh < KS; ++jh) {
+      const float* __restrict__ row = &tile[c][(ty + (FLIP ? KS - 1 - jh : jh)) * RS + tx];
+      float v[4 + KS - 1 + 1];
+      *(float4*)&v[0] = *(const float4*)&row[0];
+      if (KS == 3) {
+        *(float2*)&v[4] = *(const float2*)&row[4];
+      } else {
+        *(float4*)&v[4] = *(const float4*)&row[4];
+        *(float2*)&v[8] = *(const float2*)&row[8];
+      }
+      const float* __restrict__ Ar = A + (c * KS + jh) * KS;
+#pragma unroll
+      for (int jw = 0; jw < KS; ++jw)
+#pragma unroll
+        for (int m = 0; m < MG; ++m) {
+          const float w = Ar[(size_t)m * K + jw];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[m][q] = fmaf(w, v[q + (FLIP ? KS - 1 - jw : jw)], acc[m][q]);
+        }
+    }
+  }
+  const int oy = y0 + ty, ox = x0 + tx;
+  if (oy >= OHt) return;
+#pragma unroll
+  for (int m = 0; m < MG; ++m) {
+    float* __restrict__ out = p.dst + (((size_t)b * p.M + m0 + m) * p.DH + oy) * p.DW + ox;
+    const float bb = p.bias ? p.bias[m0 + m] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (ox + q < OWt) out[q] = apply_act(acc[m][q] + bb, p.act, p.slope);
+  }
+}
+
+static bool fewin_tiled_ok(const GConvP& p) {
+  static const bool off = getenv("HIM_NO_FEWIN_TILED") != nullptr;
+  if (off || p.nphase != 1 || p.C2 > 4 || p.M < 16 || (p.M % 16) != 0 || p.ksplit > 1) return false;
+  const GPhase& ph = p.ph[0];
+  const int ks = ph.JH;
+  if (ph.JW != ks || (ks != 3 && ks != 7)) return false;
+  if (p.sy != 1 || p.sx != 1 || p.oys != 1 || p.oxs != 1 || ph.oy0 != 0 || ph.ox0 != 0) return false;
+  if (!((p.dy == 1 && p.dx == 1) || (p.dy == -1 && p.dx == -1))) return false;
+  if (p.pad_mode != HIM_PAD_ZERO || ph.NA != p.DH || ph.NC != p.DW || p.B > 65535) return false;
+  return (long long)p.B * cdiv(ph.NC, 64) * cdiv(ph.NA, 16) >= 512;
+}
+
+static void launch_fewin_tiled(const GConvP& p, hipStream_t st) {
+  const GPhase& ph = p.ph[0];
+  dim3 grid(cdiv(ph.NC, 64) * cdiv(ph.NA, 16), p.B, p.M / 16);
+  const bool flip = p.dy < 0;
+  if (ph.JH == 7) {
+    if (flip) hipLaunchKernelGGL((gconv_fewin_tiled_kernel<7, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gconv_fewin_tiled_kernel<7, false>), grid, dim3(256), 0, st, p);
+  } else {
+    if (flip) hipLaunchKernelGGL((gconv_fewin_tiled_kernel<3, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gconv_fewin_tiled_kernel<3, false>), grid, dim3(256), 0, st, p);
+  }
+}
+
 template <int MM, int TJ>
 static void launch_small_cfg(const GConvP& p, long long maxN, hipStream_t st) {
   const bool split = maxN < 256 * 512 && p.C2 >= 64;  // too few positions to fill 256 CUs: split the channels
@@ -623,6 +717,10 @@ static int launch_gconv(const GConvP& p, hipStream_t st) {
   }
   if (maxN == 0 || p.M <= 0) return HIM_OK;
   if (launch_gconv_small(p, maxN, st)) return check_launch("gconv_small");
+  if (fewin_tiled_ok(p)) {
+    launch_fewin_tiled(p, st);
+    return check_launch("gconv_fewin_tiled");
+  }
   if (p.fast) {
     // the fast kernel gathers through a buffer resource: 31-bit byte offsets (larger tensors: split the batch)
     if ((unsigned long long)p.B * p.C2 * p.SH * p.SW * 4ull >= (1ull << 31))

@@ -72,6 +72,10 @@ CONV_CASES = [
     (36, 3, 40, 66, 16, 3, 1, 1, 'zero', 'relu'),        # tiled few-output kernel as the DATA GRADIENT of a 3 -> 16 3x3 layer (flipped taps), ragged
     (8, 2, 130, 250, 8, 3, 1, 1, 'zero', 'none'),        # the same with 2 input channels, W % 4 != 0 (scalar stores)
     (34, 12, 33, 65, 4, 3, 1, 1, 'zero', 'none'),        # tiled few-output forward, 4 outputs, 3x3 zero padding, odd plane
+    (8, 32, 128, 250, 3, 7, 1, 3, 'reflect', 'none'),    # few-INPUT tiled kernel: data gradient of the G head (3 -> 32 on the padded plane + fold)
+    (8, 16, 130, 250, 2, 3, 1, 1, 'zero', 'none'),       # few-input tiled kernel: data gradient of a 2-output 3x3 layer
+    (8, 3, 128, 256, 32, 3, 1, 1, 'zero', 'relu'),       # few-input tiled kernel, forward form (VGG conv1_1), bias + ReLU
+    (8, 4, 120, 250, 16, 7, 1, 3, 'zero', 'none'),       # few-input tiled kernel, forward 7x7, ragged tiles
 ]
 
 
