@@ -1,9 +1,2 @@
-"""reference data/base_data_loader.py"""
-
-
-class BaseDataLoader(object):
-    def initialize(self, opt):
-        self.opt = opt
-
-    def load_data(self):
-        return None
+"""Import location of the reference's ``BaseDataLoader`` (data/base_data_loader.py)."""
+from .custom_dataset_data_loader import BaseDataLoader  # noqa: F401

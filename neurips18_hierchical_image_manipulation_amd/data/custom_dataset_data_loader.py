@@ -9,18 +9,23 @@ import torch
 import torch.utils.data
 
 from . import device as dv
-from .base_data_loader import BaseDataLoader
+
+
+class BaseDataLoader(object):
+    """reference data/base_data_loader.py: keeps ``opt``; ``load_data`` is the subclass's."""
+
+    def initialize(self, opt):
+        self.opt = opt
+
+    def load_data(self):
+        return None
 
 
 def CreateDataset(opt):
-    if opt.dataloader == 'cityscape':
-        from .cityscape_dataset import CityscapeDataset
-        dataset = CityscapeDataset()
-    elif opt.dataloader == 'ade20k':
-        from .ade20k_dataset import ADE20KDataset
-        dataset = ADE20KDataset()
-    else:
-        raise ValueError('unknown --dataloader %r (cityscape | ade20k)' % (opt.dataloader,))
+    from .segmentation_dataset import DATASETS
+    if opt.dataloader not in DATASETS:
+        raise ValueError('unknown --dataloader %r (%s)' % (opt.dataloader, ' | '.join(sorted(DATASETS))))
+    dataset = DATASETS[opt.dataloader]()
     print("dataset [%s] was created" % (dataset.name()))
     dataset.initialize(opt)
     return dataset
@@ -95,3 +100,11 @@ class CustomDatasetDataLoader(BaseDataLoader):
 
     def __len__(self):
         return min(len(self.dataset), self.opt.max_dataset_size)
+
+
+def CreateDataLoader(opt):
+    """reference data/data_loader.py:3-7: the one entry point the training scripts call."""
+    loader = CustomDatasetDataLoader()
+    print(loader.name())
+    loader.initialize(opt)
+    return loader

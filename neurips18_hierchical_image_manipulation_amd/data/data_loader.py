@@ -1,9 +1,2 @@
-"""reference data/data_loader.py:3-7"""
-from .custom_dataset_data_loader import CustomDatasetDataLoader
-
-
-def CreateDataLoader(opt):
-    data_loader = CustomDatasetDataLoader()
-    print(data_loader.name())
-    data_loader.initialize(opt)
-    return data_loader
+"""``from data.data_loader import CreateDataLoader`` of the training scripts (reference data/data_loader.py)."""
+from .custom_dataset_data_loader import CreateDataLoader, CustomDatasetDataLoader  # noqa: F401

@@ -180,3 +180,21 @@ class SegmentationDataset(BaseDataset):
     def __getitem__(self, index):
         batch = self.assemble([self.host_record(index)])
         return {k: v[0] for k, v in batch.items()}
+
+
+def _dataset_with_classes(cls_name, shown_name, classes, where):
+    """The two shipped datasets differ from SegmentationDataset only in the classes an object may be sampled from."""
+    def initialize(self, opt):
+        SegmentationDataset.initialize(self, opt)
+        self.class_of_interest = list(classes)
+    return type(cls_name, (SegmentationDataset,), {'initialize': initialize, 'name': lambda self: shown_name,
+                                                   '__doc__': 'reference %s' % where})
+
+
+# Cityscapes: person ... bicycle (trainId-free label ids 24-33, data/cityscape_dataset.py:8)
+CityscapeDataset = _dataset_with_classes('CityscapeDataset', 'CitiscapeDataset', range(24, 34),
+                                         'data/cityscape_dataset.py')
+# ADE20K: ids 2..38 without 3, 6, 27, 34 (data/ade20k_dataset.py:8-10)
+ADE20KDataset = _dataset_with_classes('ADE20KDataset', 'ADE20KDataset',
+                                      [c for c in range(2, 39) if c not in (3, 6, 27, 34)], 'data/ade20k_dataset.py')
+DATASETS = {'cityscape': CityscapeDataset, 'ade20k': ADE20KDataset}
