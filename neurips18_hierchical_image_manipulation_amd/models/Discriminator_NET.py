@@ -17,7 +17,11 @@ class MultiscaleDiscriminator(nn.Module):
             raise NotImplementedError('normalization layer [%s] is not found' % norm_layer)
         norm = InstanceNorm2d if norm_layer == 'instance' else BatchNorm2d   # 'batch': the box2mask discriminator
         if use_sigmoid:
-            raise NotImplementedError('--no_lsgan (sigmoid + BCE) is not on the HIP path; LSGAN only')
+            # The reference cannot run this either: MultiscaleDiscriminator copies only model0..model<n_layers+1> of each
+            # NLayerDiscriminator when getIntermFeat is set (Discriminator_NET.py:24-27), which drops the trailing Sigmoid,
+            # so GANLoss's nn.BCELoss (losses.py:19-20) is fed raw logits (an error in torch >= 0.4, NaNs before).
+            raise NotImplementedError('--no_lsgan: the reference drops the Sigmoid in front of its BCELoss on this path '
+                                      '(Discriminator_NET.py:24-27); LSGAN only')
         if not getIntermFeat:
             raise NotImplementedError('the mask2image model always asks for intermediate features')
         self.num_D, self.n_layers = num_D, n_layers
