@@ -79,7 +79,7 @@ if __name__ == '__main__':
                 res[name] = run(tag, 8, pv)
                 print(name, ' '.join('%.1e' % x for x in res[name]), flush=True)
             if pv == 1e-6:                       # two more draws of the same-size perturbation
-                for sd in (1, 2):
+                for sd in ((1, 2, 3, 4, 5) if key == 'c2' else (1, 2)):   # c2: the configuration with the thinnest margin
                     nm = '%s_s%d' % (name, sd)
                     if nm not in res:
                         res[nm] = run(tag, 8, pv, sd)

@@ -22,6 +22,8 @@ SHAPES = [
     ('d_head', 8, 512, 34, 66, 1, 4, 1, 2, 'zero'),
     ('g_head', 8, 64, 256, 512, 3, 7, 1, 3, 'reflect'),
     ('vgg_3_64', 8, 3, 256, 512, 64, 3, 1, 1, 'zero'),
+    ('b2m_stem_70_64', 32, 70, 256, 256, 64, 5, 1, 2, 'zero'),
+    ('b2m_d_71_64_s2', 32, 71, 256, 256, 64, 4, 2, 2, 'zero'),
 ]
 
 
