@@ -46,24 +46,23 @@ def map_bytes(img):
 
 
 class _Staging(object):
-    """Byte sections appended with 16-byte alignment; uploaded with one pinned copy."""
+    """Sections laid out with 16-byte alignment; written straight into one pinned buffer and uploaded with one copy."""
 
     def __init__(self):
         self.parts, self.size = [], 0
 
     def add(self, array):
         a = np.ascontiguousarray(array)
-        pad = (-self.size) % 16
-        if pad:
-            self.parts.append(b'\0' * pad)
-            self.size += pad
-        at = self.size
-        self.parts.append(a.tobytes())
-        self.size += a.nbytes
+        at = self.size + ((-self.size) % 16)
+        self.parts.append((at, a))
+        self.size = at + a.nbytes
         return at
 
     def upload(self, dev):
-        host = torch.frombuffer(bytearray(b''.join(self.parts)), dtype=torch.uint8).pin_memory()
+        host = torch.empty(max(self.size, 16), dtype=torch.uint8, pin_memory=True)
+        view = host.numpy()
+        for at, a in self.parts:
+            view[at:at + a.nbytes] = a.reshape(-1).view(np.uint8)
         return host.to(dev, non_blocking=True)
 
 

@@ -79,6 +79,14 @@ def test_resample_tables_reproduce_pillow(seed):
         assert np.array_equal(got, ref), (h, w, ow, oh)
 
 
+def test_vectorised_tables_equal_the_scalar_transcription():
+    rng = np.random.RandomState(4)
+    for _ in range(400):
+        a, b = int(rng.randint(1, 2100)), int(rng.randint(1, 600))
+        x, y = resample.bicubic_tables(a, b), resample.bicubic_tables_scalar(a, b)
+        assert x[3] == y[3] and all(np.array_equal(p, q) for p, q in zip(x[:3], y[:3])), (a, b)
+
+
 def test_identity_tables():
     first, count, weights, ksize = resample.bicubic_tables(40, 40)
     one = 1 << resample.PRECISION_BITS
