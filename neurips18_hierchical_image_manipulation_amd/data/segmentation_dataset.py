@@ -122,6 +122,9 @@ class SegmentationDataset(BaseDataset):
         def ids(key, times_255, size=(H, W), flip=flips):
             wins = [r[key] for r in records]
             plan = dv.MapPlan(wins, size[0], size[1], flip)
+            if compact and key == 'label' and plan.windows[0].dtype != np.uint8:
+                raise ValueError('--compact_labels needs 8-bit label files (got %s): the ids would be truncated'
+                                 % plan.windows[0].dtype)
             out = 'uint8' if (compact and key == 'label') else self._ids(plan.windows, 0, 0, 0, times_255)
             kind, dtype = dv._MAP_OUT[out]
             dst = torch.empty((B, 1, size[0], size[1]), dtype=dtype, device=dev)
@@ -157,8 +160,16 @@ class SegmentationDataset(BaseDataset):
         def body(base, stream):
             keep = [fn(base, stream) for fn in work]
             if region:
-                label = out['label'] if out['label'].dtype == torch.float32 else out['label'].float()
+                # the reference builds the region masks from the tensors it RETURNS: label * 255 (16/32-bit label files:
+                # ToTensor() leaves the integers, then * 255.0) and, for ade20k, inst * 255 compared with bbox_inst_id
+                label = out['label']
+                if label.dtype == torch.int32:
+                    label = label.float() * 255.0
+                elif label.dtype != torch.float32:
+                    label = label.float()
                 inst = out['inst']
+                if inst.dtype == torch.int32 and self.opt.dataloader in _TIMES_255:
+                    inst = inst * 255
                 names = ('mask_in', 'mask_object_in', 'mask_context_in', 'mask_out', 'mask_object_out',
                          'mask_object_inst')
                 out.update(zip(names, masks.run(base, label, inst, stream)))

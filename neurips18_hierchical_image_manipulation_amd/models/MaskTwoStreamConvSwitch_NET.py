@@ -47,6 +47,8 @@ def _conv(l, x, pad_mode='zero', pad=None, norm=None):
                                                  (isinstance(norm, BatchNorm2d) and norm.training)):
         l.bias._him_dead_grad = True
         b = b.detach()
+    elif b is not None and getattr(l.bias, '_him_dead_grad', False):
+        l.bias._him_dead_grad = False       # BatchNorm went to eval(): the bias gradient is live again (nn.run_layers)
     return ops.conv2d(x, _pw(l.weight), b, l.stride, l.padding if pad is None else pad, pad_mode, 'none', 0.0)
 
 
@@ -92,6 +94,8 @@ class DeconvResnetBlock(nn.Module):
         if b is not None and hn._DEAD_BIAS_SKIP and (isinstance(nrm, InstanceNorm2d) or nrm.training):
             d.bias._him_dead_grad = True
             b = b.detach()
+        elif b is not None and getattr(d.bias, '_him_dead_grad', False):
+            d.bias._him_dead_grad = False
         y = ops.conv_transpose2d(r, _pw(d.weight), b, d.stride, d.padding, d.output_padding, 'none', 0.0)
         return nrm.apply_to(y, residual=res)
 
@@ -116,8 +120,12 @@ class _BiasFreeConv3x3(nn.Module):
     def __init__(self, cin, cout, dilation):
         super().__init__()
         import torch
+        import math
         self.dilation = dilation
-        self.weight = nn.Parameter(torch.randn(cout, cin, 3, 3) * 0.02)
+        # construction-time init of the nn.Conv2d the reference builds here (kaiming_uniform, a = sqrt(5)):
+        # U(+-1/sqrt(fan_in)); the box2mask generator is never passed through weights_init
+        bound = 1.0 / math.sqrt(cin * 9)
+        self.weight = nn.Parameter((torch.rand(cout, cin, 3, 3) * 2 - 1) * bound)
 
 
 class DilatedResnetBlock(nn.Module):

@@ -26,10 +26,10 @@ def torch_default_init(net):
     import math
     with torch.no_grad():
         for m in net.modules():
-            if m.__class__.__name__ in ('Conv2d', 'ConvTranspose2d') and hasattr(m, 'weight'):
+            if m.__class__.__name__ in ('Conv2d', 'ConvTranspose2d', '_BiasFreeConv3x3') and hasattr(m, 'weight'):
                 bound = 1.0 / math.sqrt(m.weight.shape[1] * m.weight.shape[2] * m.weight.shape[3])
                 m.weight.uniform_(-bound, bound)
-                if m.bias is not None:
+                if getattr(m, 'bias', None) is not None:
                     m.bias.uniform_(-bound, bound)
     return net
 

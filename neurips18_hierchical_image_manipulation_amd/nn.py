@@ -173,6 +173,10 @@ def run_layers(layers, x, final_residual=None, relu_gated=None):
                 # pass -- a full read of dy per layer -- is skipped and the parameter stays where it is.
                 l.bias._him_dead_grad = True
                 b = b.detach()
+            elif b is not None and getattr(l.bias, '_him_dead_grad', False):
+                # the same conv now runs WITHOUT a mean-subtracting norm behind it (BatchNorm switched to eval()): its
+                # bias gradient is live again and the data-parallel reducer must count it (dist.GradReducer.begin)
+                l.bias._him_dead_grad = False
             if l.transposed:
                 x = ops.conv_transpose2d(x, w, b, l.stride, l.padding, l.output_padding, epi, slope)
             else:

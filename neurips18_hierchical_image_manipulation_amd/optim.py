@@ -155,17 +155,32 @@ class FusedAdam(object):
                 self.exp_avg_sq.zero_()
                 self.step_count = 0
             else:
-                keys = sorted(st.keys(), key=lambda k: int(k))
-                if len(keys) != len(a.params):
-                    raise ValueError('optimizer state holds %d parameters, the arena %d' % (len(keys), len(a.params)))
-                for k, p in zip(keys, a.params):
-                    if tuple(st[k]['exp_avg'].shape) != tuple(p.shape):
+                # Parameter ORDER comes from the file's own param_groups: torch >= 1.6 keys the state by index, but the
+                # reference's era (torch 0.3 / 0.4) keys it by id(p) -- memory addresses, also listed per group -- whose
+                # numeric order says nothing about the parameter order.  A parameter without an entry (never received a
+                # gradient) gets zero moments, as torch does.
+                order = [pid for g in sd['param_groups'] for pid in g['params']]
+                if len(order) != len(a.params):
+                    raise ValueError('optimizer state lists %d parameters, the arena holds %d' % (len(order), len(a.params)))
+                unknown = [k for k in st.keys() if k not in set(order)]
+                if unknown:
+                    raise ValueError('optimizer state has entries no param_group lists: %s' % unknown[:4])
+                ms, vs, steps = [], [], set()
+                for pid, p in zip(order, a.params):
+                    e = st.get(pid)
+                    if e is None:
+                        ms.append(torch.zeros(p.shape))
+                        vs.append(torch.zeros(p.shape))
+                        continue
+                    if tuple(e['exp_avg'].shape) != tuple(p.shape):
                         raise ValueError('optimizer state %s: shape %s vs parameter %s'
-                                         % (k, tuple(st[k]['exp_avg'].shape), tuple(p.shape)))
-                steps = set(int(float(st[k]['step'])) for k in keys)
+                                         % (pid, tuple(e['exp_avg'].shape), tuple(p.shape)))
+                    ms.append(e['exp_avg'])
+                    vs.append(e['exp_avg_sq'])
+                    steps.add(int(float(e['step'])))
                 if len(steps) != 1:
                     raise ValueError('per-parameter step counts differ (%s): one fused step count only' % sorted(steps))
-                self.load_moments([st[k]['exp_avg'] for k in keys], [st[k]['exp_avg_sq'] for k in keys], steps.pop())
+                self.load_moments(ms, vs, steps.pop())
             for g, s in zip(self.param_groups, sd['param_groups']):
                 for k in ('lr', 'betas', 'eps'):
                     if k in s:

@@ -201,6 +201,31 @@ def test_fused_adam_state_dict_is_torch_adam_format():
     fa2 = FusedAdam([torch.nn.Parameter(p.detach().clone()) for p in tp])
     fa2.load_state_dict(legacy)
     assert fa2.step_count == 2
+    # torch < 1.6 (the reference's 0.3 / 0.4): 'state' keyed by id(p) -- memory addresses whose numeric order is NOT the
+    # parameter order -- with the same addresses listed in param_groups; two equal-shaped tensors (2 and 4 below) make
+    # a wrong assignment invisible to a shape check.  A parameter that never saw a gradient has no entry.
+    shapes5 = shapes + [(70,)]
+    tq = [torch.nn.Parameter(torch.randn(s)) for s in shapes5]
+    tc = torch.optim.Adam(tq, lr=1e-3, betas=(0.5, 0.999))
+    for _ in range(3):
+        for p in tq[:4] + tq[4:]:
+            p.grad = torch.randn_like(p)
+        tq[1].grad = None                                     # this one is never stepped
+        tc.step()
+    fake_ids = [140002, 140001, 140005, 140000, 140003]       # descending / shuffled "addresses"
+    modern = tc.state_dict()
+    by_id = dict(state={fake_ids[i]: dict(e, step=3) for i, e in modern['state'].items()},
+                 param_groups=[dict(modern['param_groups'][0], params=[fake_ids[i] for i in range(5)])])
+    assert 1 not in modern['state'] and len(by_id['state']) == 4
+    fa4 = FusedAdam([torch.nn.Parameter(p.detach().clone()) for p in tq])
+    fa4.load_state_dict(by_id)
+    assert fa4.step_count == 3
+    for i, (p, o) in enumerate(zip(fa4.arena.params, fa4.arena.offsets)):
+        n = p.numel()
+        want = tc.state[tq[i]]['exp_avg'] if i != 1 else torch.zeros(p.shape)
+        assert torch.equal(fa4.exp_avg[o:o + n].view(p.shape), want), i
+    with pytest.raises(ValueError):
+        fa4.load_state_dict(dict(state={7: modern['state'][0]}, param_groups=by_id['param_groups']))
     # a fresh optimizer round-trips an empty state
     fa3 = FusedAdam([torch.nn.Parameter(p.detach().clone()) for p in tp])
     fa3.load_state_dict(FusedAdam([torch.nn.Parameter(p.detach().clone()) for p in tp]).state_dict())
