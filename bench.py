@@ -353,6 +353,9 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    timing_on = world > 1 and hasattr(model, 'start_comm_timing')
+    if timing_on:
+        model.start_comm_timing()          # event pairs around every wait for the exchange (dist.timed_wait)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -362,8 +365,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    identical = None
+    identical = exposed = None
     if world > 1:
+        if timing_on:
+            mine = model.read_comm_timing(args.steps)
+            exposed = [None] * world
+            dist.all_gather_object(exposed, mine)
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -386,6 +393,12 @@ def main():
         if world > 1:
             out['ranks'] = {'world_size': dist.get_world_size(), 'backend': 'rccl' if backend == 'nccl' else backend,
                             'replicas_identical': identical}
+            if exposed is not None:
+                # per rank, ms per step a stream sat idle for the gradient exchange (models/pix2pixHD_condImg_model.py
+                # read_comm_timing): g_update_tail and d_update_wait are on the main stream, i.e. they delay the step
+                out['exposed_comm_ms'] = {'per_rank': exposed,
+                                          'main_stream_max': round(max(e['g_update_tail'] + e['d_update_wait']
+                                                                       for e in exposed), 4)}
         if not args.no_roofline:
             if args.workload == 'box2mask':
                 out['roofline'] = direct_conv_roofline(device, bs, 256, 256, 3, 1, 1, 32, 32,

@@ -39,6 +39,20 @@ def init_process_group_from_env(backend=None):
     return rank, local, world
 
 
+def timed_wait(waiter, other, sink=None):
+    """``waiter.wait_stream(other)``; with a ``sink`` list, bracketed by two timing events on ``waiter`` whose distance
+    is the time that stream sat idle for ``other`` (nothing else lies between them): the EXPOSED part of whatever
+    ``other`` was doing (bench.py's ``exposed_comm_ms``)."""
+    if sink is None:
+        waiter.wait_stream(other)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(waiter)
+    waiter.wait_stream(other)
+    e1.record(waiter)
+    sink.append((e0, e1))
+
+
 class GradReducer(object):
     """Bucketed all-reduce(avg) of a flat gradient buffer.
 
@@ -73,6 +87,7 @@ class GradReducer(object):
         self.launched = [True] * len(self.buckets)
         self.works = []
         self.armed = False
+        self.timing = None           # list of (event, event) pairs while a caller measures the exposed exchange
 
     def attach(self, params):
         """Bind parameters (carrying ``_him_arena_range``) so the wgrad kernels' completion triggers buckets."""
@@ -143,7 +158,7 @@ class GradReducer(object):
             if not self.launched[b]:
                 self._launch(b)
         if self.on_gpu:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+            timed_wait(torch.cuda.current_stream(), self.comm_stream, self.timing)
         self.armed = False
 
 

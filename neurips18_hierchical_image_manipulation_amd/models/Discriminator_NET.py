@@ -5,14 +5,20 @@ import os
 import torch
 import torch.nn as nn
 
-from ..nn import Conv2d, InstanceNorm2d, BatchNorm2d, LeakyReLU, FusedSequential, AvgPool3s2
+from ..nn import InstanceNorm2d, BatchNorm2d, LeakyReLU, FusedSequential, AvgPool3s2
 from .layer_util import weights_init
 
 
 class MultiscaleDiscriminator(nn.Module):
     def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer='instance', use_sigmoid=False, num_D=3,
-                 getIntermFeat=True):
+                 getIntermFeat=True, spectral_norm=False):
+        """``spectral_norm`` (the build's ``--sn_D``): every convolution is an ``SNConv2d`` (models/sn_utils.py; the
+        reference wires its SN layers only into the unreachable Res_Discriminator) -- same keys plus ``...0.u``."""
         super().__init__()
+        if spectral_norm:
+            from .sn_utils import SNConv2d as Conv2d
+        else:
+            from ..nn import Conv2d
         if norm_layer not in ('instance', 'batch'):
             raise NotImplementedError('normalization layer [%s] is not found' % norm_layer)
         norm = InstanceNorm2d if norm_layer == 'instance' else BatchNorm2d   # 'batch': the box2mask discriminator

@@ -97,7 +97,7 @@ class Pix2PixHDModel_condImg(BaseModel):
                 netD_input_nc = 3
             from .Discriminator_NET import MultiscaleDiscriminator
             self.netD = MultiscaleDiscriminator(netD_input_nc, opt.ndf, opt.n_layers_D, opt.norm, opt.no_lsgan,
-                                                opt.num_D, True)   # intermediate features always returned
+                                                opt.num_D, True, spectral_norm=bool(getattr(opt, 'sn_D', False)))
             self.netD.to(self.device)
 
         if not self.isTrain or opt.continue_train or opt.load_pretrain:
@@ -135,6 +135,7 @@ class Pix2PixHDModel_condImg(BaseModel):
             self.optimizer_G = FusedAdam(params, lr=opt.lr, betas=(opt.beta1, 0.999))
             self.optimizer_D = FusedAdam(self.netD.parameters(), lr=opt.lr, betas=(opt.beta1, 0.999))
             self.reducer_G = self.reducer_D = None
+            self.comm_timing = None
             # gradient routing of the shared fake-image discriminator pass (see forward)
             self._d_weight_ids = set(id(p) for p in self.netD.parameters())
             self._d_first_weight_ids = set(id(getattr(self.netD, 'scale%d_layer0' % i)[0].weight)
@@ -259,7 +260,9 @@ class Pix2PixHDModel_condImg(BaseModel):
         # loss_G.backward() they
         # reach the generator but D's weight gradients are skipped (the reference computes and discards them,
         # train_mask2image.py:84); during loss_D.backward() they reach D's weights and stop in front of the generator.
-        share = opt.pool_size == 0 and self._share_fake_pass   # only optimize_parameters() owns both backward calls
+        # only optimize_parameters() owns both backward calls; --sn_D: every discriminator forward moves the persisted
+        # power-iteration vectors, so the reference's three passes are kept as three passes
+        share = opt.pool_size == 0 and self._share_fake_pass and not getattr(opt, 'sn_D', False)
         if share:
             self._fake_gate = {'open': True}
             pred_fake = self.netD.forward(self._d_input(netD_cond, ops.grad_switch(fake_image, self._fake_gate),
@@ -418,7 +421,8 @@ class Pix2PixHDModel_condImg(BaseModel):
             if self.reducer_D is not None:
                 self.reducer_D.begin(contributions=2)
             self._run_backward_D()
-        main.wait_stream(opt_stream)
+        from ..dist import timed_wait
+        timed_wait(main, opt_stream, self.comm_timing['g_update_tail'] if self.comm_timing else None)
         if gan:
             if self.reducer_D is not None:
                 # D's exchange (34 MB over xGMI) + Adam step go to a stream of their own and are NOT waited for here:
@@ -442,7 +446,31 @@ class Pix2PixHDModel_condImg(BaseModel):
     def _wait_d_update(self, stream=None):
         """Make ``stream`` (default: the current one) wait for a discriminator update still running on its own stream."""
         if getattr(self, '_d_update_pending', False):
-            (stream or torch.cuda.current_stream(self.device)).wait_stream(ops._d_opt_stream(self.device))
+            from ..dist import timed_wait
+            timed_wait(stream or torch.cuda.current_stream(self.device), ops._d_opt_stream(self.device),
+                       self.comm_timing['d_update_wait'] if (self.comm_timing and stream is None) else None)
+
+    def start_comm_timing(self):
+        """From now on every wait of a compute stream for the gradient exchange / a deferred optimizer step is bracketed
+        by timing events (dist.timed_wait).  ``read_comm_timing`` turns them into milliseconds per step."""
+        self.comm_timing = {'g_update_tail': [], 'd_update_wait': [], 'g_exchange_wait': [], 'd_exchange_wait': []}
+        if self.reducer_G is not None:
+            self.reducer_G.timing = self.comm_timing['g_exchange_wait']
+        if self.reducer_D is not None:
+            self.reducer_D.timing = self.comm_timing['d_exchange_wait']
+
+    def read_comm_timing(self, steps):
+        """ms per step a stream sat idle: ``g_exchange_wait`` = the optimizer stream waiting for G's all-reduce after
+        the last weight gradient; ``g_update_tail`` = the main stream, after loss_D.backward(), waiting for G's exchange +
+        Adam; ``d_exchange_wait`` = D's update stream waiting for D's all-reduce; ``d_update_wait`` = the NEXT step's
+        discriminator pass waiting for D's exchange + Adam.  Only the two main-stream figures delay the step."""
+        torch.cuda.synchronize(self.device)
+        out = {k: round(sum(a.elapsed_time(b) for a, b in v) / max(steps, 1), 4) for k, v in self.comm_timing.items()}
+        self.comm_timing = None
+        for r in (self.reducer_G, self.reducer_D):
+            if r is not None:
+                r.timing = None
+        return out
 
     def sync(self):
         """Join every helper stream into the current one (before parameters are read from outside the step)."""

@@ -150,6 +150,12 @@ class _GradSwitch(torch.autograd.Function):
         return (g if (g is not None and ctx.state['open']) else None), None
 
 
+def _wkey(w):
+    """Routing key of a weight tensor: the id of the PARAMETER it was derived from (spectral-norm layers hand the conv a
+    fresh W / sigma tensor every forward and tag it with ``_him_wkey``), else its own id."""
+    return getattr(w, '_him_wkey', id(w))
+
+
 def grad_switch(x, state):
     return _GradSwitch.apply(x, state)
 
@@ -304,7 +310,7 @@ class _Conv2d(torch.autograd.Function):
             dz = dy
         dx = dw = db = None
         gs = ctx.gslice
-        if ctx.needs_input_grad[0] and id(w) not in SKIP_DGRAD and gs is not None and gs[1] <= 4 < d.Cin:
+        if ctx.needs_input_grad[0] and _wkey(w) not in SKIP_DGRAD and gs is not None and gs[1] <= 4 < d.Cin:
             # only channels [c0, c0+n) of the input can use a gradient (first PatchGAN conv: the image channels behind
             # 35..70 channels of data): data gradient of the n-channel weight slice (tiny-M kernel), zeros elsewhere
             c0, n = gs
@@ -317,7 +323,7 @@ class _Conv2d(torch.autograd.Function):
             lib.him_conv2d_bwd_data(ctypes.byref(d2), _p(dz), _p(wsl), _p(dxs), _p(ws), nb, st)
             dx = torch.zeros_like(x)
             lib.him_copy_channels(_p(dxs), n, 0, _p(dx), d.Cin, c0, n, d.B, d.H * d.W, 0, 0, 0, st)
-        elif ctx.needs_input_grad[0] and id(w) not in SKIP_DGRAD:
+        elif ctx.needs_input_grad[0] and _wkey(w) not in SKIP_DGRAD:
             dx = torch.empty_like(x)
             nb = lib.him_conv2d_bwd_data_ws(ctypes.byref(d))
             ws = _ws(nb, x)
@@ -329,7 +335,7 @@ class _Conv2d(torch.autograd.Function):
                 lib.him_conv2d_bwd_data_panel(ctypes.byref(d), _p(dz), pan, _p(dx), _p(ws), nb, st)
             else:
                 lib.him_conv2d_bwd_data(ctypes.byref(d), _p(dz), _p(w), _p(dx), _p(ws), nb, st)
-        skip_w = id(w) in SKIP_WGRAD
+        skip_w = _wkey(w) in SKIP_WGRAD
         need_w = ctx.needs_input_grad[1] and not skip_w
         need_b = b is not None and ctx.needs_input_grad[2] and not skip_w
         if need_w or need_b:
@@ -383,7 +389,7 @@ class _OneHotConv2d(torch.autograd.Function):
         else:
             dz = dy
         dw = db = None
-        skip_w = id(w) in SKIP_WGRAD
+        skip_w = _wkey(w) in SKIP_WGRAD
         need_w = ctx.needs_input_grad[3] and not skip_w
         need_b = b is not None and ctx.needs_input_grad[4] and not skip_w
         if need_w or need_b:

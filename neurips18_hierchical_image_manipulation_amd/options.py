@@ -37,7 +37,8 @@ TRAIN_FLAGS = [
 ]
 # additions of this build (absent in the reference)
 BUILD_FLAGS = [('vgg_weights', str, ''), ('verbose', 'flag', False), ('color_noise', 'flag', False),
-               ('compact_labels', 'flag', False)]   # loader: label ids as uint8 (the trainers widen them on the device)
+               ('compact_labels', 'flag', False),
+               ('sn_D', 'flag', False)]             # spectral-norm convolutions in the multi-scale PatchGAN (sn_utils.py)   # loader: label ids as uint8 (the trainers widen them on the device)
 
 
 class MaskToImageOptions(object):

@@ -183,19 +183,20 @@ class GlobalTwoStreamGenerator(nn.Module):
 class MultiscaleDiscriminator(nn.Module):
     """models/Discriminator_NET.py:11-118 with getIntermFeat=True (keys ``scale<i>_layer<j>.0.*``)."""
 
-    def __init__(self, input_nc, ndf=64, n_layers=3, num_D=3, norm='instance'):
+    def __init__(self, input_nc, ndf=64, n_layers=3, num_D=3, norm='instance', spectral_norm=False):
         super().__init__()
         self.num_D, self.n_layers = num_D, n_layers
         _in_layer = globals()['_in_layer'] if norm == 'instance' else nn.BatchNorm2d   # 'batch': box2mask D
+        conv = globals()['SNConv2d'] if spectral_norm else nn.Conv2d   # the build's --sn_D wrap (not a reference flag)
         for i in range(num_D):
-            blocks = [[nn.Conv2d(input_nc, ndf, 4, 2, 2), nn.LeakyReLU(0.2, False)]]
+            blocks = [[conv(input_nc, ndf, 4, 2, 2), nn.LeakyReLU(0.2, False)]]
             nf = ndf
             for _ in range(1, n_layers):
                 nf_prev, nf = nf, min(nf * 2, 512)
-                blocks.append([nn.Conv2d(nf_prev, nf, 4, 2, 2), _in_layer(nf), nn.LeakyReLU(0.2, False)])
+                blocks.append([conv(nf_prev, nf, 4, 2, 2), _in_layer(nf), nn.LeakyReLU(0.2, False)])
             nf_prev, nf = nf, min(nf * 2, 512)
-            blocks.append([nn.Conv2d(nf_prev, nf, 4, 1, 2), _in_layer(nf), nn.LeakyReLU(0.2, False)])
-            blocks.append([nn.Conv2d(nf, 1, 4, 1, 2)])
+            blocks.append([conv(nf_prev, nf, 4, 1, 2), _in_layer(nf), nn.LeakyReLU(0.2, False)])
+            blocks.append([conv(nf, 1, 4, 1, 2)])
             for j, b in enumerate(blocks):
                 setattr(self, 'scale%d_layer%d' % (i, j), nn.Sequential(*b))
         self.downsample = nn.AvgPool2d(3, stride=2, padding=1, count_include_pad=False)
@@ -282,6 +283,45 @@ def max_singular_value(W, u, Ip=1):
     return sigma, _u
 
 
+class SNLinear(nn.Linear):
+    """models/sn_utils.py:28-47: y = x (W / sigma(W))^T + b; ``u`` moves on every training-mode forward.  (The reference
+    re-registers u as a non-grad Parameter; a buffer under the same key here.)"""
+    Ip = 1
+
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__(in_features, out_features, bias)
+        self.register_buffer('u', torch.randn(1, out_features))
+
+    @property
+    def W_bar(self):
+        sigma, _u = max_singular_value(self.weight, self.u, self.Ip)
+        if self.training:
+            self.u = _u.detach()
+        return self.weight / sigma
+
+    def forward(self, x):
+        return F.linear(x, self.W_bar, self.bias)
+
+
+class SNConv2d(nn.Conv2d):
+    """models/sn_utils.py:49-72."""
+    Ip = 1
+
+    def __init__(self, cin, cout, k, stride=1, padding=0, bias=True):
+        super().__init__(cin, cout, k, stride, padding, bias=bias)
+        self.register_buffer('u', torch.randn(1, cout))
+
+    @property
+    def W_bar(self):
+        sigma, _u = max_singular_value(self.weight, self.u, self.Ip)
+        if self.training:
+            self.u = _u.detach()
+        return self.weight / sigma
+
+    def forward(self, x):
+        return F.conv2d(x, self.W_bar, self.bias, self.stride, self.padding)
+
+
 # ----------------------------------------------------------------------------------------------
 # the model (models/pix2pixHD_condImg_model.py, models/pix2pixHD_condImgColor_model.py)
 # ----------------------------------------------------------------------------------------------
@@ -316,7 +356,7 @@ class Opt(dict):
         feat_fusion='early_add', num_D=2, n_layers_D=3, ndf=64, lambda_feat=10.0, lambda_rec=0.0,
         no_ganFeat_loss=False, no_vgg_loss=False, no_lsgan=False, pool_size=0, no_imgCond=False,
         mask_gan_input=False, use_soft_mask=False, lr=2e-4, beta1=0.5, niter=100, niter_decay=100,
-        isTrain=True, batchSize=1)
+        isTrain=True, batchSize=1, sn_D=False)
 
     def __init__(self, **kw):
         super().__init__(self.DEFAULTS)
@@ -352,7 +392,7 @@ class Mask2ImageModel(nn.Module):
         if opt.netG == 'global_twostream' and opt.which_encoder == 'ctx':
             d_in = 3
         self.d_in = d_in
-        self.netD = MultiscaleDiscriminator(d_in, opt.ndf, opt.n_layers_D, opt.num_D)
+        self.netD = MultiscaleDiscriminator(d_in, opt.ndf, opt.n_layers_D, opt.num_D, spectral_norm=opt.sn_D)
         self.vgg = None if opt.no_vgg_loss else Vgg19()
         self.optimizer_G = torch.optim.Adam(self.netG.parameters(), lr=opt.lr, betas=(opt.beta1, 0.999))
         self.optimizer_D = torch.optim.Adam(self.netD.parameters(), lr=opt.lr, betas=(opt.beta1, 0.999))

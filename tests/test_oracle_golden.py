@@ -125,3 +125,26 @@ def test_lr_control_rule_restatement():
     assert ref_mask_cpu.lr_control(0.1, 0.5) == (1.0, 0.0)      # D pauses: one of its losses is under the margin
     assert ref_mask_cpu.lr_control(0.9, 0.5) == (0.0, 1.0)      # G pauses: D is losing
     assert ref_mask_cpu.lr_control(0.1, 0.9) == (1.0, 1.0)      # both would pause -> both train
+
+
+@pytest.mark.parametrize('tag', ['lin', 'conv'])
+def test_oracle_sn_layers_match_reference_golden(tag):
+    """SNLinear / SNConv2d restatements against the REAL reference classes (models/sn_utils.py:28-72; sn_layers.npz):
+    training-mode output, the persisted u, and the gradients through both normalisations."""
+    g = load_golden('sn_layers')
+    layer = ref_cpu.SNLinear(24, 10) if tag == 'lin' else ref_cpu.SNConv2d(6, 10, 3, 1, 1)
+    with torch.no_grad():
+        layer.weight.copy_(torch.from_numpy(g[tag + '_W']))
+        layer.bias.copy_(torch.from_numpy(g[tag + '_b']))
+    layer.u = torch.from_numpy(g[tag + '_u0']).clone()
+    layer.train()
+    x = torch.from_numpy(g[tag + '_x']).requires_grad_(True)
+    y = layer(x)
+    gW, gb, gx = torch.autograd.grad((y * torch.from_numpy(g[tag + '_gy'])).sum(), [layer.weight, layer.bias, x])
+    for got, key in ((y, 'y'), (layer.u, 'u'), (gW, 'gW'), (gb, 'gb'), (gx, 'gx')):
+        ref = torch.from_numpy(g['%s_%s' % (tag, key)])
+        assert float((got.detach() - ref).abs().max()) <= 2e-6 * max(float(ref.abs().max()), 1.0), key
+    layer.eval()
+    u = layer.u.clone()
+    layer(x)
+    assert torch.equal(layer.u, u)

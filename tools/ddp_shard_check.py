@@ -1,0 +1,216 @@
+#!/usr/bin/env python
+"""Sharded == unsharded ("per-rank batches must be the same images as the single-process oracle run").
+
+Run under torch.distributed.run with W ranks (gloo ranks may share one GPU: HIM_DDP_BACKEND=gloo).  Every rank trains
+on ITS shard ``synth.make_batch(step, rank, B/W)``; rank 0 also runs, on the CONCATENATED batch of all shards,
+  (1) the same HIP trainer un-attached (one rank, no reducer) and
+  (2) the CPU oracle (oracle/ref_cpu.py / oracle/ref_mask_cpu.py),
+and the three must agree per step in
+  * the losses (mean over ranks of the per-rank batch means == the whole-batch mean: equal shard sizes),
+  * the AVERAGED gradients that the exchange leaves in every rank's gradient arena (per tensor, relative L2),
+  * the parameters after the Adam step (update delta per network, relative L2).
+Covered: mask2image (InstanceNorm G + D, VGG loss) and the box2mask ADE recipe (InstanceNorm G + D).  NOT equal by
+construction, as in the reference's nn.DataParallel: the box2mask CITY recipe (BatchNorm statistics are per replica) and
+``--lr_control`` (its gate reads per-replica loss values) -- those keep per-rank behaviour, replicas stay identical
+(tools/ddp_selfcheck.py) but differ from a single-process run on the whole batch.
+
+Teacher forcing between steps: after each step every HIP model adopts the oracle's parameters and Adam moments, so
+each step is compared on its own (free-running GAN steps amplify rounding, tests/golden/chaos_envelope.json)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import torch
+import torch.distributed as dist
+from neurips18_hierchical_image_manipulation_amd import synth, ops
+from neurips18_hierchical_image_manipulation_amd.dist import init_process_group_from_env, attach_data_parallel
+from neurips18_hierchical_image_manipulation_amd.models import create_model
+
+rank, local, world = init_process_group_from_env()
+assert world >= 2, 'run with >= 2 ranks'
+torch.cuda.set_device(local)
+dev = torch.device('cuda', local)
+ops.set_winograd_min_channels(64)        # the toy nets' 128-channel ResnetBlocks take the Winograd kernels
+STEPS, PER = 2, 2
+GRAD_TOL, DELTA_TOL, LOSS_TOL = 2e-4, 5e-2, 2e-5
+
+
+def cat_batches(bs):
+    return type(bs[0])((k, torch.cat([b[k] for b in bs], 0)) for k in bs[0])
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def dead_bias_names(net):
+    names = set()
+    for mname, mod in net.named_modules():
+        kids = list(mod.named_children())
+        for (n0, c0), (_, c1) in zip(kids[:-1], kids[1:]):
+            if c0.__class__.__name__ in ('Conv2d', 'ConvTranspose2d', 'SNConv2d') and c1.__class__.__name__ == 'InstanceNorm2d':
+                names.add((mname + '.' if mname else '') + n0 + '.bias')
+    return names
+
+
+def adopt(hopts, oopts, hnets, onets):
+    for hn, on in zip(hnets, onets):
+        hn.load_state_dict(on.state_dict())
+    for ho, oo, on in zip(hopts, oopts, onets):
+        if oo.state:
+            st = [oo.state[p] for p in on.parameters()]
+            ho.load_moments([s['exp_avg'] for s in st], [s['exp_avg_sq'] for s in st], int(st[0]['step']))
+
+
+def gather_losses(vals):
+    t = torch.tensor(vals, dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return (t / world).tolist()
+
+
+def broadcast_state(nets, opts):
+    """rank 0's (oracle-adopted) parameters and moments -> every rank."""
+    from neurips18_hierchical_image_manipulation_amd.ops import invalidate_panels
+    for o in opts:
+        for flat in (o.arena.data, o.exp_avg, o.exp_avg_sq):
+            dist.broadcast(flat, src=0)
+        step = torch.tensor([o.step_count], dtype=torch.int64, device=dev)
+        dist.broadcast(step, src=0)
+        o.step_count = int(step.item())
+        invalidate_panels(o.arena.params)
+
+
+def compare(tag, sharded, single, oracle_nets, oracle_opts, before, losses_sh, losses_single, losses_or, nets_of, opts_of):
+    """rank 0: sharded run vs the single-rank HIP run and vs the oracle."""
+    worst = dict(loss_vs_single=0.0, loss_vs_oracle=0.0, grad_vs_single=0.0, grad_vs_oracle=0.0, delta_vs_single=0.0,
+                 delta_vs_oracle=0.0)
+    for a, b, c in zip(losses_sh, losses_single, losses_or):
+        worst['loss_vs_single'] = max(worst['loss_vs_single'], abs(a - b) / max(abs(b), 1e-12))
+        worst['loss_vs_oracle'] = max(worst['loss_vs_oracle'], abs(a - c) / max(abs(c), 1e-12))
+    for hs, h1, on, oo, key in zip(nets_of(sharded), nets_of(single), oracle_nets, oracle_opts, ('G', 'D')):
+        dead = dead_bias_names(hs)
+        num = {'single': 0.0, 'oracle': 0.0}
+        den = {'single': 0.0, 'oracle': 0.0}
+        for (name, ps), p1, po in zip(hs.named_parameters(), h1.parameters(), on.parameters()):
+            if name in dead or po.grad is None:
+                continue
+            worst['grad_vs_single'] = max(worst['grad_vs_single'], rel_l2(ps.grad, p1.grad))
+            worst['grad_vs_oracle'] = max(worst['grad_vs_oracle'], rel_l2(ps.grad, po.grad))
+            b0 = before[key][name].double()
+            d_s, d_1, d_o = ps.detach().double().cpu() - b0, p1.detach().double().cpu() - b0, po.detach().double() - b0
+            num['single'] += float((d_s - d_1).pow(2).sum())
+            den['single'] += float(d_1.pow(2).sum())
+            num['oracle'] += float((d_s - d_o).pow(2).sum())
+            den['oracle'] += float(d_o.pow(2).sum())
+        for k in ('single', 'oracle'):
+            worst['delta_vs_' + k] = max(worst['delta_vs_' + k], (num[k] / max(den[k], 1e-300)) ** 0.5)
+    print('%s: %s' % (tag, ' '.join('%s=%.2e' % kv for kv in worst.items())), flush=True)
+    assert worst['loss_vs_single'] < LOSS_TOL and worst['loss_vs_oracle'] < LOSS_TOL, (tag, worst)
+    assert worst['grad_vs_single'] < GRAD_TOL and worst['grad_vs_oracle'] < GRAD_TOL, (tag, worst)
+    assert worst['delta_vs_single'] < DELTA_TOL and worst['delta_vs_oracle'] < DELTA_TOL, (tag, worst)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# mask2image
+# ------------------------------------------------------------------------------------------------------------------
+M2I = dict(model='pix2pixHD_condImg', netG='global', ngf=16, ndf=16, n_downsample_global=3, n_blocks_global=2, num_D=2,
+           n_layers_D=3, label_nc=35, no_instance=True)
+NAMES = ['G_GAN', 'G_GAN_Feat', 'G_VGG', 'D_real', 'D_fake']
+
+
+def build_m2i():
+    m = create_model(dict(M2I, gpu_ids=[local], isTrain=True, checkpoints_dir='/tmp/him_shard', name='m'))
+    m.netG.load_state_dict(synth.init_state_dict(m.netG.state_dict(), 1))
+    m.netD.load_state_dict(synth.init_state_dict(m.netD.state_dict(), 2))
+    return m
+
+
+sharded = build_m2i()
+attach_data_parallel(sharded, bucket_bytes=1 << 16)
+assert sharded.reducer_G is not None and len(sharded.reducer_G.buckets) > 3
+nets_m2i = lambda m: (m.netG, m.netD)
+opts_m2i = lambda m: (m.optimizer_G, m.optimizer_D)
+if rank == 0:
+    from oracle import ref_cpu
+    single = build_m2i()
+    ora = ref_cpu.Mask2ImageModel(ref_cpu.Opt(**M2I))
+    ora.netG.load_state_dict(synth.init_state_dict(ora.netG.state_dict(), 1))
+    ora.netD.load_state_dict(synth.init_state_dict(ora.netD.state_dict(), 2))
+    ora.vgg.load_state_dict(synth.init_state_dict(ora.vgg.state_dict(), 3, 'vgg'))
+for s in range(STEPS):
+    if rank == 0:
+        adopt(opts_m2i(sharded), (ora.optimizer_G, ora.optimizer_D), nets_m2i(sharded), (ora.netG, ora.netD))
+        adopt(opts_m2i(single), (ora.optimizer_G, ora.optimizer_D), nets_m2i(single), (ora.netG, ora.netD))
+        before = {'G': {k: v.detach().clone() for k, v in ora.netG.named_parameters()},
+                  'D': {k: v.detach().clone() for k, v in ora.netD.named_parameters()}}
+    broadcast_state(nets_m2i(sharded), opts_m2i(sharded))
+    mine = synth.make_batch(s, rank, PER, 64, 64)
+    ld = sharded.optimize_parameters(mine)
+    sharded.sync()
+    torch.cuda.synchronize()
+    losses_sh = gather_losses([float(ld[k]) for k in NAMES])
+    if rank == 0:
+        whole = cat_batches([synth.make_batch(s, r, PER, 64, 64) for r in range(world)])
+        l1 = single.optimize_parameters(whole)
+        single.sync()
+        lo = ora.optimize_parameters(whole)
+        compare('mask2image step %d' % s, sharded, single, (ora.netG, ora.netD), (ora.optimizer_G, ora.optimizer_D), before,
+                losses_sh, [float(l1[k]) for k in NAMES], [lo[k] for k in NAMES], nets_m2i, opts_m2i)
+    dist.barrier()
+
+# ------------------------------------------------------------------------------------------------------------------
+# box2mask, ADE recipe (InstanceNorm generator and discriminator, dilated blocks), lr_control off (per-replica gate)
+# ------------------------------------------------------------------------------------------------------------------
+ADE = dict(label_nc=49, output_nc=49, norm_layer='instance', add_dilated_layers=True, ndf=16, num_layers_D=3, gan_weight=0.1,
+           lr=2e-4, beta1=0.5, beta2=0.999, lr_control=False)
+B2M_NAMES = ['G_Recon_comb', 'G_Recon_obj', 'KL_loss', 'loss_G_GAN', 'loss_D_GAN', 'loss_G_GAN_Feat']
+
+
+def build_b2m():
+    m = create_model(dict(ADE, model='AE_maskgen_twostream', gpu_ids=[local], isTrain=True, checkpoints_dir='/tmp/him_shard',
+                          name='b'))
+    m.netG.load_state_dict(synth.init_state_dict(m.netG.state_dict(), 31))
+    m.netD.load_state_dict(synth.init_state_dict(m.netD.state_dict(), 32))
+    return m
+
+
+def b2m_step(m, bt):
+    out, _ = m.forward(bt['label'], None, bt['mask_ctx_in'], None, bt['mask_out'], bt['mask_obj_inst'], bt['cls'], bt['mask_in'],
+                       eval_mode=False)
+    return [float(x.detach().reshape(-1)[0]) if torch.is_tensor(x) else float(x) for x in out]
+
+
+sharded = build_b2m()
+attach_data_parallel(sharded, bucket_bytes=1 << 16)
+nets_b2m = lambda m: (m.netG, m.netD)
+opts_b2m = lambda m: (m.optimizer, m.optimizer_D)
+if rank == 0:
+    from oracle import ref_mask_cpu
+    single = build_b2m()
+    ora = ref_mask_cpu.TwoStreamAEMask(**{k: v for k, v in ADE.items() if k != 'output_nc'})
+    ora.netG.load_state_dict(synth.init_state_dict(ora.netG.state_dict(), 31))
+    ora.netD.load_state_dict(synth.init_state_dict(ora.netD.state_dict(), 32))
+for s in range(STEPS):
+    if rank == 0:
+        adopt(opts_b2m(sharded), (ora.optimizer, ora.optimizer_D), nets_b2m(sharded), (ora.netG, ora.netD))
+        adopt(opts_b2m(single), (ora.optimizer, ora.optimizer_D), nets_b2m(single), (ora.netG, ora.netD))
+        before = {'G': {k: v.detach().clone() for k, v in ora.netG.named_parameters()},
+                  'D': {k: v.detach().clone() for k, v in ora.netD.named_parameters()}}
+    broadcast_state(nets_b2m(sharded), opts_b2m(sharded))
+    got = b2m_step(sharded, synth.make_box2mask_batch(s, rank, PER, 64, 64, 49))
+    if hasattr(sharded, 'sync'):
+        sharded.sync()
+    torch.cuda.synchronize()
+    losses_sh = gather_losses(got)
+    if rank == 0:
+        whole = cat_batches([synth.make_box2mask_batch(s, r, PER, 64, 64, 49) for r in range(world)])
+        l1 = b2m_step(single, whole)
+        torch.cuda.synchronize()
+        lo = ora.step(whole)
+        compare('box2mask-ADE step %d' % s, sharded, single, (ora.netG, ora.netD), (ora.optimizer, ora.optimizer_D), before,
+                losses_sh, l1, [lo[k] for k in B2M_NAMES], nets_b2m, opts_b2m)
+    dist.barrier()
+if rank == 0:
+    print('DDP SHARD CHECK OK world=%d' % world)
+dist.destroy_process_group()
