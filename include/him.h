@@ -284,10 +284,11 @@ int him_mse_const_bwd(const float* x, size_t n, float target, const float* g, fl
 /* ---------------------------------------------------------------------------------------------
  * torch.optim.Adam (betas=(beta1,0.999), eps 1e-8, no weight decay) over a flat parameter arena:
  * pix2pixHD_condImg_model.py:135-139 + the .step() calls of train_mask2image.py:80,86.
- * `step` is the 1-based step count (bias correction is computed on the host in double, as torch does).
+ * `step` is the 1-based step count.  lr / betas / eps are DOUBLES: 1 - beta2, the bias corrections and lr / bc1 are
+ * derived in double and rounded to fp32 once, as torch.optim.Adam does with its python-float hyper-parameters.
  * ------------------------------------------------------------------------------------------- */
-int him_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
-                  float beta2, float eps, int step, void* stream);
+int him_adam_step(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1,
+                  double beta2, double eps, int step, void* stream);
 int him_fill(float* p, size_t n, float value, void* stream);
 int him_scale(float* p, size_t n, float s, void* stream);
 

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libhim_hip.so')
 
 c_float_p = C.c_void_p  # raw device pointers travel as integers
-c_int, c_size_t, c_float, c_void_p = C.c_int, C.c_size_t, C.c_float, C.c_void_p
+c_int, c_size_t, c_float, c_void_p, c_double = C.c_int, C.c_size_t, C.c_float, C.c_void_p, C.c_double
 
 
 class HimConv2d(C.Structure):
@@ -105,7 +105,7 @@ _SIGS = {
     'him_l1_mean_bwd': (c_int, [P, P, c_size_t, P, P, c_int, P]),
     'him_mse_const_fwd': (c_int, [P, c_size_t, c_float, P, P, c_size_t, P]),
     'him_mse_const_bwd': (c_int, [P, c_size_t, c_float, P, P, c_int, P]),
-    'him_adam_step': (c_int, [P, P, P, P, c_size_t, c_float, c_float, c_float, c_float, c_int, P]),
+    'him_adam_step': (c_int, [P, P, P, P, c_size_t, c_double, c_double, c_double, c_double, c_int, P]),
     'him_fill': (c_int, [P, c_size_t, c_float, P]),
     'him_scale': (c_int, [P, c_size_t, c_float, P]),
     'him_sn_ws': (c_size_t, [c_int, c_int]),

@@ -1834,29 +1834,41 @@ static int bias_slices(int B, int hw) {
   if (per > hw) per = hw;
   return per < 1 ? 1 : (int)per;
 }
+// Bias gradients are sums of ~1e6 signed values that largely cancel (the head's: |sum| ~ 1e-2 of sum |dy|): fp32 partial
+// sums left 1.6e-4 relative error against 2e-5 of torch's pairwise CPU sum (fp64-anchored step test).  The pass is
+// HBM-bound and MI355X adds doubles at full vector rate, so every partial sum is carried in double.
 __global__ __launch_bounds__(256) void bias_grad1_kernel(const float* __restrict__ dy, float* __restrict__ part,
                                                          int B, int C, int hw) {
-  __shared__ float sh[8];
+  __shared__ double shd[4];
   const int c = blockIdx.x, sl = blockIdx.y;
   const int chunk = (hw + gridDim.y - 1) / gridDim.y;
   const int beg = sl * chunk, end = min(hw, beg + chunk);
-  float s = 0.f;
+  double s = 0.0;
   for (int b = 0; b < B; ++b) {
     const float* pl = dy + ((size_t)b * C + c) * hw;
-    for (int i = beg + threadIdx.x; i < end; i += 256) s += pl[i];
+    for (int i = beg + threadIdx.x; i < end; i += 256) s += (double)pl[i];
   }
-  s = block_sum_256(s, sh);
-  if (threadIdx.x == 0) part[c * BIAS_SLICES + sl] = s;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = s;
+  __syncthreads();
+  // the slice sums travel as (hi, lo) float pairs: 48 significant bits through the fp32 workspace
+  if (threadIdx.x == 0) {
+    const double t = (shd[0] + shd[1]) + (shd[2] + shd[3]);
+    const float hi = (float)t;
+    part[(c * BIAS_SLICES + sl) * 2] = hi;
+    part[(c * BIAS_SLICES + sl) * 2 + 1] = (float)(t - (double)hi);
+  }
 }
 __global__ void bias_grad2_kernel(const float* __restrict__ part, float* __restrict__ db, int C, int nsl,
                                   int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  float s = 0.f;
-  for (int i = 0; i < nsl; ++i) s += part[c * BIAS_SLICES + i];
-  db[c] = accumulate ? db[c] + s : s;
+  double s = 0.0;
+  for (int i = 0; i < nsl; ++i) s += (double)part[(c * BIAS_SLICES + i) * 2] + (double)part[(c * BIAS_SLICES + i) * 2 + 1];
+  db[c] = accumulate ? db[c] + (float)s : (float)s;
 }
-static size_t bias_ws_bytes(int C) { return (size_t)C * BIAS_SLICES * sizeof(float) + 256; }
+static size_t bias_ws_bytes(int C) { return (size_t)C * BIAS_SLICES * 2 * sizeof(float) + 256; }
 
 static int wgrad_splits(int M, int Np, int Kdim, int BM, int BN) {
   const long long tiles = (long long)cdiv(M, BM) * cdiv(Np, BN);
@@ -2002,6 +2014,8 @@ __global__ __launch_bounds__(256) void wgrad_small_win_kernel(const WGradP p, in
       }
 }
 
+#include "him_wgrad_fewch.inc"
+
 static const int SMALL_WIN_SLOTS = 256;
 static bool small_win_ok(int M, int KH, int KW, int stride, int pad, int H, int W, int OH, int OW) {
   static int off = -1;
@@ -2021,7 +2035,17 @@ static size_t wgrad_slab_bytes(int M, int C, int KH, int KW, int Kdim, size_t wi
   const int Np = C * KH * KW;
   size_t slabs;
   if (wino_floats) return ((wino_floats * sizeof(float) + 255) / 256) * 256;
-  if (small_wgrad_ok(M, KH, KW) || (M <= 4 && KH == KW && KH == 5)) {
+  const bool fewch_shape = !fewch_off() && KH == KW && (KH == 5 || KH == 7) &&
+                           ((M <= 4 && C >= 32 && (C % 32) == 0) || (C <= 4 && M >= 32 && (M % 32) == 0));
+  if (fewch_shape) {   // upper bound: the runner re-checks stride / padding / plane (else the kernels below, which need less)
+    slabs = fewch_ws_floats(M <= 4 ? C : M, KH) * sizeof(float);
+    if (small_wgrad_ok(M, KH, KW) || (M <= 4 && KH == 5))
+      slabs = std::max(slabs, (size_t)std::max(small_wgrad_slices(C, Kdim), SMALL_WIN_SLOTS) * M * Np * sizeof(float));
+    int BM2, BN2;
+    wgrad_tile(M, &BM2, &BN2);
+    const int s2 = wgrad_splits(M, Np, Kdim, BM2, BN2);
+    if (s2 > 1) slabs = std::max(slabs, (size_t)s2 * M * Np * sizeof(float));
+  } else if (small_wgrad_ok(M, KH, KW) || (M <= 4 && KH == KW && KH == 5)) {
     slabs = (size_t)std::max(small_wgrad_slices(C, Kdim), SMALL_WIN_SLOTS) * M * Np * sizeof(float);
   } else if (wgrad_fast_ok(M, C, 1, 4)) {  /* upper bound; the runner re-checks OH*OW */
     int BM, BN, sp;
@@ -2095,6 +2119,10 @@ static int run_wgrad(const float* dy, const float* x, float* dw, int M, int C, i
                        accumulate);
     return check_launch("wino_wgrad_out");
   }
+  if (fewch_head_ok(M, C, KH, KW, stride, pad, H, W, OH, OW))
+    return run_wgrad_fewch(true, dy, x, dw, M, C, B, H, W, KH, pad, pad_mode, accumulate, ws, ws_bytes, st);
+  if (fewch_stem_ok(M, C, KH, KW, stride, pad, H, W, OH, OW))
+    return run_wgrad_fewch(false, dy, x, dw, M, C, B, H, W, KH, pad, pad_mode, accumulate, ws, ws_bytes, st);
   if (small_win_ok(M, KH, KW, stride, pad, H, W, OH, OW)) {
     const int nsx = cdiv(W, 64), rows_per = 64, nyc = cdiv(H, rows_per), ntasks = B * nsx * nyc;
     const int slots = std::min(ntasks, SMALL_WIN_SLOTS);

@@ -3,14 +3,31 @@
 // registers: one read) or per 256-thread workgroup (large planes, float4 streams).  Per-plane sums use
 // wave64 butterfly shuffles (+ a 4-entry LDS exchange across the waves of a workgroup); the variance is
 // the centred second pass (matches torch's biased variance without E[x^2]-mean^2 cancellation).
+#include <stdlib.h>
+
 #include "him_common.h"
 
 namespace him {
+
+// block-wide sum for 1024-thread blocks (16 waves); `sh` holds >= 16 floats
+__device__ __forceinline__ float block_sum_1024(float v, float* sh) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += sh[i];
+  return s;
+}
 
 template <int G>
 __device__ __forceinline__ float group_sum(float v, float* sh) {
   if constexpr (G == 64) {
     return wave_sum(v);
+  } else if constexpr (G == 1024) {
+    return block_sum_1024(v, sh);
   } else {
     return block_sum_256(v, sh);
   }
@@ -28,13 +45,15 @@ __device__ __forceinline__ float act_grad_from_xhat(float xh, int act, float slo
 }
 
 // G = threads cooperating on one plane (64 or 256); CACHE = elements per thread kept in registers (0: stream)
+// G = 1024: the full-resolution planes (131072 elements at 512x256): one 256-thread workgroup per plane left a CU with
+// 8 waves of float4 streams -- too little memory parallelism (3.8 TB/s); 16 waves per plane, two planes per CU
 template <int G, int CACHE>
-__global__ __launch_bounds__(256) void instnorm_fwd_kernel(const float* __restrict__ x,
+__global__ __launch_bounds__(G > 256 ? G : 256) void instnorm_fwd_kernel(const float* __restrict__ x,
                                                            const float* __restrict__ res, float* __restrict__ y,
                                                            float* __restrict__ mean, float* __restrict__ rstd,
                                                            int planes, int hw, float eps, int act, float slope) {
-  __shared__ float sh[8];
-  constexpr int PPB = 256 / G;
+  __shared__ float sh[16];
+  constexpr int PPB = G >= 256 ? 1 : 256 / G;
   const int plane = blockIdx.x * PPB + (G == 64 ? (threadIdx.x >> 6) : 0);
   if (G == 64 && plane >= planes) return;  // whole wave exits together
   const int tid = G == 64 ? (threadIdx.x & 63) : threadIdx.x;
@@ -136,13 +155,13 @@ __global__ __launch_bounds__(256) void instnorm_fwd_kernel(const float* __restri
 }
 
 template <int G, int CACHE>
-__global__ __launch_bounds__(256) void instnorm_bwd_kernel(const float* __restrict__ x,
+__global__ __launch_bounds__(G > 256 ? G : 256) void instnorm_bwd_kernel(const float* __restrict__ x,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ rstd,
                                                            const float* __restrict__ dy, float* __restrict__ dx,
                                                            int planes, int hw, int act, float slope) {
-  __shared__ float sh[8];
-  constexpr int PPB = 256 / G;
+  __shared__ float sh[16];
+  constexpr int PPB = G >= 256 ? 1 : 256 / G;
   const int plane = blockIdx.x * PPB + (G == 64 ? (threadIdx.x >> 6) : 0);
   if (G == 64 && plane >= planes) return;
   const int tid = G == 64 ? (threadIdx.x & 63) : threadIdx.x;
@@ -227,6 +246,12 @@ __global__ __launch_bounds__(256) void instnorm_bwd_kernel(const float* __restri
 
 using namespace him;
 
+static bool big_plane_256() {   // A/B switch: HIM_IN_BIG_256=1 keeps the 256-thread kernel on the full-resolution planes
+  static int v = -1;
+  if (v < 0) v = getenv("HIM_IN_BIG_256") ? 1 : 0;
+  return v != 0;
+}
+
 extern "C" {
 
 int him_instnorm_fwd(const float* x, const float* residual, float* y, float* mean, float* rstd, int planes,
@@ -239,8 +264,11 @@ int him_instnorm_fwd(const float* x, const float* residual, float* y, float* mea
   } else if (hw <= 4096) {
     hipLaunchKernelGGL((instnorm_fwd_kernel<256, 16>), dim3(planes), dim3(256), 0, st, x, residual, y, mean,
                        rstd, planes, hw, eps, act, slope);
-  } else {
+  } else if (hw < 32768 || big_plane_256()) {
     hipLaunchKernelGGL((instnorm_fwd_kernel<256, 0>), dim3(planes), dim3(256), 0, st, x, residual, y, mean, rstd,
+                       planes, hw, eps, act, slope);
+  } else {
+    hipLaunchKernelGGL((instnorm_fwd_kernel<1024, 0>), dim3(planes), dim3(1024), 0, st, x, residual, y, mean, rstd,
                        planes, hw, eps, act, slope);
   }
   return check_launch("instnorm_fwd");
@@ -256,8 +284,11 @@ int him_instnorm_bwd(const float* x, const float* mean, const float* rstd, const
   } else if (hw <= 4096) {
     hipLaunchKernelGGL((instnorm_bwd_kernel<256, 16>), dim3(planes), dim3(256), 0, st, x, mean, rstd, dy, dx,
                        planes, hw, act, slope);
-  } else {
+  } else if (hw < 32768 || big_plane_256()) {
     hipLaunchKernelGGL((instnorm_bwd_kernel<256, 0>), dim3(planes), dim3(256), 0, st, x, mean, rstd, dy, dx,
+                       planes, hw, act, slope);
+  } else {
+    hipLaunchKernelGGL((instnorm_bwd_kernel<1024, 0>), dim3(planes), dim3(1024), 0, st, x, mean, rstd, dy, dx,
                        planes, hw, act, slope);
   }
   return check_launch("instnorm_bwd");

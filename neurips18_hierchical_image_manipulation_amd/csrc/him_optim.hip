@@ -154,21 +154,24 @@ using namespace him;
 
 extern "C" {
 
-const char* him_version(void) { return "him-hip 0.2 (round 2)"; }
+const char* him_version(void) { return "him-hip 0.3 (round 3)"; }
 const char* him_arch(void) { return "gfx950"; }
 const char* him_last_error(void) { return err_buf(); }
 
-int him_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
-                  float eps, int step, void* stream) {
+int him_adam_step(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1, double beta2,
+                  double eps, int step, void* stream) {
   if (!n) return HIM_OK;
   if (step < 1) return fail(HIM_E_INVALID, "adam: step must be >= 1");
-  const double bc1 = 1.0 - pow((double)beta1, step);
-  const double bc2 = 1.0 - pow((double)beta2, step);
-  const float step_size = (float)((double)lr / bc1);
+  // Hyper-parameters arrive as the DOUBLES the caller holds (python floats), exactly as torch.optim.Adam sees them:
+  // torch derives 1 - beta2, the bias corrections and lr / bc1 in double and only then rounds each scalar to fp32
+  // (round 2 took floats: 1.f - 0.999f = 1.0000467e-3 instead of 1e-3, a 4.7e-5 relative bias of exp_avg_sq).
+  const double bc1 = 1.0 - pow(beta1, step);
+  const double bc2 = 1.0 - pow(beta2, step);
+  const float step_size = (float)(lr / bc1);
   const float bc2_sqrt = (float)sqrt(bc2);
   const int nb = (int)std::min<size_t>((n + 255) / 256, 256 * 16);
-  hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(256), 0, ST, p, g, m, v, n, 1.f - beta1, beta2, 1.f - beta2,
-                     bc2_sqrt, eps, step_size);
+  hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(256), 0, ST, p, g, m, v, n, (float)(1.0 - beta1), (float)beta2,
+                     (float)(1.0 - beta2), bc2_sqrt, (float)eps, step_size);
   return check_launch("adam");
 }
 

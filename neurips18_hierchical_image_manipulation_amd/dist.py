@@ -132,11 +132,10 @@ class GradReducer(object):
             ev.record(torch.cuda.current_stream())
             # a bucket can hold gradients written on two streams (conv weight gradients on the side stream, BatchNorm
             # gamma / beta on the main one): the exchange waits for the triggering stream AND the side stream
-            from .ops import _SIDE
-            side = _SIDE.get(self.flat.device)
+            from .ops import wgrad_streams
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
-                if side is not None:
+                for side in wgrad_streams(self.flat.device):
                     self.comm_stream.wait_stream(side)
                 if dist.get_backend(self.group) == 'nccl':       # RCCL: averaging collective
                     dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group)

@@ -18,6 +18,7 @@ from ..optim import FusedAdam
 from .base_model import BaseModel
 
 NULLVAL = 0.0
+_D_WGRAD_ROUTES = os.environ.get('HIM_D_WGRAD_ROUTES', '1') != '0'
 _VGG_STREAM = os.environ.get('HIM_VGG_STREAM', '1') != '0'
 
 
@@ -136,6 +137,16 @@ class Pix2PixHDModel_condImg(BaseModel):
             self.optimizer_D = FusedAdam(self.netD.parameters(), lr=opt.lr, betas=(opt.beta1, 0.999))
             self.reducer_G = self.reducer_D = None
             self.comm_timing = None
+            # autograd creates a parameter's AccumulateGrad node lazily, on the stream that is current at the parameter's
+            # first use of a step -- for D the side stream (real-image branch) -- and makes the caller's stream wait for
+            # every such "leaf stream" when backward() returns: loss_G.backward() ended with the main stream waiting for
+            # ALL weight gradients queued on the side stream (3.4 ms idle per step in the r02 trace) although nothing on
+            # the main stream needs them (the optimizers join that stream themselves).  Holding the nodes, created here
+            # on the main stream, pins them to it.
+            with torch.cuda.device(self.device):
+                self._grad_accumulators = [p.expand_as(p).grad_fn.next_functions[0][0]
+                                           for p in list(self.netG.parameters()) + list(self.netD.parameters())
+                                           if p.requires_grad]
             # gradient routing of the shared fake-image discriminator pass (see forward)
             self._d_weight_ids = set(id(p) for p in self.netD.parameters())
             self._d_first_weight_ids = set(id(getattr(self.netD, 'scale%d_layer0' % i)[0].weight)
@@ -189,25 +200,35 @@ class Pix2PixHDModel_condImg(BaseModel):
             x = self.fake_pool.query(x)
         return self.netD.forward(x)
 
-    def _real_branch_ahead(self, netD_cond, real_image, mask_cond):
-        """D(real) + LSGAN loss and VGG(real) on the side stream (None when disabled)."""
+    def _real_branch_ahead(self, netD_cond, real_image, mask_cond, inputs_ready=None):
+        """D(real) + LSGAN loss and VGG(real) on the side stream (None when disabled).  ``inputs_ready``: event recorded
+        on the main stream right after the input encoding -- the side stream waits for THAT, not for whatever the caller
+        has enqueued on the main stream since (the generator forward)."""
         if os.environ.get('HIM_REAL_AHEAD', '1') == '0':
             return None
         main = torch.cuda.current_stream(self.device)
         side = ops._side_stream(self.device)
-        side.wait_stream(main)
+        if inputs_ready is not None:
+            side.wait_event(inputs_ready)
+        else:
+            side.wait_stream(main)
         self._wait_d_update(side)
         out = {'stream': side, 'y_vgg': None}
+        # --sn_D: every discriminator forward moves the persisted power-iteration vectors, so the three passes must run
+        # in the reference's order (fake-detached, real, fake): only the VGG features of the real image run ahead
+        with_d = not getattr(self.opt, 'sn_D', False)
         with torch.cuda.stream(side):
-            out['pred_real'] = self.discriminate(netD_cond, real_image, mask_cond, False)
-            out['loss_D_real'] = self.criterionGAN(out['pred_real'], True)
+            if with_d:
+                out['pred_real'] = self.discriminate(netD_cond, real_image, mask_cond, False)
+                out['loss_D_real'] = self.criterionGAN(out['pred_real'], True)
             if not self.opt.no_vgg_loss:
                 out['y_vgg'] = self.criterionVGG.target_features(real_image)
         # these tensors were allocated on the side stream and are read on the main one
-        for feats in out['pred_real']:
+        for feats in out.get('pred_real', ()):
             for t in feats:
                 t.record_stream(main)
-        out['loss_D_real'].record_stream(main)
+        if with_d:
+            out['loss_D_real'].record_stream(main)
         for t in (out['y_vgg'] or []):
             t.record_stream(main)
         for t in (netD_cond, real_image, mask_cond):
@@ -232,8 +253,12 @@ class Pix2PixHDModel_condImg(BaseModel):
         # Everything that depends only on the REAL image (its discriminator pass and its VGG features) is independent
         # of the generator: it runs on a side stream next to the generator forward and fills the matrix pipe where the
         # one-tile-per-CU ResnetBlock launches leave it idle.
-        ahead = self._real_branch_ahead(netD_cond, real_image, mask_cond)
+        # The generator forward is enqueued FIRST: the host needs ~2.5 ms to issue the ~80 launches of the real branch,
+        # and the main stream would sit idle for that long at the start of every step (r02 trace) if they went first.
+        inputs_ready = torch.cuda.Event()
+        inputs_ready.record(torch.cuda.current_stream(self.device))
         fake_image = self._generate(buf, input_mask, cond_image, mask_in)
+        ahead = self._real_branch_ahead(netD_cond, real_image, mask_cond, inputs_ready)
         if ahead is not None:
             torch.cuda.current_stream(self.device).wait_stream(ahead['stream'])
         if self.isTrain:
@@ -272,7 +297,7 @@ class Pix2PixHDModel_condImg(BaseModel):
             self._fake_gate = None
             pred_fake_pool = self.discriminate(netD_cond, fake_image, mask_cond, True)
         loss_D_fake = self.criterionGAN(pred_fake_pool, False)
-        if ahead is not None:
+        if ahead is not None and 'pred_real' in ahead:
             pred_real, loss_D_real = ahead['pred_real'], ahead['loss_D_real']
         else:
             pred_real = self.discriminate(netD_cond, real_image, mask_cond, False)
@@ -356,8 +381,15 @@ class Pix2PixHDModel_condImg(BaseModel):
         if shared:
             self._fake_gate['open'] = False
             ops.SKIP_DGRAD.update(self._d_first_weight_ids)
+        # D's weight gradients -- fake branch issued from the main stream, real branch from the side stream where its
+        # forward ran -- all go to the VGG stream (idle by now) instead of queueing behind the generator's last weight
+        # gradients on the side stream.  ONE stream for both branches: they accumulate into the same arena slots.
+        main = torch.cuda.current_stream(self.device)
+        wg = ops._vgg_stream(self.device)
+        routes = {main: wg, ops._side_stream(self.device): wg}
         try:
-            self.loss_D.backward()
+            with ops.route_wgrads(routes if _D_WGRAD_ROUTES else {}):
+                self.loss_D.backward()
         finally:
             ops.SKIP_DGRAD.difference_update(self._d_first_weight_ids)
 

@@ -98,14 +98,50 @@ def _d_opt_stream(device):
     return s
 
 
+# Weight-gradient routing: by default every weight gradient goes to the one side stream.  A trainer may route the weight
+# gradients ISSUED FROM a given stream to another one for the duration of a backward pass (``route_wgrads``): during
+# loss_D.backward() the fake-image branch (data gradients on the main stream) and the real-image branch (data gradients
+# on the side stream, where its forward ran) then each get a weight-gradient stream of their own instead of queueing all
+# of D's weight gradients behind the generator's on the single side stream.
+_WGRAD_ROUTE = {}      # cuda_stream handle of the issuing stream -> torch.cuda.Stream that takes its weight gradients
+_WGRAD_USED = {}       # device -> set of extra streams that carried weight gradients since the last join
+
+
+class route_wgrads(object):
+    def __init__(self, routes):
+        self.routes = {src.cuda_stream: dst for src, dst in routes.items()}
+
+    def __enter__(self):
+        _WGRAD_ROUTE.update(self.routes)
+
+    def __exit__(self, *a):
+        for k in self.routes:
+            _WGRAD_ROUTE.pop(k, None)
+        return False
+
+
+def wgrad_streams(device):
+    """Every stream that may hold unfinished weight-gradient launches of ``device``."""
+    out = [s for dev, s in _SIDE.items() if dev == device]
+    out += list(_WGRAD_USED.get(device, ()))
+    return out
+
+
 def join_side_stream(device=None):
     for dev, s in _SIDE.items():
         if device is None or dev == device:
             torch.cuda.current_stream(dev).wait_stream(s)
+    for dev, used in _WGRAD_USED.items():
+        if device is None or dev == device:
+            cur = torch.cuda.current_stream(dev)
+            for s in used:
+                if s.cuda_stream != cur.cuda_stream:
+                    cur.wait_stream(s)
 
 
 class _wgrad_stream(object):
-    """Context: run the enclosed launches on the side stream, after everything enqueued so far on the current one."""
+    """Context: run the enclosed launches on the weight-gradient stream (the side stream, or the stream the issuing stream
+    is routed to), after everything enqueued so far on the current one."""
 
     def __init__(self, *tensors):
         self.tensors = [t for t in tensors if t is not None]
@@ -115,7 +151,11 @@ class _wgrad_stream(object):
             return None
         dev = self.tensors[0].device
         main = torch.cuda.current_stream(dev)
-        side = _side_stream(dev)
+        side = _WGRAD_ROUTE.get(main.cuda_stream)
+        if side is None:
+            side = _side_stream(dev)
+        else:
+            _WGRAD_USED.setdefault(dev, set()).add(side)
         side.wait_stream(main)
         for t in self.tensors:
             t.record_stream(side)

@@ -25,6 +25,10 @@ from neurips18_hierchical_image_manipulation_amd import synth
 tag, threads, pert = sys.argv[1], int(sys.argv[2]), float(sys.argv[3])
 pseed = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 torch.set_num_threads(threads)
+if len(sys.argv) > 5 and sys.argv[5] == 'native':
+    # every convolution through ATen's own im2col + sgemm path instead of oneDNN: the SAME algorithm, weights and data
+    # with a different fp32 summation order in every layer (what a re-implementation on other hardware also has)
+    torch.backends.mkldnn.enabled = False
 g = np.load(%r + '/' + tag + '.npz'); flags = json.loads(str(g['flags']))
 B, H, W = int(g['B']), int(g['H']), int(g['W']); color = bool(int(g['color']))
 om = ref_cpu.Mask2ImageModel(ref_cpu.Opt(**flags))
@@ -45,8 +49,8 @@ print('RESULT ' + json.dumps(rel))
 ''' % (ROOT, os.path.join(ROOT, 'tests'), HERE)
 
 
-def run(tag, threads, pert=0.0, pseed=0):
-    out = subprocess.run([sys.executable, '-c', WORKER, tag, str(threads), str(pert), str(pseed)], stdout=subprocess.PIPE,
+def run(tag, threads, pert=0.0, pseed=0, alg='onednn'):
+    out = subprocess.run([sys.executable, '-c', WORKER, tag, str(threads), str(pert), str(pseed), alg], stdout=subprocess.PIPE,
                          stderr=subprocess.DEVNULL, text=True, check=True).stdout
     line = [l for l in out.splitlines() if l.startswith('RESULT ')][-1]
     return json.loads(line[7:])
@@ -71,6 +75,15 @@ if __name__ == '__main__':
             if name not in res:
                 res[name] = run(tag, t)
                 print(name, ' '.join('%.1e' % x for x in res[name]), flush=True)
+        # summation order of EVERY convolution changed (ATen native conv instead of oneDNN), nothing else: keys
+        # '<config>_convalg_native_threads<n>_vs_8'
+        for t in ((8, 4) if key != 'tiny_global' else ()):
+            name = '%s_convalg_native_threads%d_vs_8' % (key, t)
+            if name not in res and not os.environ.get('HIM_ENVELOPE_SKIP_NATIVE'):
+                res[name] = run(tag, t, alg='native')
+                print(name, ' '.join('%.1e' % x for x in res[name]), flush=True)
+                with open(out_path, 'w') as f:
+                    json.dump(res, f, indent=1)
         # weight perturbations at the fp32 rounding level (1e-7) and at the level of fp32 Winograd-transform rounding
         # (1e-6: the HIP path evaluates the wide 3x3 layers as F(2x2,3x3), whose rounding error is ~10x the direct form's)
         for pv in ((1e-7, 1e-6) if pert else ()):

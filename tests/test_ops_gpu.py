@@ -76,6 +76,11 @@ CONV_CASES = [
     (8, 16, 130, 250, 2, 3, 1, 1, 'zero', 'none'),       # few-input tiled kernel: data gradient of a 2-output 3x3 layer
     (8, 3, 128, 256, 32, 3, 1, 1, 'zero', 'relu'),       # few-input tiled kernel, forward form (VGG conv1_1), bias + ReLU
     (8, 4, 120, 250, 16, 7, 1, 3, 'zero', 'none'),       # few-input tiled kernel, forward 7x7, ragged tiles
+    (2, 96, 37, 150, 3, 7, 1, 3, 'zero', 'none'),        # MFMA few-channel wgrad, head form: 3 channel groups of 32, 2 column chunks, zero pad
+    (3, 64, 40, 300, 4, 5, 1, 2, 'reflect', 'none'),     # MFMA few-channel wgrad, head form 5x5, 4 outputs, 3 chunks, several row bands
+    (2, 3, 37, 150, 64, 7, 1, 3, 'reflect', 'none'),     # MFMA few-channel wgrad, stem form (3 dense inputs -> 64), reflect
+    (2, 4, 20, 140, 32, 5, 1, 2, 'zero', 'none'),        # MFMA few-channel wgrad, stem form 5x5, 4 inputs -> 32, zero pad
+    (8, 64, 64, 128, 3, 7, 1, 3, 'reflect', 'none'),     # MFMA few-channel wgrad: every workgroup walks several tasks
 ]
 
 
@@ -141,7 +146,8 @@ def test_conv_transpose2d_fwd_bwd(case, act):
     assert_close('deconv bgrad', gb, gb_ref)
 
 
-@pytest.mark.parametrize('shape', [(2, 16, 16, 32), (2, 8, 2, 3), (1, 4, 33, 65), (2, 3, 64, 128), (1, 2, 300, 301)],
+@pytest.mark.parametrize('shape', [(2, 16, 16, 32), (2, 8, 2, 3), (1, 4, 33, 65), (2, 3, 64, 128), (1, 2, 300, 301),
+                                   (1, 3, 256, 512), (1, 2, 181, 183)],
                          ids=str)
 @pytest.mark.parametrize('act', ['none', 'relu', 'lrelu'])
 @pytest.mark.parametrize('with_res', [False, True])

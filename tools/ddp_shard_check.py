@@ -32,7 +32,14 @@ torch.cuda.set_device(local)
 dev = torch.device('cuda', local)
 ops.set_winograd_min_channels(64)        # the toy nets' 128-channel ResnetBlocks take the Winograd kernels
 STEPS, PER = 2, 2
-GRAD_TOL, DELTA_TOL, LOSS_TOL = 2e-4, 5e-2, 2e-5
+# sharded vs the one-rank HIP run: the same kernels on the same images, only the batch split differs -> rounding level;
+# sharded vs the CPU oracle: one fp32 implementation against another -- a ReLU / L1-sign decision within rounding of its
+# threshold falls differently in about one step of three and moves the gradients by up to 1e-2 (tests/fp64_anchor.py),
+# and the first Adam update is lr * sign(g), so its error counts the sign flips of noise-level gradients (the oracle
+# itself is 5..8e-2 away from a float64 step there, tests/golden/fp64_anchor.json)
+LOSS_TOL = 2e-5
+GRAD_TOL_SINGLE, DELTA_TOL_SINGLE = 2e-5, 2e-3
+GRAD_TOL_ORACLE, DELTA_TOL_ORACLE = 2e-2, 0.2
 
 
 def cat_batches(bs):
@@ -107,8 +114,8 @@ def compare(tag, sharded, single, oracle_nets, oracle_opts, before, losses_sh, l
             worst['delta_vs_' + k] = max(worst['delta_vs_' + k], (num[k] / max(den[k], 1e-300)) ** 0.5)
     print('%s: %s' % (tag, ' '.join('%s=%.2e' % kv for kv in worst.items())), flush=True)
     assert worst['loss_vs_single'] < LOSS_TOL and worst['loss_vs_oracle'] < LOSS_TOL, (tag, worst)
-    assert worst['grad_vs_single'] < GRAD_TOL and worst['grad_vs_oracle'] < GRAD_TOL, (tag, worst)
-    assert worst['delta_vs_single'] < DELTA_TOL and worst['delta_vs_oracle'] < DELTA_TOL, (tag, worst)
+    assert worst['grad_vs_single'] < GRAD_TOL_SINGLE and worst['grad_vs_oracle'] < GRAD_TOL_ORACLE, (tag, worst)
+    assert worst['delta_vs_single'] < DELTA_TOL_SINGLE and worst['delta_vs_oracle'] < DELTA_TOL_ORACLE, (tag, worst)
 
 
 # ------------------------------------------------------------------------------------------------------------------
