@@ -109,12 +109,29 @@ def _event_ms(fn, iters):
     return start.elapsed_time(end) / iters
 
 
-def _profile_json(name):
-    p = os.path.join(ROOT, 'profiles', name)
-    if os.path.isfile(p):
-        with open(p) as f:
-            return json.load(f)
-    return None
+def _profile_json(suffix):
+    """Newest committed ``profiles/r<NN>_<suffix>`` (rocprofv3 summaries folded by tools/collect_profiles.sh) -> (name, dict)."""
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_' + suffix)))
+    if not hits:
+        return None, None
+    with open(hits[-1]) as f:
+        return os.path.join('profiles', os.path.basename(hits[-1])), json.load(f)
+
+
+def _event_ms_isolated(fn, iters):
+    """Average duration of ONE launch: an event pair around every launch, the device drained in between (launches
+    issued back to back overlap the tail of one with the ramp-up of the next and under-state the launch by 3-4 %)."""
+    tot = 0.0
+    for _ in range(iters):
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        b.synchronize()
+        tot += a.elapsed_time(b)
+    return tot / iters
 
 
 def dominant_kernel_roofline(device, bs, ntiles):
@@ -123,15 +140,16 @@ def dominant_kernel_roofline(device, bs, ntiles):
     [16] x (1024 x 1024) x (1024 x ntiles) with ntiles = B * H/2 * W/2 (C2: 8x8x16 = 1024, 34.36 GFLOP EXECUTED per
     launch; the direct form of the same conv is 77.31 GFLOP: Winograd does 2.25x fewer multiplies).  18 forward + 18
     data-gradient + 18 weight-gradient launches of this shape per step.
-    `achieved` = executed FLOP / average launch time.  `source: "microbench"`: the launches timed here are issued
-    back-to-back by this function through the C ABI (him_winograd_gemm = exactly the kernel/grid the conv launches),
-    with HIP events on the launch stream -- NOT the launches inside the timed training step (those share the GPU with
-    side-stream kernels); `avg_launch_ms_rocprof` is the same kernel's average duration in the committed rocprofv3
-    kernel trace of the same microbench (profiles/), which the HIP-event figure must agree with (back-to-back launches
-    overlap their tails by a few %).  MFMA-bound: algorithmic bytes = the three operands read/written once, intensity
-    171 FLOP/B >> the fp32 ridge of ~25.
-    `traffic` = HBM-side bytes per launch from the committed PMC passes (FETCH_SIZE x2 (gfx950 correction) +
-    WRITE_SIZE; profiles/*pmc_dominant_kernel.json), null if that file is absent or the shape differs.
+    `achieved` = executed FLOP / `avg_launch_ms`, the average duration of ONE launch: issued through the C ABI
+    (him_winograd_gemm = exactly the kernel / grid the conv launches) between two HIP events on the launch stream with
+    the device drained before each launch (`avg_launch_ms_back_to_back`: 20 launches between one event pair -- the tails
+    overlap, 3-4 % shorter).  `source: "microbench"`: these are NOT the launches inside the timed training step, which
+    share the GPU with other streams; `rocprof` quotes the committed rocprofv3 kernel trace (profiles/
+    r<NN>_dominant_kernel_rocprof.json, written by tools/collect_profiles.sh): the same launch isolated -- which
+    `avg_launch_ms` must agree with -- and its average inside the traced step.  MFMA-bound: algorithmic bytes = the three
+    operands read / written once, intensity 171 FLOP/B >> the fp32 ridge of ~25.
+    `traffic` = HBM-side bytes per launch from the committed PMC passes named in `traffic_source` (FETCH_SIZE x2 (gfx950
+    correction) + WRITE_SIZE), null if that file is absent or the shape differs -- not measured in this run.
     `conv_launch` times the WHOLE conv (transforms + GEMM, cached weight panel) and states its rate in
     direct-form-equivalent FLOP, for comparison with a non-Winograd implementation."""
     from neurips18_hierchical_image_manipulation_amd import ops
@@ -145,7 +163,8 @@ def dominant_kernel_roofline(device, bs, ntiles):
     gemm = lambda: lib.him_winograd_gemm(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, K, N, st)  # noqa: E731
     for _ in range(3):
         gemm()
-    ms = _event_ms(gemm, 20)
+    ms_b2b = _event_ms(gemm, 20)
+    ms = _event_ms_isolated(gemm, 20)
     flops = 2.0 * 16 * M * K * N
     ach = flops / (ms * 1e-3) / 1e12
     # the whole conv launch, as the trainer runs it (Parameter weight: cached Winograd panel)
@@ -162,22 +181,48 @@ def dominant_kernel_roofline(device, bs, ntiles):
             conv()
         cms = _event_ms(conv, 20)
     direct = 2.0 * 1024 * (bs * hw) * (1024 * 9)
-    traffic = rocprof_ms = None
-    pmc = _profile_json('r02_pmc_dominant_kernel.json') or _profile_json('r01_pmc_dominant_kernel.json')
+    traffic = traffic_src = None
+    pmc_name, pmc = _profile_json('pmc_dominant_kernel.json')
     if pmc is not None and int(pmc.get('N', 1024)) == N:
-        traffic = int(pmc['traffic_bytes_corrected'])
-    kt = _profile_json('r02_gemm_bench_rocprof.json')
+        traffic, traffic_src = int(pmc['traffic_bytes_corrected']), pmc_name
+    kt_name, kt = _profile_json('dominant_kernel_rocprof.json')
+    rocprof = None
     if kt is not None and int(kt.get('N', 1024)) == N:
-        rocprof_ms = kt.get('avg_launch_ms')
+        rocprof = dict(file=kt_name, avg_launch_ms_isolated=kt.get('avg_launch_ms'),
+                       avg_launch_ms_in_step=kt.get('in_step_avg_launch_ms'),
+                       frac_isolated=kt.get('frac_of_f32_mfma_peak'), frac_in_step=kt.get('in_step_frac_of_f32_mfma_peak'))
     return dict(bound='mfma', source='microbench',
                 kernel='batched Winograd GEMM [16]x(1024x1024)x(1024x%d) on the fp32-MFMA conv kernel '
                        '(ResnetBlock conv3x3 1024->1024, bs %d)' % (N, bs),
                 achieved=round(ach, 2), peak=PEAK_F32_MFMA, unit='TFLOP/s', frac=round(ach / PEAK_F32_MFMA, 4),
-                traffic=traffic, traffic_unit='bytes/launch (PMC, corrected)', algorithmic_bytes=16 * 4 * (M * K + K * N + M * N),
-                flop_per_launch=flops, avg_launch_ms=round(ms, 4), avg_launch_ms_rocprof=rocprof_ms,
+                frac_is='achieved / peak with achieved = flop_per_launch / avg_launch_ms (ONE launch between two HIP '
+                        'events on the launch stream, device drained before each); rocprof.* = the committed rocprofv3 '
+                        'kernel trace: the same launch isolated, and its average inside the traced training step',
+                traffic=traffic, traffic_unit='bytes/launch (PMC, corrected)', traffic_source=traffic_src,
+                algorithmic_bytes=16 * 4 * (M * K + K * N + M * N),
+                flop_per_launch=flops, avg_launch_ms=round(ms, 4), avg_launch_ms_back_to_back=round(ms_b2b, 4),
+                rocprof=rocprof,
                 conv_launch=dict(ms=round(cms, 4), direct_form_gflop=round(direct / 1e9, 2),
                                  direct_form_equivalent_tflops=round(direct / (cms * 1e-3) / 1e12, 1),
                                  executed_tflops=round(flops / (cms * 1e-3) / 1e12, 1)))
+
+
+def step_flop_accounting(ms_per_step, bs):
+    """Whole-step roofline of the C2 workload: SURVEY 8(d)'s direct-form count (3 F_G + 9 F_D + 3 F_V = 1225 GFLOP per
+    image) minus what this build does not execute, over the measured step time."""
+    f_g, f_d, f_v = 246.3, 22.4, 94.7                        # GFLOP per image, forward, direct form (SURVEY appendix A)
+    direct = (3 * f_g + 9 * f_d + 3 * f_v) * bs / 1e3        # TFLOP per step
+    terms = {
+        'winograd_resnet_stack_54_launches': 54 * (77.309 - 34.360) / 1e3,            # F(2x2,3x3): 2.25x fewer multiplies
+        'winograd_vgg_3_passes': 3 * (f_v - 0.45) * bs / 1e3 * (1 - 1 / 2.25),        # every VGG conv but conv1_1
+        'stem_from_label_ids_fwd_and_wgrad': 2 * 2.0 * 64 * 35 * 49 * (bs * 256 * 512) / 1e12,
+        'discriminator_passes_7_instead_of_9': 2 * f_d * bs / 1e3,   # shared fake pass; no D weight gradients in loss_G
+    }
+    executed = direct - sum(terms.values())
+    return dict(direct_form_tflop=round(direct, 3), not_executed_tflop={k: round(v, 3) for k, v in terms.items()},
+                step_executed_tflop=round(executed, 3),
+                step_executed_tflops_rate=round(executed / (ms_per_step * 1e-3), 2),
+                step_frac_of_peak=round(executed / (ms_per_step * 1e-3) / PEAK_F32_MFMA, 4))
 
 
 def direct_conv_roofline(device, bs, cin, cout, k, stride, pad, h, w, what):
@@ -408,6 +453,8 @@ def main():
                 ntiles = {'c2': 8 * 8 * 16, 'c2local': 8 * 4 * 8, 'c4': 16 * 8 * 8}[args.workload]
                 out['roofline'] = dominant_kernel_roofline(device, bs, ntiles)
                 out['g_forward'] = g_forward_roofline(model, batches[0], wl)
+                if args.workload == 'c2':
+                    out['step_roofline'] = step_flop_accounting(ms, bs)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.workload, wl, args.cpu_steps)
         print(json.dumps(out), flush=True)

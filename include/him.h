@@ -183,6 +183,33 @@ int him_set_winograd_min_channels(int c);
  * This is the launch the roofline in bench.py is measured on (fp32 MFMA, 2*16*M*K*N executed FLOP). */
 int him_winograd_gemm(const float* a, const float* b, float* c, int M, int K, int N, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * ResnetBlock  out = x + IN(conv3x3(refpad(relu(IN(conv3x3(refpad(x)))))))  with both InstanceNorms fused into the
+ * Winograd transforms of the two convolutions: reference models/layer_util.py:333-378 (ResnetBlock.build_conv_block /
+ * forward) with norm_layer = InstanceNorm2d(affine=False) (:19-26), as built by GlobalGenerator
+ * (models/Pix2Pix_NET.py:82-84).  Statistics are reduced in the output transform, the normalisation + ReLU is applied on
+ * load by the next input transform (the normalised tensor is never written), the tail norm + residual in the second
+ * output transform; backward applies the ReLU gate + InstanceNorm backward in the data gradient's output transform.
+ * Supported: the separate-transform Winograd range (C above the fused kernel's, C % 128 == 0), even planes >= 4x4 with
+ * H*W <= 4096; him_resblock_supported() tells.  panel*: HIM_PANEL_FWD / HIM_PANEL_BWD_DATA panels of the 3x3 reflect-pad
+ * conv descriptor (him_conv2d_panel_build).  stat*: [mean(B*C) | rstd(B*C)].  y1 / y2: raw conv outputs (+bias).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  int B, C, H, W;
+  float eps;
+} HimResBlock;
+int him_resblock_supported(const HimResBlock* d);
+size_t him_resblock_ws(const HimResBlock* d);
+size_t him_resblock_bwd_weight_ws(const HimResBlock* d);
+int him_resblock_fwd(const HimResBlock* d, const float* x, const void* panel1, const float* bias1, const void* panel2,
+                     const float* bias2, float* y1, float* stat1, float* y2, float* stat2, float* out, void* ws,
+                     size_t ws_bytes, void* stream);
+int him_resblock_bwd_data(const HimResBlock* d, const float* g_out, const float* y1, const float* stat1, const float* y2,
+                          const float* stat2, const void* panel1_bwd, const void* panel2_bwd, float* dy2, float* dy1,
+                          float* dx, void* ws, size_t ws_bytes, void* stream);
+int him_resblock_bwd_weight(const HimResBlock* d, int which, const float* src, const float* stat, const float* dy, float* dw,
+                            int accumulate, void* ws, size_t ws_bytes, void* stream);
+
 #define HIM_PANEL_FWD 0
 #define HIM_PANEL_BWD_DATA 1
 size_t him_conv2d_panel_bytes(const HimConv2d* d, int kind);

@@ -23,11 +23,15 @@ class HimDeconv2d(C.Structure):
                                      'OH', 'OW', 'act')] + [('slope', c_float)]
 
 
+class HimResBlock(C.Structure):
+    _fields_ = [(n, c_int) for n in ('B', 'C', 'H', 'W')] + [('eps', c_float)]
+
+
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 PAD_ZERO, PAD_REFLECT = 0, 1
 
 P = c_void_p
-_CONV, _DECONV = C.POINTER(HimConv2d), C.POINTER(HimDeconv2d)
+_CONV, _DECONV, _RESB = C.POINTER(HimConv2d), C.POINTER(HimDeconv2d), C.POINTER(HimResBlock)
 
 # name -> (restype, argtypes); int-returning entries are error-checked by the wrapper
 _SIGS = {
@@ -105,6 +109,12 @@ _SIGS = {
     'him_l1_mean_bwd': (c_int, [P, P, c_size_t, P, P, c_int, P]),
     'him_mse_const_fwd': (c_int, [P, c_size_t, c_float, P, P, c_size_t, P]),
     'him_mse_const_bwd': (c_int, [P, c_size_t, c_float, P, P, c_int, P]),
+    'him_resblock_supported': (C.c_uint, [_RESB]),
+    'him_resblock_ws': (c_size_t, [_RESB]),
+    'him_resblock_bwd_weight_ws': (c_size_t, [_RESB]),
+    'him_resblock_fwd': (c_int, [_RESB, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
+    'him_resblock_bwd_data': (c_int, [_RESB, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
+    'him_resblock_bwd_weight': (c_int, [_RESB, c_int, P, P, P, P, c_int, P, c_size_t, P]),
     'him_adam_step': (c_int, [P, P, P, P, c_size_t, c_double, c_double, c_double, c_double, c_int, P]),
     'him_fill': (c_int, [P, c_size_t, c_float, P]),
     'him_scale': (c_int, [P, c_size_t, c_float, P]),

@@ -19,6 +19,7 @@ from .base_model import BaseModel
 
 NULLVAL = 0.0
 _D_WGRAD_ROUTES = os.environ.get('HIM_D_WGRAD_ROUTES', '1') != '0'
+_REAL_FIRST = os.environ.get('HIM_REAL_FIRST', '0') != '0'
 _VGG_STREAM = os.environ.get('HIM_VGG_STREAM', '1') != '0'
 
 
@@ -207,7 +208,7 @@ class Pix2PixHDModel_condImg(BaseModel):
         if os.environ.get('HIM_REAL_AHEAD', '1') == '0':
             return None
         main = torch.cuda.current_stream(self.device)
-        side = ops._side_stream(self.device)
+        side = ops._real_stream(self.device)
         if inputs_ready is not None:
             side.wait_event(inputs_ready)
         else:
@@ -257,8 +258,12 @@ class Pix2PixHDModel_condImg(BaseModel):
         # and the main stream would sit idle for that long at the start of every step (r02 trace) if they went first.
         inputs_ready = torch.cuda.Event()
         inputs_ready.record(torch.cuda.current_stream(self.device))
-        fake_image = self._generate(buf, input_mask, cond_image, mask_in)
-        ahead = self._real_branch_ahead(netD_cond, real_image, mask_cond, inputs_ready)
+        if _REAL_FIRST:      # A/B switch: round 2's issue order
+            ahead = self._real_branch_ahead(netD_cond, real_image, mask_cond, inputs_ready)
+            fake_image = self._generate(buf, input_mask, cond_image, mask_in)
+        else:
+            fake_image = self._generate(buf, input_mask, cond_image, mask_in)
+            ahead = self._real_branch_ahead(netD_cond, real_image, mask_cond, inputs_ready)
         if ahead is not None:
             torch.cuda.current_stream(self.device).wait_stream(ahead['stream'])
         if self.isTrain:
@@ -381,17 +386,19 @@ class Pix2PixHDModel_condImg(BaseModel):
         if shared:
             self._fake_gate['open'] = False
             ops.SKIP_DGRAD.update(self._d_first_weight_ids)
-        # D's weight gradients -- fake branch issued from the main stream, real branch from the side stream where its
-        # forward ran -- all go to the VGG stream (idle by now) instead of queueing behind the generator's last weight
+        # D's weight gradients -- fake branch issued from the main stream, real branch from the real-image stream where
+        # its forward ran -- all go to the VGG stream (idle by now) instead of queueing behind the generator's last weight
         # gradients on the side stream.  ONE stream for both branches: they accumulate into the same arena slots.
         main = torch.cuda.current_stream(self.device)
         wg = ops._vgg_stream(self.device)
-        routes = {main: wg, ops._side_stream(self.device): wg}
+        routes = {main: wg, ops._real_stream(self.device): wg}
         try:
             with ops.route_wgrads(routes if _D_WGRAD_ROUTES else {}):
                 self.loss_D.backward()
         finally:
             ops.SKIP_DGRAD.difference_update(self._d_first_weight_ids)
+        # the real branch's data-gradient chain reads D's weights on its own stream: D's Adam step comes after it
+        main.wait_stream(ops._real_stream(self.device))
 
     def backward_G(self):
         """optimizer_G.zero_grad(); loss_G.backward(); optimizer_G.step()   (:78-80)."""

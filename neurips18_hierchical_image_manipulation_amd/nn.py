@@ -234,7 +234,16 @@ class ResnetBlock(nn.Module):
                                         ReflectionPad2d(1), Conv2d(dim, dim, 3), InstanceNorm2d(dim))
 
     def forward(self, x):
-        return run_layers(list(self.conv_block), x, final_residual=x)
+        cb = self.conv_block
+        c1, c2 = cb[1], cb[5]
+        if (_DEAD_BIAS_SKIP and type(c1) is Conv2d and type(c2) is Conv2d and not _Frozen.on
+                and ops.resblock_supported(x, c1.weight, c2.weight)):
+            # the 1024-channel stack: both InstanceNorms ride in the Winograd transforms of the two convolutions
+            for c in (c1, c2):
+                if c.bias is not None:
+                    c.bias._him_dead_grad = True
+            return ops.resnet_block(x, c1.weight, c1.bias, c2.weight, c2.bias, cb[2].eps)
+        return run_layers(list(cb), x, final_residual=x)
 
 
 class AvgPool3s2(nn.Module):

@@ -14,7 +14,7 @@ import os
 
 import torch
 
-from ._cabi import (lib, HimConv2d, HimDeconv2d, ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID, PAD_ZERO,
+from ._cabi import (lib, HimConv2d, HimDeconv2d, HimResBlock, ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID, PAD_ZERO,
                     PAD_REFLECT, HimError)
 
 ACTS = {'none': ACT_NONE, 'relu': ACT_RELU, 'lrelu': ACT_LRELU, 'tanh': ACT_TANH, 'sigmoid': ACT_SIGMOID}
@@ -83,6 +83,19 @@ def _vgg_stream(device):
     s = _VGGS.get(device)
     if s is None:
         s = _VGGS[device] = torch.cuda.Stream(device=device)
+    return s
+
+
+_REAL = {}
+
+
+def _real_stream(device):
+    """Stream of everything that depends only on the REAL image (its discriminator pass, its VGG features) and of that
+    branch's backward.  Not the weight-gradient stream: the branch's data-gradient chain must not queue behind the
+    generator's last weight gradients at the end of the step (r03b trace: 4 ms of idle main stream)."""
+    s = _REAL.get(device)
+    if s is None:
+        s = _REAL[device] = torch.cuda.Stream(device=device)
     return s
 
 
@@ -552,6 +565,94 @@ class _Deconv2d(torch.autograd.Function):
 
 def conv_transpose2d(x, w, b=None, stride=2, pad=1, out_pad=1, act='none', slope=0.2):
     return _Deconv2d.apply(x, w, b, stride, pad, out_pad, ACTS[act], float(slope))
+
+
+# ------------------------------------------------------------------------------------------------
+# ResnetBlock with both InstanceNorms fused into the Winograd transforms (include/him.h "ResnetBlock")
+# ------------------------------------------------------------------------------------------------
+class _ResBlock(torch.autograd.Function):
+    """out = x + IN(conv3(refpad(relu(IN(conv3(refpad(x)))))))  (reference models/layer_util.py:333-378) as ONE node:
+    7 launches forward (two input transforms -- the second normalises on load --, two batched GEMMs, two output
+    transforms that reduce the plane statistics), no normalised intermediate in HBM; backward applies the ReLU gate and
+    the InstanceNorm backward inside the data gradient's output transform and adds the skip gradient in the last one.
+    The conv biases feed an InstanceNorm (zero true gradient): they take part in the forward only."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, eps):
+        ctx.set_materialize_grads(False)
+        x = x.contiguous()
+        _chk(x, w1, b1, w2, b2)
+        B, Cn, H, W = x.shape
+        d = HimResBlock(B, Cn, H, W, eps)
+        cd = _conv_desc(x, w1, 1, 1, PAD_REFLECT, ACT_NONE, 0.0)
+        p1, p2 = _panel(w1, cd, PANEL_FWD, False), _panel(w2, cd, PANEL_FWD, False)
+        if not p1 or not p2:
+            raise HimError('fused ResnetBlock needs cached weight panels (nn.Parameter weights)')
+        y1, y2, out = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        st1 = torch.empty(2 * B * Cn, dtype=torch.float32, device=x.device)
+        st2 = torch.empty_like(st1)
+        nb = lib.him_resblock_ws(ctypes.byref(d))
+        ws = _ws(nb, x)
+        lib.him_resblock_fwd(ctypes.byref(d), _p(x), p1, _p(b1), p2, _p(b2), _p(y1), _p(st1), _p(y2), _p(st2), _p(out),
+                             _p(ws), nb, _stream())
+        ctx.d, ctx.cd = d, cd
+        ctx.x, ctx.w1, ctx.w2 = x, w1, w2
+        ctx.save_for_backward(y1, st1, y2, st2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return (None,) * 6
+        g = g.contiguous()
+        d, cd, x, w1, w2 = ctx.d, ctx.cd, ctx.x, ctx.w1, ctx.w2
+        y1, st1, y2, st2 = ctx.saved_tensors
+        q1, q2 = _panel(w1, cd, PANEL_BWD_DATA, False), _panel(w2, cd, PANEL_BWD_DATA, False)
+        dy2, dy1 = torch.empty_like(x), torch.empty_like(x)
+        dx = torch.empty_like(x)
+        nb = lib.him_resblock_ws(ctypes.byref(d))
+        ws = _ws(nb, x)
+        lib.him_resblock_bwd_data(ctypes.byref(d), _p(g), _p(y1), _p(st1), _p(y2), _p(st2), q1, q2, _p(dy2), _p(dy1), _p(dx),
+                                  _p(ws), nb, _stream())
+        dws = [None, None]
+        nbw = lib.him_resblock_bwd_weight_ws(ctypes.byref(d))
+        for i, (w, src, stat, dy) in enumerate(((w2, y1, st1, dy2), (w1, x, None, dy1))):
+            which = 2 - i
+            if not ctx.needs_input_grad[1 if which == 1 else 3] or _wkey(w) in SKIP_WGRAD:
+                continue
+            if _direct(w):
+                with _wgrad_stream(src, dy, stat):
+                    wsw = _ws(nbw, x)
+                    lib.him_resblock_bwd_weight(ctypes.byref(d), which, _p(src), _p(stat), _p(dy), _p(w.grad), 1, _p(wsw), nbw,
+                                                _stream())
+                    _notify(w)
+            else:
+                wsw = _ws(nbw, x)
+                dw = torch.empty_like(w)
+                lib.him_resblock_bwd_weight(ctypes.byref(d), which, _p(src), _p(stat), _p(dy), _p(dw), 0, _p(wsw), nbw, _stream())
+                dws[which - 1] = dw
+        return (dx if ctx.needs_input_grad[0] else None), dws[0], None, dws[1], None, None
+
+
+_RESBLOCK_ON = os.environ.get('HIM_NO_RESBLOCK_FUSED') is None
+
+
+def resblock_supported(x, w1, w2):
+    """True when ``resnet_block`` can take (x, w1, w2): CUDA fp32, nn.Parameter weights (cached panels) and a shape in
+    the separate-transform Winograd range (him_resblock_supported)."""
+    if not (_RESBLOCK_ON and _PANELS_ON and x.is_cuda and x.dim() == 4 and isinstance(w1, torch.nn.Parameter)
+            and isinstance(w2, torch.nn.Parameter)):
+        return False
+    B, Cn, H, W = x.shape
+    if tuple(w1.shape) != (Cn, Cn, 3, 3) or tuple(w2.shape) != (Cn, Cn, 3, 3):
+        return False
+    return bool(lib.him_resblock_supported(ctypes.byref(HimResBlock(B, Cn, H, W, 1e-5))))
+
+
+def resnet_block(x, w1, b1, w2, b2, eps=1e-5):
+    """x + IN(conv3x3(refpad(relu(IN(conv3x3(refpad(x), w1, b1)))), w2, b2)) with the norms fused into the convolutions'
+    Winograd transforms; b1 / b2 (in front of an InstanceNorm: zero true gradient) are used as data."""
+    return _ResBlock.apply(x, w1, None if b1 is None else b1.detach(), w2, None if b2 is None else b2.detach(), float(eps))
 
 
 # ------------------------------------------------------------------------------------------------

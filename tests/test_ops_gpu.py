@@ -540,3 +540,52 @@ def test_gated_ops_match_plain_ops():
     (g1,) = torch.autograd.grad(ops.l1_weighted_sum([(a, b)], [0.5], gate_relu=True), a)
     (g0,) = torch.autograd.grad(ops.l1_weighted_sum([(a, b)], [0.5]), a)
     assert torch.equal(g1, g0 * (a.detach() > 0))
+
+
+@pytest.mark.parametrize('shape', [(2, 640, 8, 12), (1, 1024, 16, 16)], ids=str)
+def test_fused_resnet_block_matches_layerwise_path_and_torch(shape):
+    """ResnetBlock with the InstanceNorms fused into the Winograd transforms (include/him.h "ResnetBlock", reference
+    models/layer_util.py:333-378) against (1) the layer-by-layer HIP path (same GEMMs and transform arithmetic: only the
+    order of the plane-statistics sums differs) and (2) the torch CPU block -- forward, input gradient, both weight
+    gradients."""
+    import torch.nn as tnn
+    from neurips18_hierchical_image_manipulation_amd import nn as hn
+    ops = _ops()
+    B, Cn, H, W = shape
+    blk = hn.ResnetBlock(Cn)
+    g = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        for conv in (blk.conv_block[1], blk.conv_block[5]):
+            conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (Cn * 9) ** -0.5)
+            conv.bias.copy_(torch.randn(Cn, generator=g) * 0.1)
+    ref = tnn.Sequential(tnn.ReflectionPad2d(1), tnn.Conv2d(Cn, Cn, 3), tnn.InstanceNorm2d(Cn), tnn.ReLU(),
+                         tnn.ReflectionPad2d(1), tnn.Conv2d(Cn, Cn, 3), tnn.InstanceNorm2d(Cn))
+    with torch.no_grad():
+        ref[1].weight.copy_(blk.conv_block[1].weight)
+        ref[1].bias.copy_(blk.conv_block[1].bias)
+        ref[5].weight.copy_(blk.conv_block[5].weight)
+        ref[5].bias.copy_(blk.conv_block[5].bias)
+    x = _rand(B, Cn, H, W, seed=5).requires_grad_(True)
+    gy = _rand(B, Cn, H, W, seed=6)
+    y_ref = x + ref(x)
+    gx_ref, gw1_ref, gw2_ref = torch.autograd.grad(y_ref, (x, ref[1].weight, ref[5].weight), gy)
+    blk.to(DEV)
+    w1, w2 = blk.conv_block[1].weight, blk.conv_block[5].weight
+
+    def run(fused):
+        prev, ops._RESBLOCK_ON = ops._RESBLOCK_ON, fused
+        try:
+            xd = x.detach().to(DEV).requires_grad_(True)
+            assert ops.resblock_supported(xd, w1, w2) == fused
+            y = blk(xd)
+            return (y,) + torch.autograd.grad(y, (xd, w1, w2), gy.to(DEV))
+        finally:
+            ops._RESBLOCK_ON = prev
+    fused, plain = run(True), run(False)
+    for name, a, b in zip(('out', 'dx', 'dw1', 'dw2'), fused, plain):
+        assert_close('fused vs layer-wise ' + name, a, b, rtol=2e-5)
+    assert_close('block fwd', fused[0], y_ref, rtol=1e-4)
+    # a handful of the 1e5 ReLU inputs sit within rounding of zero and flip between two fp32 summation orders
+    assert_close('block dx', fused[1], gx_ref, rtol=2e-3)
+    assert_close('block dw1', fused[2], gw1_ref, rtol=2e-3)
+    assert_close('block dw2', fused[3], gw2_ref, rtol=2e-3)

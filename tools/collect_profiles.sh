@@ -14,10 +14,12 @@ python $ROOT/tools/prof_summary.py $OUT/bench_trace --by-grid > $OUT/${TAG}_benc
 python $ROOT/tools/stream_view.py $OUT/bench_trace > $OUT/${TAG}_bench_stream_view.txt 2>&1
 python $ROOT/tools/timeline.py $OUT/bench_trace > $OUT/${TAG}_bench_timeline.txt 2>&1
 for f in $(find $OUT/bench_trace -name "*.db" -size -30M); do cp $f $OUT/bench_trace.db; done
+python $ROOT/tools/step_phases.py $OUT/bench_trace.db 80 > $OUT/${TAG}_bench_step_phases.txt 2>&1
 rm -rf $OUT/bench_trace
 # 2. the dominant launch on its own: kernel trace with stats, then one PMC group per pass
 rocprofv3 --kernel-trace --stats -d $OUT/gemm_trace -o r -- python $ROOT/tools/gemm_bench.py 20 > $OUT/gemm_under_trace.log 2>&1
 python $ROOT/tools/prof_summary.py $OUT/gemm_trace > $OUT/${TAG}_gemm_bench_kernel_stats.txt 2>&1
+python $ROOT/tools/dominant_kernel_json.py $OUT/gemm_trace $OUT/bench_trace.db $OUT/${TAG}_dominant_kernel_rocprof.json > $OUT/dominant_kernel_json.log 2>&1
 rm -rf $OUT/gemm_trace
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_INST_LDS"; do
   d=$OUT/pmc_$(echo $grp | cut -d' ' -f1)

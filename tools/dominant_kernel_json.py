@@ -1,0 +1,49 @@
+#!/usr/bin/env python
+"""profiles/r<NN>_dominant_kernel_rocprof.json: the dominant launch (batched Winograd GEMM, gconv_fast_kernel<2,2,2,2,0,false>
+on a grid of 16 * (1024/128)^2 = 1024 workgroups) as rocprofv3 --kernel-trace saw it (a) alone, in the trace of
+tools/gemm_bench.py, and (b) inside the traced training step of bench.py.
+Usage: python tools/dominant_kernel_json.py <gemm_trace dir|db> <bench_trace dir|db> <out.json>"""
+import glob
+import json
+import os
+import sqlite3
+import sys
+
+PEAK, FLOP = 157.3, 2.0 * 16 * 1024 ** 3
+
+
+def durations(path, need_adam):
+    if os.path.isdir(path):
+        path = sorted(glob.glob(os.path.join(path, '**', '*.db'), recursive=True))[0]
+    c = sqlite3.connect(path)
+    rows = c.execute('select name, start, end, grid_x, grid_y, grid_z, workgroup_x from kernels order by start').fetchall()
+    if need_adam:       # whole training steps only: between the first and the last Adam launch, warm-up steps dropped
+        adam = [r[2] for r in rows if 'adam_kernel' in r[0]]
+        lo, hi = adam[len(adam) // 3], adam[-1]
+        rows = [r for r in rows if r[1] >= lo and r[2] <= hi]
+    sel = [r[2] - r[1] for r in rows if 'gconv_fast_kernel<2, 2, 2, 2, 0, false>' in r[0]
+           and r[3] // max(r[6], 1) == 1024 and r[4] == 1 and r[5] == 1]
+    return sel
+
+
+def main():
+    iso, step = durations(sys.argv[1], False), durations(sys.argv[2], True)
+    iso = iso[3:] if len(iso) > 6 else iso        # warm-up launches of the microbench
+    out = dict(N=1024, kernel='gconv_fast_kernel<2,2,2,2,0,false> grid 1024', launches=len(iso),
+               avg_launch_ms=round(sum(iso) / len(iso) / 1e6, 4),
+               executed_tflops=round(FLOP / (sum(iso) / len(iso) * 1e-9) / 1e12, 2))
+    out['frac_of_f32_mfma_peak'] = round(out['executed_tflops'] / PEAK, 4)
+    if step:
+        avg = sum(step) / len(step)
+        out.update(in_step_launches=len(step), in_step_avg_launch_ms=round(avg / 1e6, 4),
+                   in_step_executed_tflops=round(FLOP / (avg * 1e-9) / 1e12, 2))
+        out['in_step_frac_of_f32_mfma_peak'] = round(out['in_step_executed_tflops'] / PEAK, 4)
+    out['command'] = ('rocprofv3 --kernel-trace --stats -- python tools/gemm_bench.py 20 (isolated) and rocprofv3 --kernel-trace '
+                      '-- python bench.py --steps 6 --warmup 3 (in step); tools/collect_profiles.sh')
+    with open(sys.argv[3], 'w') as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()
