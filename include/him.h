@@ -175,7 +175,9 @@ int him_conv2d_onehot_bwd_weight(const HimConv2d* d, const float* label, int n_o
  * HIM_NO_WINOGRAD) run as Winograd F(2x2,3x3): transforms + ONE batched fp32-MFMA GEMM over the 16 transform
  * positions (2.25x fewer multiplies; fp32 rounding differs from the direct form at the 1e-6 level).  The data and
  * weight gradients of those layers use the same scheme.  Workspace / panel sizes follow the current setting: change
- * it only between steps, then rebuild cached panels.  c <= 0 turns it off.  Returns the previous value. */
+ * it only between steps, then rebuild cached panels.  c <= 0 turns EVERY Winograd form off (also the fused
+ * single-launch kernel of the 64..512-channel layers): all convolutions then run in the direct form.  Returns the
+ * previous value. */
 int him_set_winograd_min_channels(int c);
 
 /* Stage 2 of the Winograd convolution on its own: c[z][m][n] = sum_k a[z][m][k] * b[z][k][n] for the 16 transform

@@ -822,7 +822,8 @@ static int wino_fused_max_c() {
 }
 static bool wino_fused_ok(int Co, int Ci, int KH, int KW, int stride, int pad, int B, int H, int W) {
   const int mc = wino_fused_min_c();
-  return mc > 0 && Ci >= mc && Ci <= wino_fused_max_c() && Co >= 64 &&
+  // him_set_winograd_min_channels(<= 0) / HIM_NO_WINOGRAD turn EVERY Winograd form off (parity runs in the direct form)
+  return mc > 0 && wino_min_c() > 0 && Ci >= mc && Ci <= wino_fused_max_c() && Co >= 64 &&
          wino_fused_shape_ok(Co, Ci, KH, KW, stride, pad, B, H, W);
 }
 static bool wino_fused_fwd_ok(const HimConv2d* d) {

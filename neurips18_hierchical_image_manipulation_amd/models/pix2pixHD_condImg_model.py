@@ -20,6 +20,7 @@ from .base_model import BaseModel
 NULLVAL = 0.0
 _D_WGRAD_ROUTES = os.environ.get('HIM_D_WGRAD_ROUTES', '1') != '0'
 _REAL_FIRST = os.environ.get('HIM_REAL_FIRST', '0') != '0'
+_D_FIRST = os.environ.get('HIM_D_BACKWARD_FIRST', '1') != '0'
 _VGG_STREAM = os.environ.get('HIM_VGG_STREAM', '1') != '0'
 
 
@@ -258,7 +259,13 @@ class Pix2PixHDModel_condImg(BaseModel):
         # and the main stream would sit idle for that long at the start of every step (r02 trace) if they went first.
         inputs_ready = torch.cuda.Event()
         inputs_ready.record(torch.cuda.current_stream(self.device))
-        if _REAL_FIRST:      # A/B switch: round 2's issue order
+        if getattr(self, '_g_update_pending', False):
+            # the previous step left G's exchange + Adam + panel rebuild running on the optimizer stream: the real-image
+            # branch (no generator weights) is enqueued first and runs next to them, the generator waits
+            ahead = self._real_branch_ahead(netD_cond, real_image, mask_cond, inputs_ready)
+            self._wait_g_update()
+            fake_image = self._generate(buf, input_mask, cond_image, mask_in)
+        elif _REAL_FIRST:      # A/B switch: round 2's issue order
             ahead = self._real_branch_ahead(netD_cond, real_image, mask_cond, inputs_ready)
             fake_image = self._generate(buf, input_mask, cond_image, mask_in)
         else:
@@ -342,6 +349,7 @@ class Pix2PixHDModel_condImg(BaseModel):
                                                                         infer=True, obj_mask=obj_mask,
                                                                         color_embed=color_embed)
             buf, _, _, mask_dev = self._enc
+            self._wait_g_update()
             fake_image = self._generate(buf, input_mask, cond_image, mask_dev)
         self._visuals = (fake_image, real_image, input_mask, cond_image)
         return fake_image
@@ -369,19 +377,22 @@ class Pix2PixHDModel_condImg(BaseModel):
         self.loss_G = loss_dict['G_GAN'] + loss_dict['G_GAN_Feat'] + loss_dict['G_VGG']
         return loss_dict
 
-    def _run_backward_G(self):
-        """loss_G.backward() with the shared fake-image D pass routed to the generator only."""
+    def _run_backward_G(self, last=False):
+        """loss_G.backward() with the shared fake-image D pass routed to the generator only.  ``last``: loss_D.backward()
+        has already run (the shared graph may be freed)."""
         shared = self._fake_gate is not None
         if shared:
             self._fake_gate['open'] = True
             ops.SKIP_WGRAD.update(self._d_weight_ids)
         try:
-            self.loss_G.backward(retain_graph=shared)
+            self.loss_G.backward(retain_graph=shared and not last)
         finally:
             ops.SKIP_WGRAD.difference_update(self._d_weight_ids)
 
-    def _run_backward_D(self):
-        """loss_D.backward() with the shared fake-image D pass routed to D's weights only."""
+    def _run_backward_D(self, first=False):
+        """loss_D.backward() with the shared fake-image D pass routed to D's weights only.  ``first``: loss_G.backward()
+        comes afterwards (keep the shared graph; the VGG stream is busy then, so D's weight gradients take the ordinary
+        weight-gradient stream, idle until the generator's backward starts)."""
         shared = self._fake_gate is not None
         if shared:
             self._fake_gate['open'] = False
@@ -393,8 +404,8 @@ class Pix2PixHDModel_condImg(BaseModel):
         wg = ops._vgg_stream(self.device)
         routes = {main: wg, ops._real_stream(self.device): wg}
         try:
-            with ops.route_wgrads(routes if _D_WGRAD_ROUTES else {}):
-                self.loss_D.backward()
+            with ops.route_wgrads(routes if (_D_WGRAD_ROUTES and not first) else {}):
+                self.loss_D.backward(retain_graph=shared and first)
         finally:
             ops.SKIP_DGRAD.difference_update(self._d_first_weight_ids)
         # the real branch's data-gradient chain reads D's weights on its own stream: D's Adam step comes after it
@@ -444,43 +455,80 @@ class Pix2PixHDModel_condImg(BaseModel):
         self.optimizer_G.zero_grad()
         if gan:
             self.optimizer_D.zero_grad()
-        if self.reducer_G is not None:
-            self.reducer_G.begin()
-        self._run_backward_G()
-        # G's exchange + Adam step (5 GB of HBM traffic, no matrix work) go to their own stream: they wait for G's
-        # data-gradient chain (main) and weight gradients (side stream), then run under D's backward
         main = torch.cuda.current_stream(self.device)
         opt_stream = ops._opt_stream(self.device)
-        opt_stream.wait_stream(main)
-        with torch.cuda.stream(opt_stream):
-            if self.reducer_G is not None:
-                self.reducer_G.finish()
-            self.optimizer_G.step()
-        if gan:
+        from ..dist import timed_wait
+        if gan and _D_FIRST:
+            # loss_D.backward() FIRST.  Its graph hangs off the discriminator passes only (the fake is detached / gated), so
+            # it can start as soon as those are enqueued: its data-gradient chains (main stream / real-image stream) and
+            # weight gradients (weight-gradient stream) then fill the window in which the main stream otherwise waits for
+            # VGG(fake) forward + backward, instead of forming a 12 ms tail behind the generator's backward (r03b trace).
+            # D's Adam waits for the generator's backward: loss_G still differentiates THROUGH D's current weights.
             if self.reducer_D is not None:
                 self.reducer_D.begin(contributions=2)
-            self._run_backward_D()
-        from ..dist import timed_wait
-        timed_wait(main, opt_stream, self.comm_timing['g_update_tail'] if self.comm_timing else None)
-        if gan:
-            if self.reducer_D is not None:
-                # D's exchange (34 MB over xGMI) + Adam step go to a stream of their own and are NOT waited for here:
-                # D's parameters are first needed by the next step's discriminator passes, so the exchange hides under the
-                # next encode_input + generator forward (forward() makes the consumers wait, see _wait_d_update)
-                d_stream = ops._d_opt_stream(self.device)
-                d_stream.wait_stream(main)
-                with torch.cuda.stream(d_stream):
+            self._run_backward_D(first=True)
+            if self.reducer_G is not None:
+                self.reducer_G.begin()
+            self._run_backward_G(last=True)
+            d_stream = ops._d_opt_stream(self.device)
+            d_stream.wait_stream(main)
+            with torch.cuda.stream(d_stream):
+                if self.reducer_D is not None:
                     self.reducer_D.finish()
-                    self.optimizer_D.step()
-                self._d_update_pending = True
-            else:
                 self.optimizer_D.step()
+            self._d_update_pending = True
+            # G's exchange + Adam + panel rebuild (5 GB of HBM traffic, no matrix work) on their own stream, NOT waited for
+            # here: the next step's input encoding and real-image branch do not touch G and run next to them; the next
+            # generator forward waits (forward()); anything else that reads parameters calls sync() first.
+            opt_stream.wait_stream(main)
+            with torch.cuda.stream(opt_stream):
+                if self.reducer_G is not None:
+                    self.reducer_G.finish()
+                self.optimizer_G.step()
+            self._g_update_pending = True
+        else:
+            if self.reducer_G is not None:
+                self.reducer_G.begin()
+            self._run_backward_G()
+            # G's exchange + Adam step go to their own stream: they wait for G's data-gradient chain (main) and weight
+            # gradients (side stream), then run under D's backward
+            opt_stream.wait_stream(main)
+            with torch.cuda.stream(opt_stream):
+                if self.reducer_G is not None:
+                    self.reducer_G.finish()
+                self.optimizer_G.step()
+            if gan:
+                if self.reducer_D is not None:
+                    self.reducer_D.begin(contributions=2)
+                self._run_backward_D()
+            timed_wait(main, opt_stream, self.comm_timing['g_update_tail'] if self.comm_timing else None)
+            if gan:
+                if self.reducer_D is not None:
+                    # D's exchange (34 MB over xGMI) + Adam step go to a stream of their own and are NOT waited for here:
+                    # D's parameters are first needed by the next step's discriminator passes, so the exchange hides under
+                    # the next encode_input + generator forward (forward() makes the consumers wait, see _wait_d_update)
+                    d_stream = ops._d_opt_stream(self.device)
+                    d_stream.wait_stream(main)
+                    with torch.cuda.stream(d_stream):
+                        self.reducer_D.finish()
+                        self.optimizer_D.step()
+                    self._d_update_pending = True
+                else:
+                    self.optimizer_D.step()
         self.generated = generated
         # both graphs have been consumed: drop them now (not at the next forward), so the previous step's G+D+VGG
         # activations are not resident while the next forward allocates its own
         self.loss_G = self.loss_D = None
         self._fake_gate = None
         return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in loss_dict.items()}
+
+    def _wait_g_update(self):
+        """Make the current stream wait for a generator update still running on the optimizer stream."""
+        if getattr(self, '_g_update_pending', False):
+            from ..dist import timed_wait
+            timed_wait(torch.cuda.current_stream(self.device), ops._opt_stream(self.device),
+                       self.comm_timing['g_update_tail'] if self.comm_timing else None)
+            self._g_update_pending = False
 
     def _wait_d_update(self, stream=None):
         """Make ``stream`` (default: the current one) wait for a discriminator update still running on its own stream."""
@@ -516,6 +564,8 @@ class Pix2PixHDModel_condImg(BaseModel):
         cur = torch.cuda.current_stream(self.device)
         ops.join_side_stream(self.device)
         cur.wait_stream(ops._opt_stream(self.device))
+        cur.wait_stream(ops._real_stream(self.device))
+        self._g_update_pending = False
         self._wait_d_update(cur)
         self._d_update_pending = False
 
@@ -530,6 +580,7 @@ class Pix2PixHDModel_condImg(BaseModel):
         self.delete_network('D', which_epoch, self.gpu_ids)
 
     def update_fixed_params(self):
+        self.sync()
         self.optimizer_G = FusedAdam(self.netG.parameters(), lr=self.opt.lr, betas=(self.opt.beta1, 0.999),
                                      arena=self.optimizer_G.arena)
         print('------------ Now also finetuning global generator -----------')
