@@ -258,7 +258,16 @@ def _post_step_state_errors(model, om, before):
 # formulas evaluated in float64 FROM THE HIP GRADIENT ITSELF and the adopted moments, so the comparison isolates the fused
 # Adam kernel (betas, bias corrections, lr, the arena walk, the side-stream join) from the gradient's own rounding: moments
 # 5e-6, update 1e-3 relative L2 per tensor.
-PARITY_K_TYPICAL, PARITY_K_EVENT, PARITY_FLOOR = 2.0, 10.0, 1e-5
+# WINOGRAD.  TYPICAL at K = 2 is asserted on the DIRECT-FORM build (him_set_winograd_min_channels(0): every convolution
+# as an implicit GEMM = 'the reference on another summation order'; measured <= 1.5 on every C1 tensor).  The shipped
+# build evaluates the 1024-channel ResnetBlocks and the VGG convolutions as Winograd F(2x2,3x3), whose fp32 rounding is a
+# few times the direct form's: the generated image is that much further from its float64 value, more decisions within
+# flipping distance of their threshold flip, and the tensors nearest to the image -- the generator's last layers and the
+# discriminator's FIRST layer, which reads the image -- show it in every step: measured lower-quartile ratios 2.6
+# (G head), 2.2 (last up-convolutions), 5.8 (D scale-0 layer 0: 5.8e-5 against the 1e-5 floor; every other D tensor
+# stays at the 3e-6 baseline).  That is the price of 2.25x fewer multiplies, two orders below the 5e-3 event level every
+# fp32 step carries anyway; the Winograd-on runs assert K_TYPICAL_WINOGRAD = 8 and record the ratios.
+PARITY_K_TYPICAL, PARITY_K_TYPICAL_WINOGRAD, PARITY_K_EVENT, PARITY_FLOOR = 2.0, 8.0, 10.0, 1e-5
 ADAM_TOL = dict(exp_avg=5e-6, exp_avg_sq=5e-6, delta=1e-3)
 
 
@@ -307,10 +316,11 @@ def _teacher_forced(tag, steps, loss_tol=2e-5, anchor=None, golden=None, batch_f
     if not winograd:     # every convolution in the direct form (him_set_winograd_min_channels(<= 0)); restored below
         prev_wino = ops.set_winograd_min_channels(0)
         try:
-            return _teacher_forced(tag, steps, loss_tol, anchor, golden, batch_fn, plumbing_tol, True, k_typical, out_tag)
+            return _teacher_forced(tag, steps, loss_tol, anchor, golden, batch_fn, plumbing_tol, True,
+                                   PARITY_K_TYPICAL if k_typical is None else k_typical, out_tag)
         finally:
             ops.set_winograd_min_channels(prev_wino)
-    k_typical = PARITY_K_TYPICAL if k_typical is None else k_typical
+    k_typical = PARITY_K_TYPICAL_WINOGRAD if k_typical is None else k_typical
     g = golden if golden is not None else load_golden(tag)
     flags = g['flags'] if isinstance(g['flags'], dict) else json.loads(str(g['flags']))
     B, H, W = int(g['B']), int(g['H']), int(g['W'])
@@ -415,7 +425,7 @@ def test_c1_teacher_forced_direct_form_gradient_parity():
 
 
 def test_tiny_global_teacher_forced_20_steps():
-    _teacher_forced('tiny_global', 20, anchor='tiny_global')
+    _teacher_forced('tiny_global', 20, anchor='tiny_global', k_typical=PARITY_K_TYPICAL)   # no Winograd layer in the toy nets
 
 
 def test_c2_teacher_forced_loss_and_gradient_parity():
@@ -425,7 +435,7 @@ def test_c2_teacher_forced_loss_and_gradient_parity():
 
 
 def test_tiny_twostream_teacher_forced_parity():
-    _teacher_forced('tiny_twostream', 6)
+    _teacher_forced('tiny_twostream', 6, k_typical=PARITY_K_TYPICAL)
 
 
 def test_local_enhancer_matches_reference():
