@@ -189,15 +189,25 @@ static int launch_gconv(const GConvP& p, hipStream_t st) {
     // the fast kernel gathers through a buffer resource: 31-bit byte offsets (larger tensors: split the batch)
     if ((unsigned long long)p.B * p.C2 * p.SH * p.SW * 4ull >= (1ull << 31))
       return fail(HIM_E_UNSUPPORTED, "conv: source tensor of %llu bytes >= 2 GiB", (unsigned long long)p.B * p.C2 * p.SH * p.SW * 4ull);
-    static int tile_override = -2;
-    if (tile_override == -2) tile_override = getenv("HIM_GCONV_TILE") ? atoi(getenv("HIM_GCONV_TILE")) : -1;
+    static int tile_all = -2, tile_wb = -1, tile_nb = -1;
+    if (tile_all == -2) {
+      tile_all = getenv("HIM_GCONV_TILE") ? atoi(getenv("HIM_GCONV_TILE")) : -1;
+      tile_wb = getenv("HIM_GCONV_TILE_WB") ? atoi(getenv("HIM_GCONV_TILE_WB")) : tile_all;   // batched Winograd GEMMs
+      tile_nb = getenv("HIM_GCONV_TILE_NB") ? atoi(getenv("HIM_GCONV_TILE_NB")) : tile_all;   // direct-form convs
+    }
+    const int tile_override = p.wbatch ? tile_wb : tile_nb;
     const int ks = p.ksplit > 1 ? p.ksplit : 1;
     if (p.M <= 64) {
       dim3 grid(cdiv(maxN, 128) * cdiv(p.M, 64), ks, p.nphase);
       launch_fast_cfg<2, 2, 1, 2>(p, grid, st);
     } else {
+      // Tile shape (override: HIM_GCONV_TILE / _WB batched Winograd GEMMs / _NB direct-form convs).  Alone, 128x128 tiles
+      // are the fastest (the batched GEMM of the ResnetBlocks: 0.321 ms vs 0.326 ms for 64x128, 0.358 ms for 64x64) --
+      // but the training step runs two to four streams, and the 64x128 workgroup (30 KB LDS, ~100 registers: 4-5 per CU
+      // instead of 3, twice as many of half the length) shares the CUs with the other streams' kernels better: round 3
+      // measured 60.7 ms per step against 61.9 (128x64: 61.0; 64x64: 63.2; `gpurun_out/r03h`).
       const long long tiles128 = (long long)cdiv(maxN, 128) * cdiv(p.M, 128) * p.nphase;
-      const bool big = tile_override >= 0 ? tile_override == 1 : (tiles128 >= 512 || (tiles128 >= 200 && tiles128 <= 256));
+      const bool big = tile_override == 1 || (tile_override == 6 && (tiles128 >= 512 || (tiles128 >= 200 && tiles128 <= 256)));
       const long long plane0 = (long long)p.ph[0].NA * p.ph[0].NC;
       const long long tiles256 = (maxN / 256) * cdiv(p.M, 128);
       if (tile_override == 3 && p.wbatch && ks == 1 && p.nphase == 1 && plane0 % 256 == 0 && tiles256 % 512 == 0) {
@@ -206,15 +216,21 @@ static int launch_gconv(const GConvP& p, hipStream_t st) {
         // it from sharing a CU with the other stream's kernels: the full step fell from 98 to 69 images/s.
         dim3 grid((unsigned)tiles256, 1, 1);
         launch_fast_cfg<2, 2, 2, 4>(p, grid, st);
+      } else if (tile_override == 5) {
+        dim3 grid(cdiv(maxN, 64) * cdiv(p.M, 64), ks, p.nphase);
+        launch_fast_cfg<2, 2, 1, 1>(p, grid, st);  // 64x64 tiles
       } else if (tile_override == 2) {
         dim3 grid(cdiv(maxN, 128) * cdiv(p.M, 128), ks, p.nphase);
         launch_fast_cfg<2, 4, 2, 1>(p, grid, st);  // 8 waves per 128x128 tile (measured: lockstep, no better than 4)
-      } else if (big || ks > 1) {
+      } else if (big || (tile_override == 6 && ks > 1)) {
         dim3 grid(cdiv(maxN, 128) * cdiv(p.M, 128), ks, p.nphase);
         launch_fast_cfg<2, 2, 2, 2>(p, grid, st);
-      } else {
+      } else if (tile_override == 0 || tile_override == 6) {
         dim3 grid(cdiv(maxN, 64) * cdiv(p.M, 128), ks, p.nphase);
         launch_fast_cfg<2, 2, 2, 1>(p, grid, st);
+      } else {   // default (and HIM_GCONV_TILE=4)
+        dim3 grid(cdiv(maxN, 128) * cdiv(p.M, 64), ks, p.nphase);
+        launch_fast_cfg<2, 2, 1, 2>(p, grid, st);
       }
     }
     int rcf = check_launch("gconv_fast");
@@ -775,7 +791,9 @@ static int fast_ksplit(int M, long long N, int nk) {
   static int off = -1;
   if (off < 0) off = getenv("HIM_NO_SPLITK") ? 1 : 0;
   if (off) return 1;
-  const long long tiles = (M <= 64 ? (long long)cdiv(N, 128) * cdiv(M, 64) : (long long)cdiv(N, 128) * cdiv(M, 128));
+  static int t64 = -1;   // experiment knob: count the 64x128 tiles the launch really uses
+  if (t64 < 0) t64 = getenv("HIM_KSPLIT_TILE64") ? 1 : 0;
+  const long long tiles = ((M <= 64 || t64) ? (long long)cdiv(N, 128) * cdiv(M, 64) : (long long)cdiv(N, 128) * cdiv(M, 128));
   if (tiles >= 1024) return 1;
   // makespan model in units of one full-K tile on one of 256 CUs: rounds/ks, a 7 % bonus once every CU hosts >= 2
   // independent workgroups (they cover each other's LDS/barrier bubbles), 2 % for the finish pass
