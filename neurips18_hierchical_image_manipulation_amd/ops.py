@@ -634,7 +634,10 @@ class _ResBlock(torch.autograd.Function):
         return (dx if ctx.needs_input_grad[0] else None), dws[0], None, dws[1], None, None
 
 
-_RESBLOCK_ON = os.environ.get('HIM_NO_RESBLOCK_FUSED') is None
+# Off by default since round 3's 64x128 conv tiles: inside the multi-stream step the layer-by-layer block is 0.4 ms
+# faster (59.6 vs 60.0 ms, three repetitions each, profiles/r03_tile_shape_ab.txt) although the fused unit launches
+# fewer kernels and moves fewer bytes; HIM_RESBLOCK_FUSED=1 turns it on, tests/test_ops_gpu.py keeps it pinned.
+_RESBLOCK_ON = os.environ.get('HIM_RESBLOCK_FUSED', '0') != '0'
 
 
 def resblock_supported(x, w1, w2):
