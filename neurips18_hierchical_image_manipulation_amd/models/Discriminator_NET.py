@@ -5,7 +5,8 @@ import os
 import torch
 import torch.nn as nn
 
-from ..nn import InstanceNorm2d, BatchNorm2d, LeakyReLU, FusedSequential, AvgPool3s2
+from .. import ops
+from ..nn import InstanceNorm2d, BatchNorm2d, LeakyReLU, FusedSequential, AvgPool3s2, _pw
 from .layer_util import weights_init
 
 
@@ -48,11 +49,33 @@ class MultiscaleDiscriminator(nn.Module):
     def _scale(self, i, x):
         feats, h = [], x
         for j in range(self.n_layers + 2):
-            h = getattr(self, 'scale%d_layer%d' % (self.num_D - 1 - i, j))(h)   # :51 index reversal
+            layer = getattr(self, 'scale%d_layer%d' % (self.num_D - 1 - i, j))   # :51 index reversal
+            if j == 0 and isinstance(h, tuple):
+                # (condition, image) kept apart (ops.CondImage): layer 0 is Conv2d + LeakyReLU
+                conv, act = layer[0], layer[1]
+                h = ops.cond_image_conv2d(h[0], h[1], conv.effective_weight(), _pw(conv.bias), conv.stride, conv.padding,
+                                          act.act, act.slope)
+            else:
+                h = layer(h)
             feats.append(h)
         return feats
 
+    def _forward_split(self, ci):
+        """``ops.CondImage`` input: the pooled condition comes from the per-step cache, only the image is pooled here."""
+        conds = ops.cond_pyramid(ci.cond, self.num_D)
+        result, img = [], ci.image
+        for i in range(self.num_D):
+            result.append(self._scale(i, (conds[i], img)))
+            if i != self.num_D - 1:
+                img = self.downsample(img)
+        return result
+
     def forward(self, input):
+        if isinstance(input, ops.CondImage):
+            if _SCALE_STREAMS and self.num_D > 1:
+                input = input.cat()
+            else:
+                return self._forward_split(input)
         if _SCALE_STREAMS and input.is_cuda and self.num_D > 1:
             return self._forward_streams(input)
         result, x = [], input

@@ -22,6 +22,11 @@ _D_WGRAD_ROUTES = os.environ.get('HIM_D_WGRAD_ROUTES', '1') != '0'
 _REAL_FIRST = os.environ.get('HIM_REAL_FIRST', '0') != '0'
 _D_FIRST = os.environ.get('HIM_D_BACKWARD_FIRST', '1') != '0'
 _VGG_STREAM = os.environ.get('HIM_VGG_STREAM', '1') != '0'
+_D_SPLIT_INPUT = os.environ.get('HIM_D_SPLIT_INPUT', '1') != '0'
+# A/B switch, off: VGG's backward started on its stream BEFORE loss_D.backward() instead of behind it (see
+# optimize_parameters) -- removes a 5.4 ms window in which only the VGG stream works, and costs 0.7 ms per step (60.2 vs
+# 59.5 ms, three repetitions): the fused-Winograd kernels use the chip well alone and slow D's backward when they share it.
+_VGG_BWD_EARLY = os.environ.get('HIM_VGG_BACKWARD_EARLY', '0') != '0'
 
 
 class ImagePool(object):
@@ -191,9 +196,17 @@ class Pix2PixHDModel_condImg(BaseModel):
         cond_image = ops.slice_channels(buf, n_label, n_cond)
         return input_label, inst_map, real_image, feat_map, cond_image
 
+    def _d_split(self):
+        """True when the discriminators get (condition, image) as an ``ops.CondImage`` pair instead of their concatenation:
+        no mask on the input, no image pool (it stores concatenated tensors), a condition at all."""
+        ctx_only = self.opt.netG == 'global_twostream' and self.opt.which_encoder == 'ctx'
+        return _D_SPLIT_INPUT and not ctx_only and not self.mask_gan_input and self.opt.pool_size == 0
+
     def _d_input(self, cond, image, mask):
         if self.opt.netG == 'global_twostream' and self.opt.which_encoder == 'ctx':
             return ops.mul_mask(image, mask) if self.mask_gan_input else image
+        if self._d_split():
+            return ops.CondImage(cond, image)       # condition and image kept apart (see ops.CondImage)
         return ops.cat_channels([cond, image], mask if self.mask_gan_input else None, 1)
 
     def discriminate(self, input_label, test_image, mask, use_pool=False):
@@ -233,7 +246,7 @@ class Pix2PixHDModel_condImg(BaseModel):
             out['loss_D_real'].record_stream(main)
         for t in (out['y_vgg'] or []):
             t.record_stream(main)
-        for t in (netD_cond, real_image, mask_cond):
+        for t in (netD_cond, real_image, mask_cond) + tuple(getattr(netD_cond, '_him_pyramid', ())):
             t.record_stream(side)
         return out
 
@@ -257,6 +270,9 @@ class Pix2PixHDModel_condImg(BaseModel):
         # one-tile-per-CU ResnetBlock launches leave it idle.
         # The generator forward is enqueued FIRST: the host needs ~2.5 ms to issue the ~80 launches of the real branch,
         # and the main stream would sit idle for that long at the start of every step (r02 trace) if they went first.
+        if self._d_split():
+            # the pooled condition of the PatchGAN scales: once per step, before the streams fork (every pass reads it)
+            ops.cond_pyramid(netD_cond, opt.num_D)
         inputs_ready = torch.cuda.Event()
         inputs_ready.record(torch.cuda.current_stream(self.device))
         if getattr(self, '_g_update_pending', False):
@@ -332,6 +348,11 @@ class Pix2PixHDModel_condImg(BaseModel):
         if vgg_side is not None:
             torch.cuda.current_stream(self.device).wait_stream(ops._vgg_stream(self.device))
             loss_G_VGG = vgg_side * opt.lambda_feat
+            if getattr(self, '_vgg_bwd_early', False):
+                # optimize_parameters() differentiates this term on its own, from ``vgg_side`` on the VGG stream and BEFORE
+                # loss_D.backward() (see there): the value stays in loss_G, the graph does not
+                self._vgg_early = (vgg_side, fake_image)
+                loss_G_VGG = loss_G_VGG.detach()
         elif not opt.no_vgg_loss:
             loss_G_VGG = self.criterionVGG(fake_image, real_image,
                                            ahead['y_vgg'] if ahead is not None else None) * opt.lambda_feat
@@ -377,15 +398,20 @@ class Pix2PixHDModel_condImg(BaseModel):
         self.loss_G = loss_dict['G_GAN'] + loss_dict['G_GAN_Feat'] + loss_dict['G_VGG']
         return loss_dict
 
-    def _run_backward_G(self, last=False):
+    def _run_backward_G(self, last=False, extra_root=None):
         """loss_G.backward() with the shared fake-image D pass routed to the generator only.  ``last``: loss_D.backward()
-        has already run (the shared graph may be freed)."""
+        has already run (the shared graph may be freed).  ``extra_root``: (fake_image, gradient) of a loss term that was
+        differentiated down to the fake image beforehand."""
         shared = self._fake_gate is not None
         if shared:
             self._fake_gate['open'] = True
             ops.SKIP_WGRAD.update(self._d_weight_ids)
         try:
-            self.loss_G.backward(retain_graph=shared and not last)
+            if extra_root is not None:
+                torch.autograd.backward([self.loss_G, extra_root[0]], [None, extra_root[1]],
+                                        retain_graph=shared and not last)
+            else:
+                self.loss_G.backward(retain_graph=shared and not last)
         finally:
             ops.SKIP_WGRAD.difference_update(self._d_weight_ids)
 
@@ -442,10 +468,13 @@ class Pix2PixHDModel_condImg(BaseModel):
         if 'obj_mask' in data:
             kw['obj_mask'] = data['obj_mask']
         self._share_fake_pass = os.environ.get('HIM_SHARE_FAKE_PASS', '1') != '0'
+        self._vgg_bwd_early = _VGG_BWD_EARLY and _D_FIRST and not self.opt.no_gan
+        self._vgg_early = None
         try:
             losses, generated = self.forward(**kw)
         finally:
             self._share_fake_pass = False
+            self._vgg_bwd_early = False
         loss_dict = self.combine_losses(losses)
         # Same arithmetic as backward_G(); backward_D(), reordered: both arenas are zeroed first, the generator's Adam
         # step (and its all-reduce) is deferred behind loss_D.backward() -- legal because loss_D's graph holds no
@@ -464,12 +493,30 @@ class Pix2PixHDModel_condImg(BaseModel):
             # weight gradients (weight-gradient stream) then fill the window in which the main stream otherwise waits for
             # VGG(fake) forward + backward, instead of forming a 12 ms tail behind the generator's backward (r03b trace).
             # D's Adam waits for the generator's backward: loss_G still differentiates THROUGH D's current weights.
+            # (HIM_VGG_BACKWARD_EARLY=1, measured slower) The VGG term of loss_G first, down to the fake image and no
+            # further: its backward lives on the VGG stream (autograd replays a node on the stream of its forward) but, as
+            # part of loss_G.backward(), can only start once the MAIN stream has worked through loss_D's backward and reached
+            # loss_G's root -- the r03 trace shows the fused-Winograd kernels of VGG's backward running alone for 5.4 ms with
+            # the main stream idle behind them.  Started here it runs next to loss_D.backward(); the generator's backward
+            # then starts from d(GAN + feature matching)/d(fake) + this gradient.
+            early = None
+            if self._vgg_early is not None:
+                vgg_side, fake_image = self._vgg_early
+                self._vgg_early = None
+                vs = ops._vgg_stream(self.device)
+                with torch.cuda.stream(vs):
+                    seed = torch.full_like(vgg_side, float(self.opt.lambda_feat))
+                    (g_vgg,) = torch.autograd.grad(vgg_side, fake_image, grad_outputs=seed)
+                g_vgg.record_stream(main)
+                early = (fake_image, g_vgg)
             if self.reducer_D is not None:
                 self.reducer_D.begin(contributions=2)
             self._run_backward_D(first=True)
             if self.reducer_G is not None:
                 self.reducer_G.begin()
-            self._run_backward_G(last=True)
+            if early is not None:
+                main.wait_stream(ops._vgg_stream(self.device))
+            self._run_backward_G(last=True, extra_root=early)
             d_stream = ops._d_opt_stream(self.device)
             d_stream.wait_stream(main)
             with torch.cuda.stream(d_stream):

@@ -492,6 +492,109 @@ def conv2d(x, w, b=None, stride=1, pad=0, pad_mode='zero', act='none', slope=0.2
                          float(slope), bool(grad_premasked), bool(gate_dx))
 
 
+class CondImage(object):
+    """Discriminator input handed over in two parts: ``cond`` (B,Cc,H,W: data, never differentiated -- one-hot labels,
+    edges, the conditioning image) and ``image`` (B,Ci,H,W: the real / generated picture).  The reference concatenates
+    them (pix2pixHD_condImg_model.py:176-182) and pools the 41-channel tensor per scale; kept apart, the pooled condition
+    is computed once per step for all passes (``cond_pyramid``), and the gradient of the first PatchGAN conv comes back as
+    Ci channels instead of a zero-filled (Cc+Ci)-channel tensor that the pooling / cat backward would walk again."""
+
+    def __init__(self, cond, image):
+        self.cond, self.image = cond, image
+
+    def cat(self):
+        return cat_channels([self.cond, self.image])
+
+
+def cond_pyramid(cond, levels):
+    """[cond, pool(cond), pool(pool(cond)), ...] (AvgPool2d(3, 2, 1, count_include_pad=False)), cached on the tensor."""
+    pyr = getattr(cond, '_him_pyramid', None)
+    if pyr is None or len(pyr) < levels:
+        with torch.no_grad():
+            pyr = [cond.detach()]
+            while len(pyr) < levels:
+                pyr.append(avgpool3s2(pyr[-1]))
+        cond._him_pyramid = pyr
+    return pyr
+
+
+class _CondImageConv2d(torch.autograd.Function):
+    """act(conv2d([cond | image], w) + b), zero padding; gradient to ``image`` (and the parameters) only."""
+
+    @staticmethod
+    def forward(ctx, cond, image, w, b, stride, pad, act, slope):
+        ctx.set_materialize_grads(False)
+        cond, image = cond.contiguous(), image.contiguous()
+        _chk(cond, image, w, b)
+        B, Cc, H, W = cond.shape
+        Ci = image.shape[1]
+        if image.shape[0] != B or tuple(image.shape[2:]) != (H, W):
+            raise HimError('cond/image conv: shapes %s and %s do not stack' % (tuple(cond.shape), tuple(image.shape)))
+        st = _stream()
+        x = torch.empty((B, Cc + Ci, H, W), dtype=torch.float32, device=cond.device)
+        lib.him_copy_channels(_p(cond), Cc, 0, _p(x), Cc + Ci, 0, Cc, B, H * W, 0, 0, 0, st)
+        lib.him_copy_channels(_p(image), Ci, 0, _p(x), Cc + Ci, Cc, Ci, B, H * W, 0, 0, 0, st)
+        d = _conv_desc(x, w, stride, pad, PAD_ZERO, act, slope)
+        y = torch.empty((d.B, d.Cout, d.OH, d.OW), dtype=torch.float32, device=x.device)
+        nb = lib.him_conv2d_fwd_ws(ctypes.byref(d))
+        ws = _ws(nb, x)
+        pan = _panel(w, d, PANEL_FWD, False)
+        if pan:
+            lib.him_conv2d_fwd_panel(ctypes.byref(d), _p(x), pan, _p(b), _p(y), _p(ws), nb, st)
+        else:
+            lib.him_conv2d_fwd(ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), _p(ws), nb, st)
+        ctx.d, ctx.Cc, ctx.Ci = d, Cc, Ci
+        ctx.x, ctx.w, ctx.b = x, w, b
+        ctx.save_for_backward(y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if dy is None:
+            return (None,) * 8
+        d, x, w, b, Cc, Ci = ctx.d, ctx.x, ctx.w, ctx.b, ctx.Cc, ctx.Ci
+        dy = dy.contiguous()
+        st = _stream()
+        if d.act != ACT_NONE:
+            dz = torch.empty_like(dy)
+            lib.him_act_bwd(_p(ctx.saved_tensors[0]), _p(dy), _p(dz), dy.numel(), d.act, d.slope, st)
+        else:
+            dz = dy
+        dimg = dw = db = None
+        if ctx.needs_input_grad[1] and _wkey(w) not in SKIP_DGRAD:
+            d2 = HimConv2d.from_buffer_copy(d)
+            d2.Cin = Ci
+            dimg = torch.empty((d.B, Ci, d.H, d.W), dtype=torch.float32, device=x.device)
+            wsl = w.detach()[:, Cc:].contiguous()
+            nb = lib.him_conv2d_bwd_data_ws(ctypes.byref(d2))
+            ws = _ws(nb, x)
+            lib.him_conv2d_bwd_data(ctypes.byref(d2), _p(dz), _p(wsl), _p(dimg), _p(ws), nb, st)
+        skip_w = _wkey(w) in SKIP_WGRAD
+        need_w = ctx.needs_input_grad[2] and not skip_w
+        need_b = b is not None and ctx.needs_input_grad[3] and not skip_w
+        if need_w or need_b:
+            nb = lib.him_conv2d_bwd_weight_ws(ctypes.byref(d))
+            if need_w and _direct(w) and (not need_b or _direct(b)):
+                with _wgrad_stream(x, dz):
+                    ws = _ws(nb, x)
+                    lib.him_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dz), _p(w.grad),
+                                              _p(b.grad) if need_b else 0, 1, _p(ws), nb, _stream())
+                    _notify(w)
+                    if need_b:
+                        _notify(b)
+            else:
+                ws = _ws(nb, x)
+                dw = torch.empty_like(w) if need_w else None
+                db = torch.empty_like(b) if need_b else None
+                lib.him_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dz), _p(dw), _p(db), 0, _p(ws), nb, st)
+        return None, dimg, dw, db, None, None, None, None
+
+
+def cond_image_conv2d(cond, image, w, b=None, stride=1, pad=0, act='none', slope=0.2):
+    """The first PatchGAN convolution on a ``CondImage`` pair (see there)."""
+    return _CondImageConv2d.apply(cond, image, w, b, stride, pad, ACTS[act], float(slope))
+
+
 class _Deconv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, pad, out_pad, act, slope):
