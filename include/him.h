@@ -215,6 +215,11 @@ int him_resblock_bwd_weight(const HimResBlock* d, int which, const float* src, c
 #define HIM_PANEL_FWD 0
 #define HIM_PANEL_BWD_DATA 1
 size_t him_conv2d_panel_bytes(const HimConv2d* d, int kind);
+/* 1 when the data gradient of `d` reads the SAME panel as its forward (the separate-transform Winograd layers: the batched
+ * GEMM reads the forward panel transposed with mirrored transform positions) -- a trainer then keeps one panel per weight:
+ * HIM_PANEL_FWD serves him_conv2d_bwd_data_panel / him_resblock_bwd_data as well (a HIM_PANEL_BWD_DATA panel built for
+ * such a layer has the same content). */
+int him_conv2d_bwd_data_shares_fwd_panel(const HimConv2d* d);
 int him_conv2d_panel_build(const HimConv2d* d, int kind, const float* w, void* panel, size_t panel_bytes,
                            void* stream);
 int him_conv2d_fwd_panel(const HimConv2d* d, const float* x, const void* panel, const float* bias, float* y,

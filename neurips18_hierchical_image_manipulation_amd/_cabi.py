@@ -57,6 +57,7 @@ _SIGS = {
     'him_conv2d_onehot_bwd_weight': (c_int, [_CONV, P, c_int, P, P, P, P, c_int, P, c_size_t, P]),
     'him_winograd_gemm': (c_int, [P, P, P, c_int, c_int, c_int, P]),
     'him_conv2d_panel_bytes': (c_size_t, [_CONV, c_int]),
+    'him_conv2d_bwd_data_shares_fwd_panel': (C.c_uint, [_CONV]),
     'him_conv2d_panel_build': (c_int, [_CONV, c_int, P, P, c_size_t, P]),
     'him_conv2d_fwd_panel': (c_int, [_CONV, P, P, P, P, P, c_size_t, P]),
     'him_conv2d_bwd_data_panel': (c_int, [_CONV, P, P, P, P, c_size_t, P]),

@@ -195,7 +195,7 @@ static int launch_gconv(const GConvP& p, hipStream_t st) {
       tile_wb = getenv("HIM_GCONV_TILE_WB") ? atoi(getenv("HIM_GCONV_TILE_WB")) : tile_all;   // batched Winograd GEMMs
       tile_nb = getenv("HIM_GCONV_TILE_NB") ? atoi(getenv("HIM_GCONV_TILE_NB")) : tile_all;   // direct-form convs
     }
-    const int tile_override = p.wbatch ? tile_wb : tile_nb;
+    const int tile_override = p.atrans ? 4 : (p.wbatch ? tile_wb : tile_nb);   // transposed weight tiles: 64x128 only
     const int ks = p.ksplit > 1 ? p.ksplit : 1;
     if (p.M <= 64) {   // (64x64 tiles here: no change of the step, round 3)
       dim3 grid(cdiv(maxN, 128) * cdiv(p.M, 64), ks, p.nphase);
@@ -429,9 +429,13 @@ static size_t wino_wgrad_floats(int B, int M, int C, int OH, int OW) {
 }
 // Cm[z][m][n] = sum_k A[z][m][k] * Bm[z][k][n] for the 16 transform positions z, on the fast MFMA conv kernel: a 1x1
 // convolution over 16 "images" [K][1][N] with per-image weight panels.  K % 16 == 0, N % 128 == 0.
-static int wino_batched_gemm(const float* A, const float* Bm, float* Cm, int M, int K, int N, hipStream_t st) {
+// atrans: A is a FORWARD panel U[z][K][M] of the layer whose data gradient this is; the kernel reads it transposed with
+// the positions mirrored (GConvP::atrans) -- no second, flipped panel per weight.
+static int wino_batched_gemm(const float* A, const float* Bm, float* Cm, int M, int K, int N, hipStream_t st,
+                             bool atrans = false) {
   GConvP g;
   memset(&g, 0, sizeof(g));
+  g.atrans = atrans ? 1 : 0;
   g.src = Bm;
   g.dst = Cm;
   g.M = M;
@@ -462,7 +466,7 @@ static int wino_batched_gemm(const float* A, const float* Bm, float* Cm, int M, 
 // dst[B][Mout][OH][OW] = act(winograd-conv(src[B][Csrc][H][W], U) + bias); ws holds V and Mo
 static int run_wino_conv(int B, int Csrc, int H, int W, int Mout, int OH, int OW, int po, bool reflect,
                          const float* src, const float* U, const float* bias, int act, float slope, float* dst,
-                         float* ws, hipStream_t st, bool fold = false) {
+                         float* ws, hipStream_t st, bool fold = false, bool atrans = false) {
   WinoGeom gi = wino_geom(B, Csrc, H, W, OH, OW, po);
   gi.fold = fold ? 1 : 0;
   float* V = ws;
@@ -472,7 +476,7 @@ static int run_wino_conv(int B, int Csrc, int H, int W, int Mout, int OH, int OW
   else hipLaunchKernelGGL((wino_input_kernel<false>), gin, dim3(256), 0, st, src, V, gi);
   int rc = check_launch("wino_input");
   if (rc) return rc;
-  rc = wino_batched_gemm(U, V, Mo, Mout, Csrc, gi.Tp, st);
+  rc = wino_batched_gemm(U, V, Mo, Mout, Csrc, gi.Tp, st, atrans);
   if (rc) return rc;
   WinoGeom go = gi;
   go.C = Mout;
@@ -1010,9 +1014,9 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
     return fail(HIM_E_UNSUPPORTED, "dgrad: Winograd panel with a fused bias/activation epilogue");
   if (wino_dgrad_ok(d) && (build_only || (!bias && act == HIM_ACT_NONE))) {
     float* U = (float*)ws;
-    if (!panel) {
-      hipLaunchKernelGGL((wino_weight_kernel<1>), dim3(cdiv(d->Cout, 256), d->Cin), dim3(256), 0, st, w, U, d->Cin,
-                         d->Cout);
+    if (!panel) {   // the FORWARD panel: the batched GEMM below reads it transposed (no flipped panel, round 3)
+      hipLaunchKernelGGL((wino_weight_kernel<0>), dim3(cdiv(d->Cin, 256), d->Cout), dim3(256), 0, st, w, U, d->Cout,
+                         d->Cin);
       int rcu = check_launch("wino_weight");
       if (rcu || build_only) return rcu;
     }
@@ -1023,7 +1027,7 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
     float* dpadw = wsv + wino_conv_floats(d->B, d->Cout, d->Cin, GH, GW);
     // reflect: full correlation (offset 2) -> padded gradient -> fold; zero pad: the plain pad-1 correlation
     int rcw = run_wino_conv(d->B, d->Cout, d->OH, d->OW, d->Cin, GH, GW, rf ? 2 : 1, false, gy, panel ? panel : U,
-                            nullptr, HIM_ACT_NONE, 0.f, rf ? dpadw : out, wsv, st, fold);
+                            nullptr, HIM_ACT_NONE, 0.f, rf ? dpadw : out, wsv, st, fold, true);
     if (rcw || !rf) return rcw;
     hipLaunchKernelGGL(reflect_fold_kernel, dim3(cdiv((long long)d->H * d->W, 256), d->B * d->Cin), dim3(256), 0, st,
                        (const float*)dpadw, out, d->B * d->Cin, d->H, d->W, 1, 1, (size_t)0);
@@ -1209,6 +1213,11 @@ int him_conv2d_bwd_data(const HimConv2d* d, const float* dy, const float* w, flo
 size_t him_conv2d_panel_bytes(const HimConv2d* d, int kind) {
   if (!d || check_conv(d)) return 0;
   return (kind == HIM_PANEL_FWD ? fprop_panel_floats(d) : dgrad_panel_floats(d)) * sizeof(float);
+}
+
+int him_conv2d_bwd_data_shares_fwd_panel(const HimConv2d* d) {
+  if (!d || check_conv(d)) return 0;
+  return (!wino_fused_dgrad_ok(d) && wino_dgrad_ok(d) && !wino_fused_fwd_ok(d) && wino_fwd_ok(d)) ? 1 : 0;
 }
 
 int him_conv2d_panel_build(const HimConv2d* d, int kind, const float* w, void* panel, size_t panel_bytes,

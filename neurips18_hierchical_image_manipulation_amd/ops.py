@@ -267,6 +267,8 @@ def _panel(w, d, kind, is_deconv):
     """Device pointer of the cached panel of parameter ``w`` for descriptor ``d`` (0: use the plain entry point)."""
     if not _PANELS_ON or not isinstance(w, torch.nn.Parameter):
         return 0
+    if kind == PANEL_BWD_DATA and not is_deconv and lib.him_conv2d_bwd_data_shares_fwd_panel(ctypes.byref(d)):
+        kind = PANEL_FWD        # separate-transform Winograd layers: ONE panel per weight serves both directions
     cache = w.__dict__.get('_him_panels')
     if cache is None:
         cache = w.__dict__['_him_panels'] = {}

@@ -10,7 +10,7 @@ import sqlite3
 import sys
 
 PEAK, FLOP = 157.3, 2.0 * 16 * 1024 ** 3
-KERNEL, GRID = 'gconv_fast_kernel<2, 2, 1, 2, 0, false>', 2048
+KERNEL, GRID = 'gconv_fast_kernel<2, 2, 1, 2, 0, false>', 2048     # + the <.., 3, false> form of the data gradients (transposed panel)
 
 
 def durations(path, need_adam):
@@ -22,7 +22,8 @@ def durations(path, need_adam):
         adam = [r[2] for r in rows if 'adam_kernel' in r[0]]
         lo, hi = adam[len(adam) // 3], adam[-1]
         rows = [r for r in rows if r[1] >= lo and r[2] <= hi]
-    sel = [r[2] - r[1] for r in rows if KERNEL in r[0] and r[3] // max(r[6], 1) == GRID and r[4] == 1 and r[5] == 1]
+    sel = [r[2] - r[1] for r in rows if (KERNEL in r[0] or KERNEL.replace('0, false', '3, false') in r[0])
+           and r[3] // max(r[6], 1) == GRID and r[4] == 1 and r[5] == 1]
     return sel
 
 
