@@ -310,6 +310,14 @@ int him_l1_mean_fwd(const float* a, const float* b, size_t n, float* out, void* 
  * backward is folded into this pass) */
 int him_l1_mean_bwd(const float* a, const float* b, size_t n, const float* g, float* da, int accumulate,
                     void* stream);
+/* Several L1 terms at once (feature matching: 12 pairs, VGG: 5): out[i] = mean|a[i] - b[i]|, da[i] = g[i] * d/da[i]
+ * (NULL da[i]: skipped).  a / b / n / da are HOST arrays of npairs entries; out and g are device vectors.  Work split and
+ * summation order per pair are those of him_l1_mean_fwd / _bwd (bit-identical results), three launches per 16 pairs. */
+size_t him_l1_multi_ws(int npairs);
+int him_l1_multi_fwd(const float* const* a, const float* const* b, const size_t* n, int npairs, float* out, void* ws,
+                     size_t ws_bytes, void* stream);
+int him_l1_multi_bwd(const float* const* a, const float* const* b, const size_t* n, int npairs, const float* g,
+                     float* const* da, int accumulate, void* stream);
 int him_mse_const_fwd(const float* x, size_t n, float target, float* out, void* ws, size_t ws_bytes,
                       void* stream);
 int him_mse_const_bwd(const float* x, size_t n, float target, const float* g, float* dx, int accumulate,

@@ -108,6 +108,9 @@ _SIGS = {
     'him_reduce_ws': (c_size_t, [c_size_t]),
     'him_l1_mean_fwd': (c_int, [P, P, c_size_t, P, P, c_size_t, P]),
     'him_l1_mean_bwd': (c_int, [P, P, c_size_t, P, P, c_int, P]),
+    'him_l1_multi_ws': (c_size_t, [c_int]),
+    'him_l1_multi_fwd': (c_int, [P, P, P, c_int, P, P, c_size_t, P]),
+    'him_l1_multi_bwd': (c_int, [P, P, P, c_int, P, P, c_int, P]),
     'him_mse_const_fwd': (c_int, [P, c_size_t, c_float, P, P, c_size_t, P]),
     'him_mse_const_bwd': (c_int, [P, c_size_t, c_float, P, P, c_int, P]),
     'him_resblock_supported': (C.c_uint, [_RESB]),

@@ -1370,13 +1370,17 @@ class _L1WeightedSum(torch.autograd.Function):
         b_s = [t.contiguous() for t in tensors[n:]]
         vals = torch.empty(n, dtype=torch.float32, device=wvec.device)
         st = _stream()
-        for i, (a, b) in enumerate(zip(a_s, b_s)):
+        for a, b in zip(a_s, b_s):
             _chk(a, b)
             if a.shape != b.shape:
                 raise HimError('l1: shape mismatch %s vs %s' % (tuple(a.shape), tuple(b.shape)))
-            nb = lib.him_reduce_ws(a.numel())
-            ws = _ws(nb, a)
-            lib.him_l1_mean_fwd(_p(a), _p(b), a.numel(), vals.data_ptr() + 4 * i, _p(ws), nb, st)
+        # all pairs in one reduction launch + one finishing launch (per-pair sums as in him_l1_mean_fwd, bit for bit)
+        ctx.pa = (ctypes.c_void_p * n)(*[_p(a) for a in a_s])
+        ctx.pb = (ctypes.c_void_p * n)(*[_p(b) for b in b_s])
+        ctx.pn = (ctypes.c_size_t * n)(*[a.numel() for a in a_s])
+        nb = lib.him_l1_multi_ws(n)
+        ws = _ws(nb, a_s[0])
+        lib.him_l1_multi_fwd(ctx.pa, ctx.pb, ctx.pn, n, _p(vals), _p(ws), nb, st)
         ctx.a_s, ctx.b_s, ctx.wvec = a_s, b_s, wvec
         return (vals * wvec).sum()
 
@@ -1386,14 +1390,10 @@ class _L1WeightedSum(torch.autograd.Function):
             return (None,) * (2 + 2 * len(ctx.a_s))
         gw = (g * ctx.wvec).contiguous()
         st = _stream()
-        grads = []
-        for i, (a, b) in enumerate(zip(ctx.a_s, ctx.b_s)):
-            if ctx.needs_input_grad[2 + i]:
-                da = torch.empty_like(a)
-                lib.him_l1_mean_bwd(_p(a), _p(b), a.numel(), gw.data_ptr() + 4 * i, _p(da), 2 if ctx.gate else 0, st)
-                grads.append(da)
-            else:
-                grads.append(None)
+        grads = [torch.empty_like(a) if ctx.needs_input_grad[2 + i] else None for i, a in enumerate(ctx.a_s)]
+        n = len(grads)
+        pda = (ctypes.c_void_p * n)(*[_p(da) for da in grads])
+        lib.him_l1_multi_bwd(ctx.pa, ctx.pb, ctx.pn, n, _p(gw), pda, 2 if ctx.gate else 0, st)
         return (None, None) + tuple(grads) + (None,) * len(ctx.b_s)
 
 

@@ -622,3 +622,47 @@ def test_cond_image_pair_matches_concatenated_discriminator_input():
         assert (a is None) == (b is None)       # biases in front of an InstanceNorm carry no gradient on either path
         if a is not None:
             assert_close('grad ' + name, a, b, rtol=1e-6)
+
+
+def test_multi_pair_l1_is_bit_identical_to_the_single_pair_kernels():
+    """him_l1_multi_fwd / _bwd (all feature-matching / VGG terms of reference models/losses.py:47-60 and
+    pix2pixHD_condImg_model.py:235-242 in three launches) against him_l1_mean_fwd / _bwd pair by pair: same work split
+    and summation order -> torch.equal; 18 pairs (two chunks of the 16-slot launch table), ragged and unaligned sizes,
+    one pair without a gradient."""
+    import ctypes
+    from neurips18_hierchical_image_manipulation_amd._cabi import lib
+    sizes = [1, 3, 4, 1000, 1023, 4096, 65537, 1 << 20, (1 << 20) + 4, 777, 12, 256, 257, 8192 * 256 + 5, 5, 64, 100000, 31]
+    a = [_rand(n, seed=2 * i).to(DEV) for i, n in enumerate(sizes)]
+    b = [_rand(n, seed=2 * i + 1).to(DEV) for i, n in enumerate(sizes)]
+    a[3] = a[3].relu()                       # exact zeros: sign(0) = 0 and the ReLU gate
+    b[3] = a[3].clone()
+    n = len(sizes)
+    st = torch.cuda.current_stream().cuda_stream
+    ws1 = torch.empty(lib.him_reduce_ws(1) // 4, device=DEV)
+    single = torch.empty(n, device=DEV)
+    for i in range(n):
+        lib.him_l1_mean_fwd(a[i].data_ptr(), b[i].data_ptr(), sizes[i], single.data_ptr() + 4 * i, ws1.data_ptr(),
+                            ws1.numel() * 4, st)
+    pa = (ctypes.c_void_p * n)(*[t.data_ptr() for t in a])
+    pb = (ctypes.c_void_p * n)(*[t.data_ptr() for t in b])
+    pn = (ctypes.c_size_t * n)(*sizes)
+    wsm = torch.empty(lib.him_l1_multi_ws(n) // 4, device=DEV)
+    multi = torch.empty(n, device=DEV)
+    lib.him_l1_multi_fwd(pa, pb, pn, n, multi.data_ptr(), wsm.data_ptr(), wsm.numel() * 4, st)
+    assert torch.equal(single, multi)
+    ref = torch.stack([(x.double() - y.double()).abs().mean() for x, y in zip(a, b)]).float()
+    assert_close('multi l1 vs float64', multi, ref, rtol=1e-5)
+    g = _rand(n, seed=99).to(DEV)
+    for gate in (0, 2):
+        d1 = [torch.empty_like(t) for t in a]
+        d2 = [torch.full_like(t, float('nan')) for t in a]
+        for i in range(n):
+            lib.him_l1_mean_bwd(a[i].data_ptr(), b[i].data_ptr(), sizes[i], g.data_ptr() + 4 * i, d1[i].data_ptr(), gate, st)
+        pd = (ctypes.c_void_p * n)(*[0 if i == 7 else t.data_ptr() for i, t in enumerate(d2)])
+        lib.him_l1_multi_bwd(pa, pb, pn, n, g.data_ptr(), pd, gate, st)
+        torch.cuda.synchronize()
+        for i in range(n):
+            if i == 7:
+                assert torch.isnan(d2[i]).all()      # no gradient tensor: untouched
+            else:
+                assert torch.equal(d1[i], d2[i]), i
