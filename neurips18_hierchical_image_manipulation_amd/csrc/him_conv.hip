@@ -805,10 +805,11 @@ static int fast_ksplit(int M, long long N, int nk) {
   double best_cost = 1e30;
   const int cand[] = {1, 2, 3, 4, 6, 8, 12, 16};
   // The model is that of a launch ALONE on the chip; inside the multi-stream step the other streams' kernels fill the CUs
-  // a few-tile launch leaves idle, and deep splits only add slab traffic and a longer finish pass: capped at 4 (round 3:
-  // 58.5 vs 58.9 ms per step uncapped; caps of 3 / 6 / 8 within noise of 4, 2: 58.7; profiles/r03_tile_shape_ab.txt).
+  // a few-tile launch leaves idle, and deep splits only add slab traffic and a longer finish pass: capped at 8 (round 3:
+  // 58.5-58.6 vs 58.9 ms per step uncapped; caps of 3 / 4 / 6 within noise of 8, 2: 58.7; profiles/r03_tile_shape_ab.txt;
+  // 8 rather than 4 because it leaves every launch of the C1 parity configuration on the split it was validated with).
   static int kmax = -1;
-  if (kmax < 0) kmax = getenv("HIM_KSPLIT_MAX") ? atoi(getenv("HIM_KSPLIT_MAX")) : 4;
+  if (kmax < 0) kmax = getenv("HIM_KSPLIT_MAX") ? atoi(getenv("HIM_KSPLIT_MAX")) : 8;
   for (int ks : cand) {
     if (ks > kmax) break;
     if (ks > 1 && nk / ks < 32) break;  // keep >= 32 K-steps per workgroup
