@@ -416,6 +416,17 @@ static bool wino_shape_ok(int Cout, int Cin, int KH, int KW, int stride, int pad
   return mc > 0 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin >= mc && Cout >= mc && (Cin % 16) == 0 &&
          (Cout % 16) == 0 && H >= 2 && W >= 2 && use_fast(Cout, Cin);
 }
+// Threads per workgroup of the Winograd transform kernels (one tile / channel per thread).  64 = one wave: inside the
+// multi-stream step the single-wave workgroups find a free slot next to the MFMA kernels sooner (58.5 vs 58.8 ms per step
+// for the input / output transforms alone, 128: 58.65; results are bit-identical); HIM_WINO_TBLOCK overrides.
+static int wino_tblock() {
+  static int tb = -1;
+  if (tb < 0) {
+    tb = getenv("HIM_WINO_TBLOCK") ? atoi(getenv("HIM_WINO_TBLOCK")) : 64;
+    if (tb != 64 && tb != 128 && tb != 256) tb = 64;
+  }
+  return tb;
+}
 static bool wino_wgrad_ok(int M, int C, int KH, int KW, int stride, int pad, int H, int W) {
   return wino_shape_ok(M, C, KH, KW, stride, pad, H, W) && (M % 128) == 0 && (C % 128) == 0;
 }
@@ -471,16 +482,17 @@ static int run_wino_conv(int B, int Csrc, int H, int W, int Mout, int OH, int OW
   gi.fold = fold ? 1 : 0;
   float* V = ws;
   float* Mo = V + (size_t)16 * Csrc * gi.Tp;
-  const dim3 gin(cdiv(gi.Tp, 256), Csrc);
-  if (reflect) hipLaunchKernelGGL((wino_input_kernel<true>), gin, dim3(256), 0, st, src, V, gi);
-  else hipLaunchKernelGGL((wino_input_kernel<false>), gin, dim3(256), 0, st, src, V, gi);
+  const int tb = wino_tblock();
+  const dim3 gin(cdiv(gi.Tp, tb), Csrc);
+  if (reflect) hipLaunchKernelGGL((wino_input_kernel<true>), gin, dim3(tb), 0, st, src, V, gi);
+  else hipLaunchKernelGGL((wino_input_kernel<false>), gin, dim3(tb), 0, st, src, V, gi);
   int rc = check_launch("wino_input");
   if (rc) return rc;
   rc = wino_batched_gemm(U, V, Mo, Mout, Csrc, gi.Tp, st, atrans);
   if (rc) return rc;
   WinoGeom go = gi;
   go.C = Mout;
-  hipLaunchKernelGGL(wino_output_kernel, dim3(cdiv(gi.Tp, 256), Mout), dim3(256), 0, st, (const float*)Mo, dst, bias, go,
+  hipLaunchKernelGGL(wino_output_kernel, dim3(cdiv(gi.Tp, tb), Mout), dim3(tb), 0, st, (const float*)Mo, dst, bias, go,
                      act, slope);
   return check_launch("wino_output");
 }
@@ -580,10 +592,11 @@ static int run_wgrad(const float* dy, const float* x, float* dw, int M, int C, i
     float* Vt = (float*)ws;                          // [16][Tp][C]
     float* dM = Vt + (size_t)16 * C * gx.Tp;         // [16][M][Tp]
     float* dU = dM + (size_t)16 * M * gx.Tp;         // [16][M][C]
-    const dim3 gin(cdiv(C, 256), gx.Tp);
-    if (pad_mode == HIM_PAD_REFLECT) hipLaunchKernelGGL((wino_input_t_kernel<true>), gin, dim3(256), 0, st, x, Vt, gx);
-    else hipLaunchKernelGGL((wino_input_t_kernel<false>), gin, dim3(256), 0, st, x, Vt, gx);
-    hipLaunchKernelGGL(wino_dy_kernel, dim3(cdiv(gx.Tp, 256), M), dim3(256), 0, st, dy, dM, gd);
+    const int tb = wino_tblock();
+    const dim3 gin(cdiv(C, tb), gx.Tp);
+    if (pad_mode == HIM_PAD_REFLECT) hipLaunchKernelGGL((wino_input_t_kernel<true>), gin, dim3(tb), 0, st, x, Vt, gx);
+    else hipLaunchKernelGGL((wino_input_t_kernel<false>), gin, dim3(tb), 0, st, x, Vt, gx);
+    hipLaunchKernelGGL(wino_dy_kernel, dim3(cdiv(gx.Tp, tb), M), dim3(tb), 0, st, dy, dM, gd);
     int rcw = check_launch("wino_wgrad_transforms");
     if (rcw) return rcw;
     rcw = wino_batched_gemm(dM, Vt, dU, M, gx.Tp, C, st);
@@ -900,7 +913,7 @@ static int run_fprop(const HimConv2d* d, const float* x, const float* w, const f
     if (!ws || ws_bytes < need) return fail(HIM_E_WORKSPACE, "conv fwd needs %zu ws bytes, got %zu", need, ws_bytes);
     float* U = (float*)ws;
     if (!panel) {
-      hipLaunchKernelGGL((wino_weight_kernel<0>), dim3(cdiv(d->Cin, 256), d->Cout), dim3(256), 0, st, w, U, d->Cout,
+      hipLaunchKernelGGL((wino_weight_kernel<0>), dim3(cdiv(d->Cin, wino_tblock()), d->Cout), dim3(wino_tblock()), 0, st, w, U, d->Cout,
                          d->Cin);
       int rc = check_launch("wino_weight");
       if (rc || build_only) return rc;
@@ -1022,7 +1035,7 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
   if (wino_dgrad_ok(d) && (build_only || (!bias && act == HIM_ACT_NONE))) {
     float* U = (float*)ws;
     if (!panel) {   // the FORWARD panel: the batched GEMM below reads it transposed (no flipped panel, round 3)
-      hipLaunchKernelGGL((wino_weight_kernel<0>), dim3(cdiv(d->Cin, 256), d->Cout), dim3(256), 0, st, w, U, d->Cout,
+      hipLaunchKernelGGL((wino_weight_kernel<0>), dim3(cdiv(d->Cin, wino_tblock()), d->Cout), dim3(wino_tblock()), 0, st, w, U, d->Cout,
                          d->Cin);
       int rcu = check_launch("wino_weight");
       if (rcu || build_only) return rcu;
