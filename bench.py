@@ -152,7 +152,7 @@ def dominant_kernel_roofline(device, bs, ntiles):
     correction) + WRITE_SIZE), null if that file is absent or the shape differs -- not measured in this run.
     `conv_launch` times the WHOLE conv (transforms + GEMM, cached weight panel) and states its rate in
     direct-form-equivalent FLOP, for comparison with a non-Winograd implementation."""
-    from neurips18_hierchical_image_manipulation_amd import ops
+    from neurips18_hierchical_image_manipulation_amd import ops, config  # noqa: F401
     from neurips18_hierchical_image_manipulation_amd._cabi import lib
     M = K = 1024
     N = ntiles
@@ -160,7 +160,7 @@ def dominant_kernel_roofline(device, bs, ntiles):
     b = torch.randn(16, K, N, device=device)
     c = torch.empty(16, M, N, device=device)
     st = torch.cuda.current_stream().cuda_stream
-    gemm = lambda: lib.him_winograd_gemm(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, K, N, st)  # noqa: E731
+    gemm = lambda: lib.him_winograd_gemm(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, K, N, None, st)  # noqa: E731
     for _ in range(3):
         gemm()
     ms_b2b = _event_ms(gemm, 20)
@@ -227,7 +227,7 @@ def step_flop_accounting(ms_per_step, bs):
 
 def direct_conv_roofline(device, bs, cin, cout, k, stride, pad, h, w, what):
     """Roofline of a direct-form MFMA conv launch (workloads whose dominant kernel is not the Winograd GEMM)."""
-    from neurips18_hierchical_image_manipulation_amd import ops
+    from neurips18_hierchical_image_manipulation_amd import ops, config  # noqa: F401
     x = torch.randn(bs, cin, h, w, device=device)
     wt = torch.nn.Parameter(torch.randn(cout, cin, k, k, device=device) * 0.02, requires_grad=False)
     bias = torch.zeros(cout, device=device)
@@ -249,7 +249,7 @@ def g_forward_roofline(model, batch, wl):
     direct-form FLOP; the >= 512-channel 3x3 stride-1 convs run as Winograd (2.25x fewer multiplies) and the stem's
     one-hot input channels are table lookups.  Both rates are reported; the roofline fraction is the EXECUTED one
     (only computed for the C2 GlobalGenerator, whose layer table is fixed: 18 ResnetBlock convs + the 38->64 stem)."""
-    from neurips18_hierchical_image_manipulation_amd import ops
+    from neurips18_hierchical_image_manipulation_amd import ops, config  # noqa: F401
     kw = dict(mask_in=batch['mask_in'])
     if 'obj_mask' in batch:
         kw['obj_mask'] = batch['obj_mask']
@@ -266,12 +266,11 @@ def g_forward_roofline(model, batch, wl):
                tflops_direct_form_equivalent=round(direct / (ms * 1e-3), 2),
                frac_direct_form_equivalent=round(direct / (ms * 1e-3) / PEAK_F32_MFMA, 4))
     if wl is WORKLOADS['c2']:
-        wino = ops.set_winograd_min_channels(0)
-        ops.set_winograd_min_channels(wino)
+        wino = ops.resolved_algo()['wino_min_c']
         executed = direct
         if 0 < wino <= 1024:            # 18 ResnetBlock convs: 34.36 instead of 77.31 GFLOP each
             executed -= 18 * (77.309 - 34.360) / 1e3
-        if ops._ONEHOT_ON:              # stem conv7x7 38->64: the 35 one-hot channels are LDS lookups, 3 dense ones stay
+        if config.SCHED.onehot_stem:              # stem conv7x7 38->64: the 35 one-hot channels are LDS lookups, 3 dense ones stay
             executed -= 2.0 * 64 * 35 * 49 * (bs * H * W) / 1e12
         out.update(tflops_executed=round(executed / (ms * 1e-3), 2),
                    frac_of_f32_mfma_peak=round(executed / (ms * 1e-3) / PEAK_F32_MFMA, 4))
@@ -350,10 +349,20 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=3, help='timed oracle steps of the cpu_baseline leg')
+    ap.add_argument('--fake-comm', action='store_true',
+                    help='1-GPU stand-in for the data-parallel gradient exchange: after the normal timed run, attach '
+                         'reducers whose buckets are device-to-device copies of the same bytes (730 MB G + 34 MB D at C2, '
+                         '64 MB buckets) on the comm streams at the real trigger points, time the same steps again and '
+                         'report the step-time delta + the event-timed exposed waits ("fake_comm" in the JSON line)')
+    ap.add_argument('--rccl-channels', type=int, default=0,
+                    help='N > 1: cap RCCL at this many channels (NCCL_MAX_NCHANNELS; each channel is a workgroup = CUs taken '
+                         'from the compute streams); 0 = the library default.  Printed under "ranks"')
     ap.add_argument('--workload', choices=sorted(WORKLOADS), default='c2',
                     help='c2 (default) = the BASELINE.json metric; c2local / c4 / box2mask = the other measured '
                          'configurations (DESIGN.md), same protocol and JSON schema')
     args = ap.parse_args()
+    if args.rccl_channels > 0:
+        os.environ['NCCL_MAX_NCHANNELS'] = str(args.rccl_channels)     # before the process group / the ranks exist
     if args.gpus > 1 and 'RANK' not in os.environ:
         sys.exit(spawn_ranks(args))
 
@@ -410,7 +419,34 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    identical = exposed = None
+    identical = exposed = fake = None
+    if args.fake_comm and world == 1 and args.workload != 'box2mask':
+        # the exchange stand-in (dist.GradReducer(fake=True)): same step, same batches, reducers attached
+        dt0 = dt
+        attach_data_parallel(model, fake=True)
+        for i in range(max(args.warmup, 2)):
+            step(i)
+        torch.cuda.synchronize()
+        model.start_comm_timing()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i)
+        torch.cuda.synchronize()
+        dt1 = time.perf_counter() - t0
+        ex = model.read_comm_timing(args.steps)
+        nbytes = sum(4 * r.flat.numel() for r in (model.reducer_G, model.reducer_D) if r is not None)
+        fake = dict(ms_per_step_without=round(dt0 / args.steps * 1e3, 3), ms_per_step_with=round(dt1 / args.steps * 1e3, 3),
+                    delta_ms=round((dt1 - dt0) / args.steps * 1e3, 3), bytes_per_step=nbytes,
+                    buckets=[len(r.buckets) for r in (model.reducer_G, model.reducer_D) if r is not None],
+                    what='device-to-device copies of the gradient buckets on the optimizer streams at the real trigger '
+                         'points (no second GPU): scheduling + HBM cost of the exchange, not xGMI time',
+                    exposed_comm_ms=ex,
+                    main_stream_upper_bound_ms=round(ex['g_update_tail'] + ex['d_update_wait'] +
+                                                     min(ex.get('d_update_wait_real', 0.0),
+                                                         ex.get('real_branch_join', 0.0)), 4))
+        model.reducer_G = model.reducer_D = None
+        for p in list(model.netG.parameters()) + list(model.netD.parameters()):
+            p.__dict__.pop('_him_reducer', None)
     if world > 1:
         if timing_on:
             mine = model.read_comm_timing(args.steps)
@@ -438,12 +474,20 @@ def main():
         if world > 1:
             out['ranks'] = {'world_size': dist.get_world_size(), 'backend': 'rccl' if backend == 'nccl' else backend,
                             'replicas_identical': identical}
+            if args.rccl_channels > 0:
+                out['ranks']['rccl_max_nchannels'] = args.rccl_channels
             if exposed is not None:
                 # per rank, ms per step a stream sat idle for the gradient exchange (models/pix2pixHD_condImg_model.py
                 # read_comm_timing): g_update_tail and d_update_wait are on the main stream, i.e. they delay the step
                 out['exposed_comm_ms'] = {'per_rank': exposed,
-                                          'main_stream_max': round(max(e['g_update_tail'] + e['d_update_wait']
+                                          'main_stream_max_is': 'UPPER bound of what delays the step: g_update_tail + '
+                                          'd_update_wait + min(d_update_wait_real, real_branch_join)',
+                                          'main_stream_max': round(max(e['g_update_tail'] + e['d_update_wait'] +
+                                                                       min(e.get('d_update_wait_real', 0.0),
+                                                                           e.get('real_branch_join', 0.0))
                                                                        for e in exposed), 4)}
+        if fake is not None:
+            out['fake_comm'] = fake
         if not args.no_roofline:
             if args.workload == 'box2mask':
                 out['roofline'] = direct_conv_roofline(device, bs, 256, 256, 3, 1, 1, 32, 32,

@@ -51,6 +51,61 @@ const char* him_last_error(void);
  * at models/Pix2Pix_NET.py:74,78-79,91; models/layer_util.py:333-378 (ResnetBlock);
  * models/Discriminator_NET.py:69-93; models/layer_util.py:380-411 (Vgg19 conv3+ReLU).
  * ------------------------------------------------------------------------------------------- */
+/* ---------------------------------------------------------------------------------------------
+ * Algorithm selection.  The library holds NO mutable global state and reads NO environment variable on any compute or
+ * size-query path: which kernel family a descriptor runs on -- and therefore its workspace size, its panel layout and
+ * its fp32 summation order -- is a pure function of the descriptor, whose `algo` member carries the caller's overrides.
+ * A zero-filled HimAlgo selects the defaults (what `him_algo_resolve` writes back); every entry point is re-entrant
+ * across host threads, also with different HimAlgo values (tests/test_ops_gpu.py::test_library_is_reentrant).
+ * Use ONE HimAlgo for the size query, the panel build and the launches of a layer.
+ * (torch has no counterpart: cuDNN / MIOpen pick algorithms behind `torch.backends.cudnn.benchmark`; reference call
+ * sites = every nn.Conv2d / nn.ConvTranspose2d of the path, see "Conv2d family" below.)
+ * ------------------------------------------------------------------------------------------- */
+#define HIM_TILE_DEFAULT 0   /* 64x128 (MxN) tiles: best inside the multi-stream training step */
+#define HIM_TILE_128x128 1
+#define HIM_TILE_128x128_8W 2
+#define HIM_TILE_128x256 3   /* batched Winograd GEMM only */
+#define HIM_TILE_64x128 4
+#define HIM_TILE_64x64 5
+#define HIM_TILE_MIXED 6     /* 128x128 when the launch has >= 512 (or 200..256) such tiles, else 128x64 */
+#define HIM_TILE_128x64 7
+
+#define HIM_ALGO_NO_SPLITK (1u << 0)        /* no split-K of few-tile conv / data-gradient launches */
+#define HIM_ALGO_NO_DFOLD (1u << 1)         /* reflect-pad-1 3x3 data gradient through the padded gradient + fold pass */
+#define HIM_ALGO_WINO_PADDED_DGRAD (1u << 2)/* Winograd reflect data gradient on the padded grid instead of folded border tiles */
+#define HIM_ALGO_NO_SMALL_WIN (1u << 3)     /* tiny-M "same"-window weight gradient kernel off */
+#define HIM_ALGO_NO_FEWOUT_TILED (1u << 4)  /* LDS-tiled VALU kernel for 2..4 output channels off */
+#define HIM_ALGO_NO_FEWIN_TILED (1u << 5)   /* LDS-tiled VALU kernel for <= 4 reduction channels off */
+#define HIM_ALGO_NO_FEWCH_MFMA (1u << 6)    /* MFMA weight gradient of the few-channel 5x5 / 7x7 layers off */
+#define HIM_ALGO_GENERIC_CONV (1u << 7)     /* generic implicit-GEMM kernels instead of the buffer-load fast path */
+#define HIM_ALGO_NO_RESBLOCK_FUSED (1u << 8)/* him_resblock_supported() answers 0 */
+#define HIM_ALGO_NO_BGEMM (1u << 10)        /* batched Winograd GEMMs on the conv kernel instead of the LDS-DMA GEMM kernel */
+#define HIM_ALGO_FROZEN_WEIGHTS (1u << 9)   /* the layer's weights never change (VGG19 of the perceptual loss,
+                                               models/layer_util.py:380-411): forward / data gradient may use Winograd
+                                               F(4x4,3x3), whose 36-position panel is built once per run */
+
+typedef struct HimAlgo {
+  int wino_min_c;       /* 3x3 s1 p1 layers with Cin and Cout >= this run as separate-transform Winograd F(2x2,3x3);
+                           0 = default (512); < 0: EVERY Winograd form off (all convolutions in the direct form) */
+  int wino_fused_min_c; /* lower end of the fused single-launch Winograd kernel's channel range; 0 = default (64); < 0: off */
+  int wino_fused_max_c; /* upper end; 0 = default (512) */
+  int wino4_min_c;      /* FROZEN_WEIGHTS layers with Cin and Cout >= this run as F(4x4,3x3); 0 = default (256); < 0: off */
+  int ksplit_max;       /* cap of the split-K factor; 0 = default (8) */
+  int tile_wb, tile_nb; /* HIM_TILE_*: batched Winograd GEMMs / direct-form convolutions */
+  int wino_tblock;      /* threads per workgroup of the Winograd transform kernels: 64 (default), 128, 256 */
+  int wgrad_splits;     /* fast weight-gradient kernel: split count; 0 = automatic */
+  unsigned disable;     /* HIM_ALGO_* bits */
+  int reserved[2];
+} HimAlgo;
+/* out = in with every 0 replaced by the default it selects (in == NULL: all defaults). */
+void him_algo_resolve(const HimAlgo* in, HimAlgo* out);
+/* Development aid for tools/: zero-fills *a, then applies the HIM_* environment overrides (HIM_NO_WINOGRAD,
+ * HIM_WINO_MIN_C, HIM_NO_WINO_FUSED, HIM_WINO_FUSED_MIN_C / _MAX_C, HIM_WINO4_MIN_C, HIM_KSPLIT_MAX, HIM_NO_SPLITK,
+ * HIM_GCONV_TILE[_WB|_NB], HIM_WINO_TBLOCK, HIM_WGRAD_SPLITS, HIM_NO_DFOLD, HIM_WINO_PADDED_DGRAD, HIM_NO_SMALL_WIN,
+ * HIM_NO_FEWOUT_TILED, HIM_NO_FEWIN_TILED, HIM_NO_FEWCH_MFMA, HIM_GENERIC_CONV, HIM_NO_RESBLOCK_FUSED, HIM_NO_BGEMM).  The ONLY place
+ * the library reads the environment; nothing else calls it. */
+void him_algo_from_env(HimAlgo* a);
+
 typedef struct HimConv2d {
   int B, Cin, H, W;   /* input  (B,Cin,H,W) */
   int Cout, KH, KW;   /* weight (Cout,Cin,KH,KW) */
@@ -59,6 +114,7 @@ typedef struct HimConv2d {
   int OH, OW;         /* output (B,Cout,OH,OW); must equal (H+2p-K)/s+1 */
   int act;            /* epilogue activation applied by *_fwd */
   float slope;        /* LeakyReLU negative slope */
+  HimAlgo algo;       /* kernel selection overrides; zero-filled = defaults */
 } HimConv2d;
 
 /* y = act(conv(x, w) + bias); bias may be NULL.  ws holds the tap-major regrouped weight tile stream. */
@@ -84,6 +140,7 @@ typedef struct HimDeconv2d {
   int OH, OW; /* (H-1)*s - 2p + K + out_pad */
   int act;
   float slope;
+  HimAlgo algo;
 } HimDeconv2d;
 size_t him_deconv2d_fwd_ws(const HimDeconv2d* d);
 int him_deconv2d_fwd(const HimDeconv2d* d, const float* x, const float* w, const float* bias, float* y,
@@ -171,19 +228,16 @@ int him_conv2d_onehot_bwd_weight(const HimConv2d* d, const float* label, int n_o
  * *_panel_bytes returns 0 when that kernel reads the raw weights (Cout <= 4 heads, Cin < 16 stems):
  * use the plain entry point.  Workspace sizes are those of the plain entry points.
  * -------------------------------------------------------------------------------------------*/
-/* 3x3 stride-1 pad-1 convs with Cin and Cout >= this many channels (default 512; env HIM_WINO_MIN_C,
- * HIM_NO_WINOGRAD) run as Winograd F(2x2,3x3): transforms + ONE batched fp32-MFMA GEMM over the 16 transform
- * positions (2.25x fewer multiplies; fp32 rounding differs from the direct form at the 1e-6 level).  The data and
- * weight gradients of those layers use the same scheme.  Workspace / panel sizes follow the current setting: change
- * it only between steps, then rebuild cached panels.  c <= 0 turns EVERY Winograd form off (also the fused
- * single-launch kernel of the 64..512-channel layers): all convolutions then run in the direct form.  Returns the
- * previous value. */
-int him_set_winograd_min_channels(int c);
+/* 3x3 stride-1 pad-1 convs with Cin and Cout >= HimAlgo.wino_min_c channels (default 512) run as Winograd F(2x2,3x3):
+ * transforms + ONE batched fp32-MFMA GEMM over the 16 transform positions (2.25x fewer multiplies; fp32 rounding differs
+ * from the direct form at the 1e-6 level).  The data and weight gradients of those layers use the same scheme.  Workspace
+ * / panel sizes follow the descriptor's HimAlgo: a cached panel belongs to the HimAlgo it was built with. */
 
 /* Stage 2 of the Winograd convolution on its own: c[z][m][n] = sum_k a[z][m][k] * b[z][k][n] for the 16 transform
  * positions z (a: [16][M][K] weight/gradient panels, b: [16][K][N], c: [16][M][N]; K % 16 == 0, N % 128 == 0).
- * This is the launch the roofline in bench.py is measured on (fp32 MFMA, 2*16*M*K*N executed FLOP). */
-int him_winograd_gemm(const float* a, const float* b, float* c, int M, int K, int N, void* stream);
+ * This is the launch the roofline in bench.py is measured on (fp32 MFMA, 2*16*M*K*N executed FLOP).  algo: tile_wb is
+ * read (NULL = defaults). */
+int him_winograd_gemm(const float* a, const float* b, float* c, int M, int K, int N, const HimAlgo* algo, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * ResnetBlock  out = x + IN(conv3x3(refpad(relu(IN(conv3x3(refpad(x)))))))  with both InstanceNorms fused into the
@@ -199,6 +253,7 @@ int him_winograd_gemm(const float* a, const float* b, float* c, int M, int K, in
 typedef struct {
   int B, C, H, W;
   float eps;
+  HimAlgo algo;
 } HimResBlock;
 int him_resblock_supported(const HimResBlock* d);
 size_t him_resblock_ws(const HimResBlock* d);

@@ -13,25 +13,41 @@ c_float_p = C.c_void_p  # raw device pointers travel as integers
 c_int, c_size_t, c_float, c_void_p, c_double = C.c_int, C.c_size_t, C.c_float, C.c_void_p, C.c_double
 
 
+class HimAlgo(C.Structure):
+    """Kernel-selection overrides carried by every descriptor (include/him.h "Algorithm selection"); zero = defaults."""
+    _fields_ = [(n, c_int) for n in ('wino_min_c', 'wino_fused_min_c', 'wino_fused_max_c', 'wino4_min_c', 'ksplit_max',
+                                     'tile_wb', 'tile_nb', 'wino_tblock', 'wgrad_splits')] + \
+               [('disable', C.c_uint), ('reserved', c_int * 2)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != 'reserved'}
+
+
+# HimAlgo.disable bits / tile codes (include/him.h)
+ALGO_NO_SPLITK, ALGO_NO_DFOLD, ALGO_WINO_PADDED_DGRAD, ALGO_NO_SMALL_WIN, ALGO_NO_FEWOUT_TILED, ALGO_NO_FEWIN_TILED, \
+    ALGO_NO_FEWCH_MFMA, ALGO_GENERIC_CONV, ALGO_NO_RESBLOCK_FUSED, ALGO_FROZEN_WEIGHTS, ALGO_NO_BGEMM = (1 << i for i in range(11))
+TILE_DEFAULT, TILE_128x128, TILE_128x128_8W, TILE_128x256, TILE_64x128, TILE_64x64, TILE_MIXED, TILE_128x64 = range(8)
+
+
 class HimConv2d(C.Structure):
     _fields_ = [(n, c_int) for n in ('B', 'Cin', 'H', 'W', 'Cout', 'KH', 'KW', 'stride', 'pad', 'pad_mode',
-                                     'OH', 'OW', 'act')] + [('slope', c_float)]
+                                     'OH', 'OW', 'act')] + [('slope', c_float), ('algo', HimAlgo)]
 
 
 class HimDeconv2d(C.Structure):
     _fields_ = [(n, c_int) for n in ('B', 'Cin', 'H', 'W', 'Cout', 'KH', 'KW', 'stride', 'pad', 'out_pad',
-                                     'OH', 'OW', 'act')] + [('slope', c_float)]
+                                     'OH', 'OW', 'act')] + [('slope', c_float), ('algo', HimAlgo)]
 
 
 class HimResBlock(C.Structure):
-    _fields_ = [(n, c_int) for n in ('B', 'C', 'H', 'W')] + [('eps', c_float)]
+    _fields_ = [(n, c_int) for n in ('B', 'C', 'H', 'W')] + [('eps', c_float), ('algo', HimAlgo)]
 
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 PAD_ZERO, PAD_REFLECT = 0, 1
 
 P = c_void_p
-_CONV, _DECONV, _RESB = C.POINTER(HimConv2d), C.POINTER(HimDeconv2d), C.POINTER(HimResBlock)
+_CONV, _DECONV, _RESB, _ALGO = C.POINTER(HimConv2d), C.POINTER(HimDeconv2d), C.POINTER(HimResBlock), C.POINTER(HimAlgo)
 
 # name -> (restype, argtypes); int-returning entries are error-checked by the wrapper
 _SIGS = {
@@ -50,12 +66,13 @@ _SIGS = {
     'him_deconv2d_bwd_data': (c_int, [_DECONV, P, P, P, P, c_size_t, P]),
     'him_deconv2d_bwd_weight_ws': (c_size_t, [_DECONV]),
     'him_deconv2d_bwd_weight': (c_int, [_DECONV, P, P, P, P, c_int, P, c_size_t, P]),
-    'him_set_winograd_min_channels': (C.c_uint, [c_int]),   # returns the previous value (not an error code)
+    'him_algo_resolve': (None, [_ALGO, _ALGO]),
+    'him_algo_from_env': (None, [_ALGO]),
     'him_conv2d_onehot_fwd_ws': (c_size_t, [_CONV, c_int]),
     'him_conv2d_onehot_fwd': (c_int, [_CONV, P, c_int, P, P, P, P, P, c_size_t, P]),
     'him_conv2d_onehot_bwd_weight_ws': (c_size_t, [_CONV, c_int]),
     'him_conv2d_onehot_bwd_weight': (c_int, [_CONV, P, c_int, P, P, P, P, c_int, P, c_size_t, P]),
-    'him_winograd_gemm': (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    'him_winograd_gemm': (c_int, [P, P, P, c_int, c_int, c_int, _ALGO, P]),
     'him_conv2d_panel_bytes': (c_size_t, [_CONV, c_int]),
     'him_conv2d_bwd_data_shares_fwd_panel': (C.c_uint, [_CONV]),
     'him_conv2d_panel_build': (c_int, [_CONV, c_int, P, P, c_size_t, P]),

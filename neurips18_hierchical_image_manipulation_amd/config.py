@@ -1,0 +1,72 @@
+"""Host-side switches of the training step's SCHEDULE and of optional fusions -- one runtime object instead of module
+constants latched from the environment at import.
+
+``SCHED`` holds the shipped defaults; the ``HIM_*`` environment variables below are read ONCE, here, when the package is
+imported (tools/ A/B runs), and everything can be changed at run time -- ``with config.schedule(wgrad_stream=False): ...``
+-- which is how the parity suite compares the multi-stream schedule bit for bit with the serial one
+(tests/test_model_gpu.py::test_multi_stream_schedule_is_bit_identical_to_the_serial_one).  None of these switches changes
+the arithmetic of a step; the kernel-selection switches, which do, travel in ``HimAlgo`` (ops.current_algo)."""
+import contextlib
+import os
+
+
+def _env(name, default):
+    v = os.environ.get(name)
+    return default if v is None else v != '0'
+
+
+class Schedule(object):
+    # name -> (environment variable, default, what it does)
+    FIELDS = {
+        'wgrad_stream': ('HIM_WGRAD_STREAM', True, 'weight gradients on a side stream next to the data-gradient chain'),
+        'd_wgrad_routes': ('HIM_D_WGRAD_ROUTES', True, "loss_D.backward(): D's weight gradients on the VGG stream"),
+        'real_first': ('HIM_REAL_FIRST', False, "round 2's issue order: real-image branch enqueued before the generator"),
+        'real_ahead': ('HIM_REAL_AHEAD', True, 'D(real) + VGG(real) on their own stream next to the generator forward'),
+        'd_backward_first': ('HIM_D_BACKWARD_FIRST', True, 'loss_D.backward() before loss_G.backward()'),
+        'vgg_stream': ('HIM_VGG_STREAM', True, 'VGG(fake) forward / backward on its own stream'),
+        'vgg_backward_early': ('HIM_VGG_BACKWARD_EARLY', False, "VGG's backward started before loss_D.backward()"),
+        'vgg_batched': ('HIM_VGG_BATCHED', False, 'VGG(real) and VGG(fake) as ONE batch-2B forward chain'),
+        'd_split_input': ('HIM_D_SPLIT_INPUT', True, 'discriminators take (condition, image) pairs'),
+        'd_scale_streams': ('HIM_D_SCALE_STREAMS', False, 'one stream per PatchGAN scale'),
+        'share_fake_pass': ('HIM_SHARE_FAKE_PASS', True, 'the fake-image discriminator pass computed once per step'),
+        'vgg_gated': ('HIM_VGG_GATED', True, "VGG's ReLU backward folded into the gradient producers"),
+        'onehot_stem': ('HIM_ONEHOT_STEM', True, 'generator stem evaluated from the label ids'),
+        'panel_cache': ('HIM_PANEL_CACHE', True, 'weight panels cached on the parameter, rebuilt after Adam'),
+        'resblock_fused': ('HIM_RESBLOCK_FUSED', False, 'ResnetBlock with the norms inside the Winograd transforms'),
+        'dead_bias_skip': ('HIM_DEAD_BIAS_SKIP', True, 'no bias gradient in front of a mean-subtracting norm'),
+    }
+    # negative spellings kept for the recorded A/B command lines of rounds 2-3
+    LEGACY_OFF = {'HIM_NO_ONEHOT_STEM': 'onehot_stem', 'HIM_NO_PANEL_CACHE': 'panel_cache',
+                  'HIM_DEAD_BIAS_GRAD': 'dead_bias_skip'}
+
+    def __init__(self):
+        for k, (env, default, _) in self.FIELDS.items():
+            setattr(self, k, _env(env, default))
+        for env, k in self.LEGACY_OFF.items():
+            if os.environ.get(env) is not None:
+                setattr(self, k, False)
+
+    def as_dict(self):
+        return {k: bool(getattr(self, k)) for k in self.FIELDS}
+
+
+SCHED = Schedule()
+
+# every stream of the step switched off: the reference's own order on ONE stream
+SERIAL = dict(wgrad_stream=False, d_wgrad_routes=False, real_ahead=False, d_backward_first=False, vgg_stream=False,
+              vgg_backward_early=False, d_scale_streams=False)
+
+
+@contextlib.contextmanager
+def schedule(**fields):
+    saved = {k: getattr(SCHED, k) for k in fields}
+    for k in fields:
+        if k not in Schedule.FIELDS:
+            raise KeyError(k)
+    try:
+        for k, v in fields.items():
+            setattr(SCHED, k, bool(v))
+        yield SCHED
+    finally:
+        for k, v in saved.items():
+            setattr(SCHED, k, v)

@@ -71,4 +71,36 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh) {
 
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// ---- LDS-DMA: 16 bytes per lane, global -> LDS, no VGPR staging (global_load_lds_dwordx4) ---------------------------
+// The 64 lanes of the wave fill 1 KB of LDS at the WAVE-UNIFORM byte address `lds_dst` in lane order; `gsrc` is per lane.
+// Issued through inline asm ON PURPOSE: hipcc (ROCm 7.2) tracks a __builtin_amdgcn_global_load_lds as a pending LDS store
+// and puts `s_waitcnt vmcnt(0)` in front of the next ds_read of the same array -- i.e. it drains a multi-stage DMA
+// pipeline at the top of every K-step (seen in the ISA of round 2/3's fused Winograd kernel: the request for chunk c+2 was
+// waited for before chunk c's first operand read).  An asm statement is invisible to that bookkeeping: completion is
+// counted by hand (`s_waitcnt vmcnt(N)` + barrier before any wave reads the data; cdna_hip_programming.md 5.7).
+// M0 (the DMA's LDS base) is saved and restored inside the statement.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+// wave-uniform LDS byte address of a __shared__ pointer
+__device__ __forceinline__ unsigned lds_addr_u(const void* p) {
+  return (unsigned)__builtin_amdgcn_readfirstlane(
+      (int)(unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p);
+}
+
+// ---- HimAlgo accessors: a zero field selects the default (include/him.h "Algorithm selection").  Kernel selection is a
+// pure function of (descriptor, HimAlgo): no statics, no environment.
+inline int algo_wino_min_c(const HimAlgo& a) { return a.wino_min_c == 0 ? 512 : a.wino_min_c; }          // <= 0: off
+inline int algo_wino_fused_min_c(const HimAlgo& a) { return a.wino_fused_min_c == 0 ? 64 : a.wino_fused_min_c; }
+inline int algo_wino_fused_max_c(const HimAlgo& a) { return a.wino_fused_max_c == 0 ? 512 : a.wino_fused_max_c; }
+inline int algo_wino4_min_c(const HimAlgo& a) { return a.wino4_min_c == 0 ? 256 : a.wino4_min_c; }
+inline int algo_ksplit_max(const HimAlgo& a) { return a.ksplit_max <= 0 ? 8 : a.ksplit_max; }
+inline int algo_tblock(const HimAlgo& a) { return (a.wino_tblock == 128 || a.wino_tblock == 256) ? a.wino_tblock : 64; }
+inline bool algo_off(const HimAlgo& a, unsigned bit) { return (a.disable & bit) != 0; }
+
 }  // namespace him

@@ -27,6 +27,7 @@ namespace him {
 
 #include "him_gconv_fast.inc"
 #include "him_wino_fused.inc"
+#include "him_bgemm.inc"
 
 // ---- weight regrouping for the fast path: out[m][cb][jh][jw][c16] = W[base + m*sm + (16cb+c16)*sc + jh*sh + jw*sw]
 struct WT2Phase {
@@ -99,11 +100,7 @@ __global__ __launch_bounds__(256) void wt_dgrad_kernel(const float* __restrict__
   }
 }
 
-static bool use_fast(int M, int C2) {
-  static int force_generic = -1;
-  if (force_generic < 0) force_generic = getenv("HIM_GENERIC_CONV") ? 1 : 0;
-  return !force_generic && M > 4 && C2 >= 16;
-}
+static bool use_fast(const HimAlgo& a, int M, int C2) { return !algo_off(a, HIM_ALGO_GENERIC_CONV) && M > 4 && C2 >= 16; }
 static int pad16(int c) { return (c + 15) / 16 * 16; }
 
 #include "him_conv_direct.inc"
@@ -127,14 +124,14 @@ static void launch_small_cfg(const GConvP& p, long long maxN, hipStream_t st) {
 }
 
 // returns true when the tiny-M path took the launch
-static bool launch_gconv_small(const GConvP& p, long long maxN, hipStream_t st) {
+static bool launch_gconv_small(const HimAlgo& a, const GConvP& p, long long maxN, hipStream_t st) {
   if (p.M > 4) return false;
   bool same = true;
   for (int i = 0; i < p.nphase; ++i) same = same && p.ph[i].JH == p.ph[0].JH && p.ph[i].JW == p.ph[0].JW;
   for (int i = 0; i < p.nphase; ++i)
     if (p.ph[i].JH > 8 || p.ph[i].JW > 8) return false;
   const int tj = (same && p.ph[0].JH == p.ph[0].JW) ? p.ph[0].JH : 0;
-  if (fewout_tiled_ok(p)) {
+  if (fewout_tiled_ok(a, p)) {
     switch (p.M * 10 + tj) {
       case 23: launch_fewout_tiled<2, 3>(p, st); return true;
       case 33: launch_fewout_tiled<3, 3>(p, st); return true;
@@ -173,15 +170,15 @@ static void launch_gconv_cfg(const GConvP& p, dim3 grid, hipStream_t st) {
     hipLaunchKernelGGL((gconv_kernel<WM, WN, TM, TN, false>), grid, dim3(256), 0, st, p);
 }
 
-static int launch_gconv(const GConvP& p, hipStream_t st) {
+static int launch_gconv(const HimAlgo& a, const GConvP& p, hipStream_t st) {
   long long maxN = 0;
   for (int i = 0; i < p.nphase; ++i) {
     long long n = (long long)p.B * p.ph[i].NA * p.ph[i].NC;
     if (n > maxN) maxN = n;
   }
   if (maxN == 0 || p.M <= 0) return HIM_OK;
-  if (launch_gconv_small(p, maxN, st)) return check_launch("gconv_small");
-  if (fewin_tiled_ok(p)) {
+  if (launch_gconv_small(a, p, maxN, st)) return check_launch("gconv_small");
+  if (fewin_tiled_ok(a, p)) {
     launch_fewin_tiled(p, st);
     return check_launch("gconv_fewin_tiled");
   }
@@ -189,46 +186,42 @@ static int launch_gconv(const GConvP& p, hipStream_t st) {
     // the fast kernel gathers through a buffer resource: 31-bit byte offsets (larger tensors: split the batch)
     if ((unsigned long long)p.B * p.C2 * p.SH * p.SW * 4ull >= (1ull << 31))
       return fail(HIM_E_UNSUPPORTED, "conv: source tensor of %llu bytes >= 2 GiB", (unsigned long long)p.B * p.C2 * p.SH * p.SW * 4ull);
-    static int tile_all = -2, tile_wb = -1, tile_nb = -1;
-    if (tile_all == -2) {
-      tile_all = getenv("HIM_GCONV_TILE") ? atoi(getenv("HIM_GCONV_TILE")) : -1;
-      tile_wb = getenv("HIM_GCONV_TILE_WB") ? atoi(getenv("HIM_GCONV_TILE_WB")) : tile_all;   // batched Winograd GEMMs
-      tile_nb = getenv("HIM_GCONV_TILE_NB") ? atoi(getenv("HIM_GCONV_TILE_NB")) : tile_all;   // direct-form convs
-    }
-    const int tile_override = p.atrans ? 4 : (p.wbatch ? tile_wb : tile_nb);   // transposed weight tiles: 64x128 only
+    // HimAlgo::tile_wb (batched Winograd GEMMs) / tile_nb (direct-form convs); transposed weight tiles: 64x128 only
+    const int tile_override = p.atrans ? HIM_TILE_64x128 : (p.wbatch ? a.tile_wb : a.tile_nb);
     const int ks = p.ksplit > 1 ? p.ksplit : 1;
     if (p.M <= 64) {   // (64x64 tiles here: no change of the step, round 3)
       dim3 grid(cdiv(maxN, 128) * cdiv(p.M, 64), ks, p.nphase);
       launch_fast_cfg<2, 2, 1, 2>(p, grid, st);
     } else {
-      // Tile shape (override: HIM_GCONV_TILE / _WB batched Winograd GEMMs / _NB direct-form convs).  Alone, 128x128 tiles
+      // Tile shape (HimAlgo::tile_wb / tile_nb).  Alone, 128x128 tiles
       // are the fastest (the batched GEMM of the ResnetBlocks: 0.321 ms vs 0.326 ms for 64x128, 0.358 ms for 64x64) --
       // but the training step runs two to four streams, and the 64x128 workgroup (30 KB LDS, ~100 registers: 4-5 per CU
       // instead of 3, twice as many of half the length) shares the CUs with the other streams' kernels better: round 3
       // measured 60.7 ms per step against 61.9 (128x64: 61.0; 64x64: 63.2; `gpurun_out/r03h`).
       const long long tiles128 = (long long)cdiv(maxN, 128) * cdiv(p.M, 128) * p.nphase;
-      const bool big = tile_override == 1 || (tile_override == 6 && (tiles128 >= 512 || (tiles128 >= 200 && tiles128 <= 256)));
+      const bool big = tile_override == HIM_TILE_128x128 ||
+                       (tile_override == HIM_TILE_MIXED && (tiles128 >= 512 || (tiles128 >= 200 && tiles128 <= 256)));
       const long long plane0 = (long long)p.ph[0].NA * p.ph[0].NC;
       const long long tiles256 = (maxN / 256) * cdiv(p.M, 128);
-      if (tile_override == 3 && p.wbatch && ks == 1 && p.nphase == 1 && plane0 % 256 == 0 && tiles256 % 512 == 0) {
-        // experiment (HIM_GCONV_TILE=3): 128x256 tiles for the batched Winograd GEMM, two workgroups per CU.  Alone it
+      if (tile_override == HIM_TILE_128x256 && p.wbatch && ks == 1 && p.nphase == 1 && plane0 % 256 == 0 && tiles256 % 512 == 0) {
+        // experiment (HIM_TILE_128x256): 128x256 tiles for the batched Winograd GEMM, two workgroups per CU.  Alone it
         // matches / beats the 128x128 tiling (weight-gradient GEMM 0.53 -> 0.42 ms) but its 232 VGPRs + 60 KB LDS stop
         // it from sharing a CU with the other stream's kernels: the full step fell from 98 to 69 images/s.
         dim3 grid((unsigned)tiles256, 1, 1);
         launch_fast_cfg<2, 2, 2, 4>(p, grid, st);
-      } else if (tile_override == 5) {
+      } else if (tile_override == HIM_TILE_64x64) {
         dim3 grid(cdiv(maxN, 64) * cdiv(p.M, 64), ks, p.nphase);
         launch_fast_cfg<2, 2, 1, 1>(p, grid, st);  // 64x64 tiles
-      } else if (tile_override == 2) {
+      } else if (tile_override == HIM_TILE_128x128_8W) {
         dim3 grid(cdiv(maxN, 128) * cdiv(p.M, 128), ks, p.nphase);
         launch_fast_cfg<2, 4, 2, 1>(p, grid, st);  // 8 waves per 128x128 tile (measured: lockstep, no better than 4)
-      } else if (big || (tile_override == 6 && ks > 1)) {
+      } else if (big || (tile_override == HIM_TILE_MIXED && ks > 1)) {
         dim3 grid(cdiv(maxN, 128) * cdiv(p.M, 128), ks, p.nphase);
         launch_fast_cfg<2, 2, 2, 2>(p, grid, st);
-      } else if (tile_override == 0 || tile_override == 6) {
+      } else if (tile_override == HIM_TILE_128x64 || tile_override == HIM_TILE_MIXED) {
         dim3 grid(cdiv(maxN, 64) * cdiv(p.M, 128), ks, p.nphase);
         launch_fast_cfg<2, 2, 2, 1>(p, grid, st);
-      } else {   // default (and HIM_GCONV_TILE=4)
+      } else {   // HIM_TILE_DEFAULT / HIM_TILE_64x128
         dim3 grid(cdiv(maxN, 128) * cdiv(p.M, 64), ks, p.nphase);
         launch_fast_cfg<2, 2, 1, 2>(p, grid, st);
       }
@@ -402,33 +395,18 @@ __global__ __launch_bounds__(256) void reflect_extend_kernel(const float* __rest
 #include "him_conv_wino.inc"
 
 // ---- Winograd host side -------------------------------------------------------------------------------------------
-static int g_wino_min_c = -2;  // -2: not initialised; <= 0: Winograd off
-static int wino_min_c() {
-  if (g_wino_min_c == -2) {
-    const char* e = getenv("HIM_WINO_MIN_C");
-    g_wino_min_c = getenv("HIM_NO_WINOGRAD") ? -1 : (e ? atoi(e) : 512);
-  }
-  return g_wino_min_c;
-}
 // wide 3x3 stride-1 pad-1 layers only: below ~512 channels the x4 transform traffic eats the 2.25x multiply saving
-static bool wino_shape_ok(int Cout, int Cin, int KH, int KW, int stride, int pad, int H, int W) {
-  const int mc = wino_min_c();
+static bool wino_shape_ok(const HimAlgo& a, int Cout, int Cin, int KH, int KW, int stride, int pad, int H, int W) {
+  const int mc = algo_wino_min_c(a);
   return mc > 0 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin >= mc && Cout >= mc && (Cin % 16) == 0 &&
-         (Cout % 16) == 0 && H >= 2 && W >= 2 && use_fast(Cout, Cin);
+         (Cout % 16) == 0 && H >= 2 && W >= 2 && use_fast(a, Cout, Cin);
 }
 // Threads per workgroup of the Winograd transform kernels (one tile / channel per thread).  64 = one wave: inside the
 // multi-stream step the single-wave workgroups find a free slot next to the MFMA kernels sooner (58.5 vs 58.8 ms per step
-// for the input / output transforms alone, 128: 58.65; results are bit-identical); HIM_WINO_TBLOCK overrides.
-static int wino_tblock() {
-  static int tb = -1;
-  if (tb < 0) {
-    tb = getenv("HIM_WINO_TBLOCK") ? atoi(getenv("HIM_WINO_TBLOCK")) : 64;
-    if (tb != 64 && tb != 128 && tb != 256) tb = 64;
-  }
-  return tb;
-}
-static bool wino_wgrad_ok(int M, int C, int KH, int KW, int stride, int pad, int H, int W) {
-  return wino_shape_ok(M, C, KH, KW, stride, pad, H, W) && (M % 128) == 0 && (C % 128) == 0;
+// for the input / output transforms alone, 128: 58.65; results are bit-identical); HimAlgo::wino_tblock overrides.
+static int wino_tblock(const HimAlgo& a) { return algo_tblock(a); }
+static bool wino_wgrad_ok(const HimAlgo& a, int M, int C, int KH, int KW, int stride, int pad, int H, int W) {
+  return wino_shape_ok(a, M, C, KH, KW, stride, pad, H, W) && (M % 128) == 0 && (C % 128) == 0;
 }
 static size_t wino_conv_floats(int B, int Csrc, int Mout, int OH, int OW) {
   const WinoGeom g = wino_geom(B, Csrc, 1, 1, OH, OW, 1);
@@ -442,8 +420,13 @@ static size_t wino_wgrad_floats(int B, int M, int C, int OH, int OW) {
 // convolution over 16 "images" [K][1][N] with per-image weight panels.  K % 16 == 0, N % 128 == 0.
 // atrans: A is a FORWARD panel U[z][K][M] of the layer whose data gradient this is; the kernel reads it transposed with
 // the positions mirrored (GConvP::atrans) -- no second, flipped panel per weight.
-static int wino_batched_gemm(const float* A, const float* Bm, float* Cm, int M, int K, int N, hipStream_t st,
+static int wino_batched_gemm(const HimAlgo& a, const float* A, const float* Bm, float* Cm, int M, int K, int N, hipStream_t st,
                              bool atrans = false) {
+  // Round 4: the dedicated GEMM kernel with LDS-DMA operand loads (him_bgemm.inc) takes every launch that fills the chip
+  // with its 128x128 tiles (C2: 1024 workgroups = 2 per CU and XCD-resident batch entries); small planes (config C1: 128
+  // tiles) stay on the conv kernel's 64x128 tiles.
+  if (!algo_off(a, HIM_ALGO_NO_BGEMM) && bgemm_shape_ok(M, K, N, 16) && 16 * (M / 128) * (N / 128) >= 512)
+    return launch_bgemm(A, Bm, Cm, M, K, N, 16, 4, atrans ? 1 : 0, 1, atrans, st);
   GConvP g;
   memset(&g, 0, sizeof(g));
   g.atrans = atrans ? 1 : 0;
@@ -472,23 +455,23 @@ static int wino_batched_gemm(const float* A, const float* Bm, float* Cm, int M, 
   P.fJW = make_fastdiv(1);
   P.NA = 1;
   P.NC = N;
-  return launch_gconv(g, st);
+  return launch_gconv(a, g, st);
 }
 // dst[B][Mout][OH][OW] = act(winograd-conv(src[B][Csrc][H][W], U) + bias); ws holds V and Mo
-static int run_wino_conv(int B, int Csrc, int H, int W, int Mout, int OH, int OW, int po, bool reflect,
+static int run_wino_conv(const HimAlgo& a, int B, int Csrc, int H, int W, int Mout, int OH, int OW, int po, bool reflect,
                          const float* src, const float* U, const float* bias, int act, float slope, float* dst,
                          float* ws, hipStream_t st, bool fold = false, bool atrans = false) {
   WinoGeom gi = wino_geom(B, Csrc, H, W, OH, OW, po);
   gi.fold = fold ? 1 : 0;
   float* V = ws;
   float* Mo = V + (size_t)16 * Csrc * gi.Tp;
-  const int tb = wino_tblock();
+  const int tb = wino_tblock(a);
   const dim3 gin(cdiv(gi.Tp, tb), Csrc);
   if (reflect) hipLaunchKernelGGL((wino_input_kernel<true>), gin, dim3(tb), 0, st, src, V, gi);
   else hipLaunchKernelGGL((wino_input_kernel<false>), gin, dim3(tb), 0, st, src, V, gi);
   int rc = check_launch("wino_input");
   if (rc) return rc;
-  rc = wino_batched_gemm(U, V, Mo, Mout, Csrc, gi.Tp, st, atrans);
+  rc = wino_batched_gemm(a, U, V, Mo, Mout, Csrc, gi.Tp, st, atrans);
   if (rc) return rc;
   WinoGeom go = gi;
   go.C = Mout;
@@ -502,10 +485,8 @@ static int run_wino_conv(int B, int Csrc, int H, int W, int Mout, int OH, int OW
 #include "him_wgrad_fewch.inc"
 
 static const int SMALL_WIN_SLOTS = 256;
-static bool small_win_ok(int M, int KH, int KW, int stride, int pad, int H, int W, int OH, int OW) {
-  static int off = -1;
-  if (off < 0) off = getenv("HIM_NO_SMALL_WIN") ? 1 : 0;
-  return !off && M <= 4 && KH == KW && (KH == 3 || KH == 5 || KH == 7) && stride == 1 && pad == KH / 2 && OH == H && OW == W &&
+static bool small_win_ok(const HimAlgo& a, int M, int KH, int KW, int stride, int pad, int H, int W, int OH, int OW) {
+  return !algo_off(a, HIM_ALGO_NO_SMALL_WIN) && M <= 4 && KH == KW && (KH == 3 || KH == 5 || KH == 7) && stride == 1 && pad == KH / 2 && OH == H && OW == W &&
          H > pad && W > pad;
 }
 
@@ -516,11 +497,11 @@ static int small_wgrad_slices(int C, int Kdim) {
   return s < 1 ? 1 : s;
 }
 static bool small_wgrad_ok(int M, int KH, int KW) { return M <= 4 && KH == KW && (KH == 7 || KH == 4 || KH == 3); }
-static size_t wgrad_slab_bytes(int M, int C, int KH, int KW, int Kdim, size_t wino_floats = 0) {
+static size_t wgrad_slab_bytes(const HimAlgo& a, int M, int C, int KH, int KW, int Kdim, size_t wino_floats = 0) {
   const int Np = C * KH * KW;
   size_t slabs;
   if (wino_floats) return ((wino_floats * sizeof(float) + 255) / 256) * 256;
-  const bool fewch_shape = !fewch_off() && KH == KW && (KH == 5 || KH == 7) &&
+  const bool fewch_shape = !fewch_off(a) && KH == KW && (KH == 5 || KH == 7) &&
                            ((M <= 4 && C >= 32 && (C % 32) == 0) || (C <= 4 && M >= 32 && (M % 32) == 0));
   if (fewch_shape) {   // upper bound: the runner re-checks stride / padding / plane (else the kernels below, which need less)
     slabs = fewch_ws_floats(M <= 4 ? C : M, KH) * sizeof(float);
@@ -532,9 +513,9 @@ static size_t wgrad_slab_bytes(int M, int C, int KH, int KW, int Kdim, size_t wi
     if (s2 > 1) slabs = std::max(slabs, (size_t)s2 * M * Np * sizeof(float));
   } else if (small_wgrad_ok(M, KH, KW) || (M <= 4 && KH == KW && KH == 5)) {
     slabs = (size_t)std::max(small_wgrad_slices(C, Kdim), SMALL_WIN_SLOTS) * M * Np * sizeof(float);
-  } else if (wgrad_fast_ok(M, C, 1, 4)) {  /* upper bound; the runner re-checks OH*OW */
+  } else if (wgrad_fast_ok(a, M, C, 1, 4)) {  /* upper bound; the runner re-checks OH*OW */
     int BM, BN, sp;
-    wgrad_fast_cfg(M, C, Kdim, KH * KW, &BM, &BN, &sp);
+    wgrad_fast_cfg(a, M, C, Kdim, KH * KW, &BM, &BN, &sp);
     slabs = (size_t)sp * M * Np * sizeof(float);
     int BM2, BN2;
     wgrad_tile(M, &BM2, &BN2);
@@ -549,17 +530,17 @@ static size_t wgrad_slab_bytes(int M, int C, int KH, int KW, int Kdim, size_t wi
   }
   return ((slabs + 255) / 256) * 256;
 }
-static size_t wgrad_ws_bytes(int M, int C, int KH, int KW, int Kdim, int biasC, size_t wino_floats = 0) {
-  return wgrad_slab_bytes(M, C, KH, KW, Kdim, wino_floats) + bias_ws_bytes(biasC);
+static size_t wgrad_ws_bytes(const HimAlgo& a, int M, int C, int KH, int KW, int Kdim, int biasC, size_t wino_floats = 0) {
+  return wgrad_slab_bytes(a, M, C, KH, KW, Kdim, wino_floats) + bias_ws_bytes(biasC);
 }
 static size_t conv_wino_wgrad_floats(const HimConv2d* d) {
-  return wino_wgrad_ok(d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad, d->H, d->W)
+  return wino_wgrad_ok(d->algo, d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad, d->H, d->W)
              ? wino_wgrad_floats(d->B, d->Cout, d->Cin, d->OH, d->OW)
              : 0;
 }
 
 // generic weight gradient: dW[M][C*KH*KW] from dy[B][M][OH][OW] and x[B][C][H][W]
-static int run_wgrad(const float* dy, const float* x, float* dw, int M, int C, int B, int H, int W, int OH,
+static int run_wgrad(const HimAlgo& a, const float* dy, const float* x, float* dw, int M, int C, int B, int H, int W, int OH,
                      int OW, int KH, int KW, int stride, int pad, int pad_mode, int accumulate, void* ws,
                      size_t ws_bytes, hipStream_t st) {
   WGradP p;
@@ -582,7 +563,7 @@ static int run_wgrad(const float* dy, const float* x, float* dw, int M, int C, i
   p.fKK = make_fastdiv((uint32_t)(KH * KW));
   p.fKW = make_fastdiv((uint32_t)KW);
   p.fOW = make_fastdiv((uint32_t)OW);
-  if (wino_wgrad_ok(M, C, KH, KW, stride, pad, H, W) && OH == H && OW == W) {
+  if (wino_wgrad_ok(a, M, C, KH, KW, stride, pad, H, W) && OH == H && OW == W) {
     // dU = dM x V^T per Winograd position (batched NT GEMM), then dw (+)= G^T dU G
     const size_t need = wino_wgrad_floats(B, M, C, OH, OW) * sizeof(float);
     if (ws_bytes < need || !ws) return fail(HIM_E_WORKSPACE, "wgrad needs %zu ws bytes, got %zu", need, ws_bytes);
@@ -592,24 +573,24 @@ static int run_wgrad(const float* dy, const float* x, float* dw, int M, int C, i
     float* Vt = (float*)ws;                          // [16][Tp][C]
     float* dM = Vt + (size_t)16 * C * gx.Tp;         // [16][M][Tp]
     float* dU = dM + (size_t)16 * M * gx.Tp;         // [16][M][C]
-    const int tb = wino_tblock();
+    const int tb = wino_tblock(a);
     const dim3 gin(cdiv(C, tb), gx.Tp);
     if (pad_mode == HIM_PAD_REFLECT) hipLaunchKernelGGL((wino_input_t_kernel<true>), gin, dim3(tb), 0, st, x, Vt, gx);
     else hipLaunchKernelGGL((wino_input_t_kernel<false>), gin, dim3(tb), 0, st, x, Vt, gx);
     hipLaunchKernelGGL(wino_dy_kernel, dim3(cdiv(gx.Tp, tb), M), dim3(tb), 0, st, dy, dM, gd);
     int rcw = check_launch("wino_wgrad_transforms");
     if (rcw) return rcw;
-    rcw = wino_batched_gemm(dM, Vt, dU, M, gx.Tp, C, st);
+    rcw = wino_batched_gemm(a, dM, Vt, dU, M, gx.Tp, C, st);
     if (rcw) return rcw;
     hipLaunchKernelGGL(wino_wgrad_out_kernel, dim3(cdiv(C, 256), M), dim3(256), 0, st, (const float*)dU, dw, M, C,
                        accumulate);
     return check_launch("wino_wgrad_out");
   }
-  if (fewch_head_ok(M, C, KH, KW, stride, pad, H, W, OH, OW))
-    return run_wgrad_fewch(true, dy, x, dw, M, C, B, H, W, KH, pad, pad_mode, accumulate, ws, ws_bytes, st);
-  if (fewch_stem_ok(M, C, KH, KW, stride, pad, H, W, OH, OW))
-    return run_wgrad_fewch(false, dy, x, dw, M, C, B, H, W, KH, pad, pad_mode, accumulate, ws, ws_bytes, st);
-  if (small_win_ok(M, KH, KW, stride, pad, H, W, OH, OW)) {
+  if (fewch_head_ok(a, M, C, KH, KW, stride, pad, H, W, OH, OW))
+    return run_wgrad_fewch(a, true, dy, x, dw, M, C, B, H, W, KH, pad, pad_mode, accumulate, ws, ws_bytes, st);
+  if (fewch_stem_ok(a, M, C, KH, KW, stride, pad, H, W, OH, OW))
+    return run_wgrad_fewch(a, false, dy, x, dw, M, C, B, H, W, KH, pad, pad_mode, accumulate, ws, ws_bytes, st);
+  if (small_win_ok(a, M, KH, KW, stride, pad, H, W, OH, OW)) {
     const int nsx = cdiv(W, 64), rows_per = 64, nyc = cdiv(H, rows_per), ntasks = B * nsx * nyc;
     const int slots = std::min(ntasks, SMALL_WIN_SLOTS);
     const size_t need = (size_t)slots * M * p.Np * sizeof(float);
@@ -664,9 +645,9 @@ static int run_wgrad(const float* dy, const float* x, float* dw, int M, int C, i
   // the fast kernel reads both operands through buffer resources (31-bit byte offsets)
   const bool fits31 = (unsigned long long)B * M * OH * OW * 4ull < (1ull << 31) &&
                       (unsigned long long)B * C * H * W * 4ull < (1ull << 31);
-  if (wgrad_fast_ok(M, C, OH, OW) && fits31) {
+  if (wgrad_fast_ok(a, M, C, OH, OW) && fits31) {
     int fBM, fBN, fs;
-    wgrad_fast_cfg(M, C, p.Kdim, KH * KW, &fBM, &fBN, &fs);
+    wgrad_fast_cfg(a, M, C, p.Kdim, KH * KW, &fBM, &fBN, &fs);
     const size_t need = (size_t)fs * M * p.Np * sizeof(float);
     if (ws_bytes < need || !ws) return fail(HIM_E_WORKSPACE, "wgrad needs %zu ws bytes, got %zu", need, ws_bytes);
     p.splits = fs;
@@ -804,10 +785,8 @@ static bool small_split_ok(const HimConv2d* d) {
   return d->Cout <= 4 && d->Cin >= 256 && (long long)d->B * d->OH * d->OW < 256 * 512;
 }
 // split-K factor of a single-phase fast launch: aim at >= 2 workgroups per CU when the output has few tiles
-static int fast_ksplit(int M, long long N, int nk) {
-  static int off = -1;
-  if (off < 0) off = getenv("HIM_NO_SPLITK") ? 1 : 0;
-  if (off) return 1;
+static int fast_ksplit(const HimAlgo& a, int M, long long N, int nk) {
+  if (algo_off(a, HIM_ALGO_NO_SPLITK)) return 1;
   // (the model still counts 128-row tiles for M > 64 although the launch uses 64x128 ones: counting those instead left
   // the step unchanged, 59.7 vs 59.8 ms; no split-K at all: 60.7)
   const long long tiles = (M <= 64 ? (long long)cdiv(N, 128) * cdiv(M, 64) : (long long)cdiv(N, 128) * cdiv(M, 128));
@@ -821,8 +800,7 @@ static int fast_ksplit(int M, long long N, int nk) {
   // a few-tile launch leaves idle, and deep splits only add slab traffic and a longer finish pass: capped at 8 (round 3:
   // 58.5-58.6 vs 58.9 ms per step uncapped; caps of 3 / 4 / 6 within noise of 8, 2: 58.7; profiles/r03_tile_shape_ab.txt;
   // 8 rather than 4 because it leaves every launch of the C1 parity configuration on the split it was validated with).
-  static int kmax = -1;
-  if (kmax < 0) kmax = getenv("HIM_KSPLIT_MAX") ? atoi(getenv("HIM_KSPLIT_MAX")) : 8;
+  const int kmax = algo_ksplit_max(a);
   for (int ks : cand) {
     if (ks > kmax) break;
     if (ks > 1 && nk / ks < 32) break;  // keep >= 32 K-steps per workgroup
@@ -838,7 +816,7 @@ static int fast_ksplit(int M, long long N, int nk) {
   return best;
 }
 static bool wino_fwd_ok(const HimConv2d* d) {
-  return wino_shape_ok(d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad, d->H, d->W);
+  return wino_shape_ok(d->algo, d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad, d->H, d->W);
 }
 // The fused Winograd kernel (him_wino_fused.inc: transforms inside the GEMM kernel) takes the 3x3 stride-1 pad-1 layers
 // with 64..512 reduction channels and a multiple of 64 output channels in the FORWARD direction (zero or reflection
@@ -848,47 +826,37 @@ static bool wino_fwd_ok(const HimConv2d* d) {
 // (separate-transform pipeline, which needs two more launches and 4x the activation in HBM).  The separate-transform
 // pipeline keeps the 1024-channel ResnetBlock stack (see wino_fused_max_c), the data gradient of reflection-padded
 // layers (border fold) and the weight gradient.
-static int wino_fused_min_c() {
-  static int v = -2;
-  if (v == -2) v = getenv("HIM_NO_WINO_FUSED") ? 0 : (getenv("HIM_WINO_FUSED_MIN_C") ? atoi(getenv("HIM_WINO_FUSED_MIN_C")) : 64);
-  return v;
-}
 // Upper end of the fused kernel's channel range.  Inside the training step (weight panels streamed from HBM, 67 MB per
 // 1024-channel layer) the ResnetBlock forward is faster on the separate-transform pipeline: 10.4 vs 11.8 ms generator
-// forward, 121.4 vs 118.9 images/s (A/B with HIM_WINO_FUSED_MAX_C) -- although the isolated kernel, whose panel stays in
-// the Infinity Cache between launches, measures 197 vs 188 TFLOP/s equivalent.
-static int wino_fused_max_c() {
-  static int v = -2;
-  if (v == -2) v = getenv("HIM_WINO_FUSED_MAX_C") ? atoi(getenv("HIM_WINO_FUSED_MAX_C")) : 512;
-  return v;
-}
-static bool wino_fused_ok(int Co, int Ci, int KH, int KW, int stride, int pad, int B, int H, int W) {
-  const int mc = wino_fused_min_c();
-  // him_set_winograd_min_channels(<= 0) / HIM_NO_WINOGRAD turn EVERY Winograd form off (parity runs in the direct form)
-  return mc > 0 && wino_min_c() > 0 && Ci >= mc && Ci <= wino_fused_max_c() && Co >= 64 &&
+// forward, 121.4 vs 118.9 images/s (A/B with HimAlgo::wino_fused_max_c) -- although the isolated kernel, whose panel stays
+// in the Infinity Cache between launches, measures 197 vs 188 TFLOP/s equivalent: the default range ends at 512 channels.
+static bool wino_fused_ok(const HimAlgo& a, int Co, int Ci, int KH, int KW, int stride, int pad, int B, int H, int W) {
+  const int mc = algo_wino_fused_min_c(a);
+  // HimAlgo::wino_min_c < 0 turns EVERY Winograd form off (parity runs in the direct form)
+  return mc > 0 && algo_wino_min_c(a) > 0 && Ci >= mc && Ci <= algo_wino_fused_max_c(a) && Co >= 64 &&
          wino_fused_shape_ok(Co, Ci, KH, KW, stride, pad, B, H, W);
 }
 static bool wino_fused_fwd_ok(const HimConv2d* d) {
-  return wino_fused_ok(d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad, d->B, d->H, d->W);
+  return wino_fused_ok(d->algo, d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad, d->B, d->H, d->W);
 }
 // data gradient of a ZERO-padded 3x3 stride-1 conv = the same convolution with the flipped / transposed filter
 static bool wino_fused_dgrad_ok(const HimConv2d* d) {
   return d->pad_mode == HIM_PAD_ZERO && d->OH == d->H && d->OW == d->W &&
-         wino_fused_ok(d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad, d->B, d->H, d->W);
+         wino_fused_ok(d->algo, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad, d->B, d->H, d->W);
 }
 static size_t fprop_ws_bytes(const HimConv2d* d) {
   if (wino_fused_fwd_ok(d)) return wino_fused_panel_floats(d->Cout, d->Cin) * sizeof(float) + 256;
   if (wino_fwd_ok(d))
     return ((size_t)16 * d->Cout * d->Cin + wino_conv_floats(d->B, d->Cin, d->Cout, d->OH, d->OW)) * sizeof(float) + 256;
   if (small_split_ok(d)) return (size_t)SMALL_NSPLIT * d->Cout * d->B * d->OH * d->OW * sizeof(float) + 256;
-  if (!use_fast(d->Cout, d->Cin)) return 0;
-  const int ks = fast_ksplit(d->Cout, (long long)d->B * d->OH * d->OW, d->KH * d->KW * (pad16(d->Cin) / 16));
+  if (!use_fast(d->algo, d->Cout, d->Cin)) return 0;
+  const int ks = fast_ksplit(d->algo, d->Cout, (long long)d->B * d->OH * d->OW, d->KH * d->KW * (pad16(d->Cin) / 16));
   const size_t wts = ((size_t)d->Cout * d->KH * d->KW * pad16(d->Cin) * sizeof(float) + 255) / 256 * 256;
   return wts + (ks > 1 ? (size_t)ks * d->B * d->Cout * d->OH * d->OW * sizeof(float) : 0) + 256;
 }
 // floats of the regrouped weight panel the forward kernel reads (0: it reads the raw weights)
 static size_t fprop_panel_floats(const HimConv2d* d) {
-  if (small_split_ok(d) || d->Cout <= 4 || !use_fast(d->Cout, d->Cin)) return 0;
+  if (small_split_ok(d) || d->Cout <= 4 || !use_fast(d->algo, d->Cout, d->Cin)) return 0;
   if (wino_fused_fwd_ok(d)) return wino_fused_panel_floats(d->Cout, d->Cin);
   if (wino_fwd_ok(d)) return (size_t)16 * d->Cout * d->Cin;
   return (size_t)d->Cout * d->KH * d->KW * pad16(d->Cin);
@@ -913,12 +881,12 @@ static int run_fprop(const HimConv2d* d, const float* x, const float* w, const f
     if (!ws || ws_bytes < need) return fail(HIM_E_WORKSPACE, "conv fwd needs %zu ws bytes, got %zu", need, ws_bytes);
     float* U = (float*)ws;
     if (!panel) {
-      hipLaunchKernelGGL((wino_weight_kernel<0>), dim3(cdiv(d->Cin, wino_tblock()), d->Cout), dim3(wino_tblock()), 0, st, w, U, d->Cout,
+      hipLaunchKernelGGL((wino_weight_kernel<0>), dim3(cdiv(d->Cin, wino_tblock(d->algo)), d->Cout), dim3(wino_tblock(d->algo)), 0, st, w, U, d->Cout,
                          d->Cin);
       int rc = check_launch("wino_weight");
       if (rc || build_only) return rc;
     }
-    return run_wino_conv(d->B, d->Cin, d->H, d->W, d->Cout, d->OH, d->OW, 1, d->pad_mode == HIM_PAD_REFLECT, x,
+    return run_wino_conv(d->algo, d->B, d->Cin, d->H, d->W, d->Cout, d->OH, d->OW, 1, d->pad_mode == HIM_PAD_REFLECT, x,
                          panel ? panel : U, bias, d->act, d->slope, y, U + (size_t)16 * d->Cout * d->Cin, st);
   }
   GConvP g;
@@ -928,7 +896,7 @@ static int run_fprop(const HimConv2d* d, const float* x, const float* w, const f
     g.small_part = (float*)ws;
     g.small_nsplit = SMALL_NSPLIT;
   }
-  if (use_fast(d->Cout, d->Cin)) {
+  if (use_fast(d->algo, d->Cout, d->Cin)) {
     const size_t need = build_only ? fprop_panel_floats(d) * sizeof(float) : fprop_ws_bytes(d);
     if (!ws || ws_bytes < need) return fail(HIM_E_WORKSPACE, "conv fwd needs %zu ws bytes, got %zu", need, ws_bytes);
     WT2P t;
@@ -959,31 +927,29 @@ static int run_fprop(const HimConv2d* d, const float* x, const float* w, const f
     g.fast = 1;
     g.ph[0].At = panel ? panel : (const float*)ws;
     g.ph[0].C2p = t.C2p;
-    const int ks = fast_ksplit(d->Cout, (long long)d->B * d->OH * d->OW, KK * (t.C2p / 16));
+    const int ks = fast_ksplit(d->algo, d->Cout, (long long)d->B * d->OH * d->OW, KK * (t.C2p / 16));
     if (ks > 1) {
       const size_t wts = ((size_t)d->Cout * KK * t.C2p * sizeof(float) + 255) / 256 * 256;
       g.ksplit = ks;
       g.kpart = (float*)((char*)ws + wts);
     }
   }
-  return launch_gconv(g, st);
+  return launch_gconv(d->algo, g, st);
 }
 
 // data gradient of the conv described by `d` (also the forward of its transposed conv):
 // out (B,Cin,H,W) = sum W * g (B,Cout,OH,OW); for reflect mode goes through the padded gradient + fold.
 // reflect-pad-1 3x3 stride-1 (every ResnetBlock conv): gather from the border-extended gradient, no padded GEMM columns
 static bool dfold_ok(const HimConv2d* d) {
-  static int off = -1;
-  if (off < 0) off = getenv("HIM_NO_DFOLD") ? 1 : 0;
-  return !off && d->pad_mode == HIM_PAD_REFLECT && d->pad == 1 && d->KH == 3 && d->KW == 3 && d->stride == 1 &&
-         d->H >= 3 && d->W >= 3 && d->OH == d->H && d->OW == d->W && use_fast(d->Cin, d->Cout);
+  return !algo_off(d->algo, HIM_ALGO_NO_DFOLD) && d->pad_mode == HIM_PAD_REFLECT && d->pad == 1 && d->KH == 3 && d->KW == 3 && d->stride == 1 &&
+         d->H >= 3 && d->W >= 3 && d->OH == d->H && d->OW == d->W && use_fast(d->algo, d->Cin, d->Cout);
 }
 static bool wino_dgrad_ok(const HimConv2d* d) {
-  return wino_shape_ok(d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad, d->H, d->W) && d->OH == d->H && d->OW == d->W;
+  return wino_shape_ok(d->algo, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad, d->H, d->W) && d->OH == d->H && d->OW == d->W;
 }
 static bool wino_dgrad_fold(const HimConv2d* d) {  // reflect folded into the border tiles' patches (see wino_input_kernel)
   return d->pad_mode == HIM_PAD_REFLECT && (d->H % 2) == 0 && (d->W % 2) == 0 && d->H >= 4 && d->W >= 4 &&
-         !getenv("HIM_WINO_PADDED_DGRAD");
+         !algo_off(d->algo, HIM_ALGO_WINO_PADDED_DGRAD);
 }
 static size_t wino_dgrad_floats(const HimConv2d* d) {  // U' + V + Mo (+ padded gradient for reflect)
   const bool refl = d->pad_mode == HIM_PAD_REFLECT && !wino_dgrad_fold(d);
@@ -992,10 +958,10 @@ static size_t wino_dgrad_floats(const HimConv2d* d) {  // U' + V + Mo (+ padded 
          (refl ? (size_t)d->B * d->Cin * GH * GW : 0);
 }
 static int dgrad_ksplit(const HimConv2d* d) {
-  if (d->stride != 1 || !use_fast(d->Cin, d->Cout)) return 1;
+  if (d->stride != 1 || !use_fast(d->algo, d->Cin, d->Cout)) return 1;
   const bool refl = d->pad_mode == HIM_PAD_REFLECT && !dfold_ok(d);
   const long long N = (long long)d->B * (refl ? d->H + 2 * d->pad : d->H) * (refl ? d->W + 2 * d->pad : d->W);
-  return fast_ksplit(d->Cin, N, d->KH * d->KW * (pad16(d->Cout) / 16));
+  return fast_ksplit(d->algo, d->Cin, N, d->KH * d->KW * (pad16(d->Cout) / 16));
 }
 static size_t dgrad_ws_bytes(const HimConv2d* d) {
   if (wino_fused_dgrad_ok(d)) return wino_fused_panel_floats(d->Cin, d->Cout) * sizeof(float) + 256;
@@ -1011,7 +977,7 @@ static size_t dgrad_ws_bytes(const HimConv2d* d) {
 static size_t dgrad_panel_floats(const HimConv2d* d) {
   if (wino_fused_dgrad_ok(d)) return wino_fused_panel_floats(d->Cin, d->Cout);
   if (wino_dgrad_ok(d)) return (size_t)16 * d->Cin * d->Cout;
-  return (size_t)d->Cin * (use_fast(d->Cin, d->Cout) ? pad16(d->Cout) : d->Cout) * d->KH * d->KW;
+  return (size_t)d->Cin * (use_fast(d->algo, d->Cin, d->Cout) ? pad16(d->Cout) : d->Cout) * d->KH * d->KW;
 }
 // panel == nullptr: regroup the weights into the workspace on every call; build_only: write the panel to ws and return
 static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float* out, const float* bias, int act,
@@ -1035,7 +1001,7 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
   if (wino_dgrad_ok(d) && (build_only || (!bias && act == HIM_ACT_NONE))) {
     float* U = (float*)ws;
     if (!panel) {   // the FORWARD panel: the batched GEMM below reads it transposed (no flipped panel, round 3)
-      hipLaunchKernelGGL((wino_weight_kernel<0>), dim3(cdiv(d->Cin, wino_tblock()), d->Cout), dim3(wino_tblock()), 0, st, w, U, d->Cout,
+      hipLaunchKernelGGL((wino_weight_kernel<0>), dim3(cdiv(d->Cin, wino_tblock(d->algo)), d->Cout), dim3(wino_tblock(d->algo)), 0, st, w, U, d->Cout,
                          d->Cin);
       int rcu = check_launch("wino_weight");
       if (rcu || build_only) return rcu;
@@ -1046,7 +1012,7 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
     float* wsv = U + (size_t)16 * d->Cin * d->Cout;
     float* dpadw = wsv + wino_conv_floats(d->B, d->Cout, d->Cin, GH, GW);
     // reflect: full correlation (offset 2) -> padded gradient -> fold; zero pad: the plain pad-1 correlation
-    int rcw = run_wino_conv(d->B, d->Cout, d->OH, d->OW, d->Cin, GH, GW, rf ? 2 : 1, false, gy, panel ? panel : U,
+    int rcw = run_wino_conv(d->algo, d->B, d->Cout, d->OH, d->OW, d->Cin, GH, GW, rf ? 2 : 1, false, gy, panel ? panel : U,
                             nullptr, HIM_ACT_NONE, 0.f, rf ? dpadw : out, wsv, st, fold, true);
     if (rcw || !rf) return rcw;
     hipLaunchKernelGGL(reflect_fold_kernel, dim3(cdiv((long long)d->H * d->W, 256), d->B * d->Cin), dim3(256), 0, st,
@@ -1056,7 +1022,7 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
   float* Wt = panel ? (float*)panel : (float*)ws;
   const bool dfold = dfold_ok(d);
   const bool refl = d->pad_mode == HIM_PAD_REFLECT && !dfold;
-  const bool fast = use_fast(d->Cin, d->Cout);
+  const bool fast = use_fast(d->algo, d->Cin, d->Cout);
   GConvP g;
   memset(&g, 0, sizeof(g));
   WTransP wt;
@@ -1148,7 +1114,7 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
     rc = check_launch("reflect_extend");
     if (rc) return rc;
   }
-  rc = launch_gconv(g, st);
+  rc = launch_gconv(d->algo, g, st);
   if (rc) return rc;
   if (refl) {
     const long long tot = (long long)d->B * d->Cin * d->H * d->W;
@@ -1185,6 +1151,7 @@ static int adjoint_of(const HimDeconv2d* t, HimConv2d* c) {
   c->OW = t->W;
   c->act = HIM_ACT_NONE;
   c->slope = 0.f;
+  c->algo = t->algo;
   if ((c->H + 2 * c->pad - c->KH) / c->stride + 1 != c->OH || (c->W + 2 * c->pad - c->KW) / c->stride + 1 != c->OW)
     return fail(HIM_E_UNSUPPORTED, "deconv2d: output_padding %d not representable", t->out_pad);
   return check_conv(c);
@@ -1198,18 +1165,56 @@ using namespace him;
 
 extern "C" {
 
-int him_set_winograd_min_channels(int c) {
-  const int prev = wino_min_c();
-  g_wino_min_c = c > 0 ? c : -1;
-  return prev;
+void him_algo_resolve(const HimAlgo* in, HimAlgo* out) {
+  if (!out) return;
+  HimAlgo z;
+  memset(&z, 0, sizeof(z));
+  const HimAlgo& a = in ? *in : z;
+  HimAlgo r = a;
+  r.wino_min_c = algo_wino_min_c(a);
+  r.wino_fused_min_c = algo_wino_fused_min_c(a);
+  r.wino_fused_max_c = algo_wino_fused_max_c(a);
+  r.wino4_min_c = algo_wino4_min_c(a);
+  r.ksplit_max = algo_off(a, HIM_ALGO_NO_SPLITK) ? 1 : algo_ksplit_max(a);
+  r.tile_wb = a.tile_wb == HIM_TILE_DEFAULT ? HIM_TILE_64x128 : a.tile_wb;
+  r.tile_nb = a.tile_nb == HIM_TILE_DEFAULT ? HIM_TILE_64x128 : a.tile_nb;
+  r.wino_tblock = algo_tblock(a);
+  *out = r;
 }
 
-int him_winograd_gemm(const float* a, const float* b, float* c, int M, int K, int N, void* stream) {
+// The ONE place the library touches the environment (tools/ A/B runs: env -> HimAlgo -> descriptors).
+void him_algo_from_env(HimAlgo* a) {
+  if (!a) return;
+  memset(a, 0, sizeof(*a));
+  auto geti = [](const char* k, int dflt) { const char* e = getenv(k); return e ? atoi(e) : dflt; };
+  a->wino_min_c = getenv("HIM_NO_WINOGRAD") ? -1 : geti("HIM_WINO_MIN_C", 0);
+  a->wino_fused_min_c = getenv("HIM_NO_WINO_FUSED") ? -1 : geti("HIM_WINO_FUSED_MIN_C", 0);
+  a->wino_fused_max_c = geti("HIM_WINO_FUSED_MAX_C", 0);
+  a->wino4_min_c = getenv("HIM_NO_WINO4") ? -1 : geti("HIM_WINO4_MIN_C", 0);
+  a->ksplit_max = geti("HIM_KSPLIT_MAX", 0);
+  const int tile_all = geti("HIM_GCONV_TILE", 0);
+  a->tile_wb = geti("HIM_GCONV_TILE_WB", tile_all);
+  a->tile_nb = geti("HIM_GCONV_TILE_NB", tile_all);
+  a->wino_tblock = geti("HIM_WINO_TBLOCK", 0);
+  a->wgrad_splits = geti("HIM_WGRAD_SPLITS", 0);
+  const struct { const char* k; unsigned bit; } flags[] = {
+      {"HIM_NO_SPLITK", HIM_ALGO_NO_SPLITK},           {"HIM_NO_DFOLD", HIM_ALGO_NO_DFOLD},
+      {"HIM_WINO_PADDED_DGRAD", HIM_ALGO_WINO_PADDED_DGRAD}, {"HIM_NO_SMALL_WIN", HIM_ALGO_NO_SMALL_WIN},
+      {"HIM_NO_FEWOUT_TILED", HIM_ALGO_NO_FEWOUT_TILED}, {"HIM_NO_FEWIN_TILED", HIM_ALGO_NO_FEWIN_TILED},
+      {"HIM_NO_FEWCH_MFMA", HIM_ALGO_NO_FEWCH_MFMA},   {"HIM_GENERIC_CONV", HIM_ALGO_GENERIC_CONV},
+      {"HIM_NO_RESBLOCK_FUSED", HIM_ALGO_NO_RESBLOCK_FUSED}, {"HIM_NO_BGEMM", HIM_ALGO_NO_BGEMM}};
+  for (const auto& f : flags)
+    if (getenv(f.k)) a->disable |= f.bit;
+}
+
+int him_winograd_gemm(const float* a, const float* b, float* c, int M, int K, int N, const HimAlgo* algo, void* stream) {
   if (!a || !b || !c || M <= 4 || K < 16 || (K % 16) || N <= 0 || (N % 128))
     return fail(HIM_E_INVALID, "winograd gemm: need M > 4, K %% 16 == 0, N %% 128 == 0 (got %d, %d, %d)", M, K, N);
   if ((long long)16 * K * N >= (1ll << 31) || (long long)16 * M * N >= (1ll << 31))
     return fail(HIM_E_UNSUPPORTED, "winograd gemm: operand larger than 2^31 elements");
-  return wino_batched_gemm(a, b, c, M, K, N, (hipStream_t)stream);
+  HimAlgo z;
+  memset(&z, 0, sizeof(z));
+  return wino_batched_gemm(algo ? *algo : z, a, b, c, M, K, N, (hipStream_t)stream);
 }
 
 size_t him_conv2d_fwd_ws(const HimConv2d* d) { return d ? fprop_ws_bytes(d) : 0; }
@@ -1294,7 +1299,7 @@ int him_conv2d_bwd_data_gated(const HimConv2d* d, const float* dy, const float* 
 }
 
 size_t him_conv2d_bwd_weight_ws(const HimConv2d* d) {
-  return d ? wgrad_ws_bytes(d->Cout, d->Cin, d->KH, d->KW, d->B * d->OH * d->OW, d->Cout, conv_wino_wgrad_floats(d)) : 0;
+  return d ? wgrad_ws_bytes(d->algo, d->Cout, d->Cin, d->KH, d->KW, d->B * d->OH * d->OW, d->Cout, conv_wino_wgrad_floats(d)) : 0;
 }
 
 int him_conv2d_bwd_weight(const HimConv2d* d, const float* x, const float* dy, float* dw, float* dbias,
@@ -1302,12 +1307,12 @@ int him_conv2d_bwd_weight(const HimConv2d* d, const float* x, const float* dy, f
   int rc = check_conv(d);
   if (rc) return rc;
   if (dw) {
-    rc = run_wgrad(dy, x, dw, d->Cout, d->Cin, d->B, d->H, d->W, d->OH, d->OW, d->KH, d->KW, d->stride, d->pad,
+    rc = run_wgrad(d->algo, dy, x, dw, d->Cout, d->Cin, d->B, d->H, d->W, d->OH, d->OW, d->KH, d->KW, d->stride, d->pad,
                    d->pad_mode, accumulate, ws, ws_bytes, (hipStream_t)stream);
     if (rc) return rc;
   }
   if (dbias) {
-    const size_t off = wgrad_slab_bytes(d->Cout, d->Cin, d->KH, d->KW, d->B * d->OH * d->OW, conv_wino_wgrad_floats(d));
+    const size_t off = wgrad_slab_bytes(d->algo, d->Cout, d->Cin, d->KH, d->KW, d->B * d->OH * d->OW, conv_wino_wgrad_floats(d));
     if (ws_bytes < off) return fail(HIM_E_WORKSPACE, "bwd_weight ws too small");
     rc = run_bias_grad(dy, dbias, d->B, d->Cout, d->OH * d->OW, accumulate, (char*)ws + off, ws_bytes - off,
                        (hipStream_t)stream);
@@ -1409,8 +1414,8 @@ int him_conv2d_onehot_bwd_weight(const HimConv2d* d, const float* label, int n_o
       float* wws = dwd + ((size_t)d->Cout * Cd * KK + 63) / 64 * 64;
       rc = him_copy_channels(x, d->Cin, NC, xd, Cd, 0, Cd, d->B, HW, nullptr, 0, 0, stream);
       if (rc) return rc;
-      rc = run_wgrad(dy, xd, dwd, d->Cout, Cd, d->B, d->H, d->W, d->OH, d->OW, d->KH, d->KW, d->stride, d->pad,
-                     d->pad_mode, 0, wws, wgrad_slab_bytes(d->Cout, Cd, d->KH, d->KW, d->B * d->OH * d->OW), st);
+      rc = run_wgrad(d->algo, dy, xd, dwd, d->Cout, Cd, d->B, d->H, d->W, d->OH, d->OW, d->KH, d->KW, d->stride, d->pad,
+                     d->pad_mode, 0, wws, wgrad_slab_bytes(d->algo, d->Cout, Cd, d->KH, d->KW, d->B * d->OH * d->OW), st);
       if (rc) return rc;
       hipLaunchKernelGGL(onehot_dense_w_kernel, dim3(cdiv((long long)d->Cout * Cd * KK, 256)), dim3(256), 0, st, dw, dwd,
                          d->Cout, d->Cin, NC, KK, 1, accumulate);
@@ -1491,7 +1496,7 @@ int him_deconv2d_bwd_data_panel(const HimDeconv2d* t, const float* dy, const voi
 size_t him_deconv2d_bwd_weight_ws(const HimDeconv2d* t) {
   HimConv2d c;
   if (adjoint_of(t, &c)) return 0;
-  return wgrad_ws_bytes(c.Cout, c.Cin, c.KH, c.KW, c.B * c.OH * c.OW, t->Cout);
+  return wgrad_ws_bytes(c.algo, c.Cout, c.Cin, c.KH, c.KW, c.B * c.OH * c.OW, t->Cout);
 }
 
 int him_deconv2d_bwd_weight(const HimDeconv2d* t, const float* x, const float* dy, float* dw, float* dbias,
@@ -1501,12 +1506,12 @@ int him_deconv2d_bwd_weight(const HimDeconv2d* t, const float* x, const float* d
   if (rc) return rc;
   // adjoint conv: "input" = deconv output gradient dy, "output gradient" = deconv input x
   if (dw) {
-    rc = run_wgrad(x, dy, dw, c.Cout, c.Cin, c.B, c.H, c.W, c.OH, c.OW, c.KH, c.KW, c.stride, c.pad, HIM_PAD_ZERO,
+    rc = run_wgrad(c.algo, x, dy, dw, c.Cout, c.Cin, c.B, c.H, c.W, c.OH, c.OW, c.KH, c.KW, c.stride, c.pad, HIM_PAD_ZERO,
                    accumulate, ws, ws_bytes, (hipStream_t)stream);
     if (rc) return rc;
   }
   if (dbias) {
-    const size_t off = wgrad_slab_bytes(c.Cout, c.Cin, c.KH, c.KW, c.B * c.OH * c.OW);
+    const size_t off = wgrad_slab_bytes(c.algo, c.Cout, c.Cin, c.KH, c.KW, c.B * c.OH * c.OW);
     if (ws_bytes < off) return fail(HIM_E_WORKSPACE, "bwd_weight ws too small");
     rc = run_bias_grad(dy, dbias, t->B, t->Cout, t->OH * t->OW, accumulate, (char*)ws + off, ws_bytes - off,
                        (hipStream_t)stream);

@@ -246,12 +246,6 @@ __global__ __launch_bounds__(G > 256 ? G : 256) void instnorm_bwd_kernel(const f
 
 using namespace him;
 
-static bool big_plane_256() {   // A/B switch: HIM_IN_BIG_256=1 keeps the 256-thread kernel on the full-resolution planes
-  static int v = -1;
-  if (v < 0) v = getenv("HIM_IN_BIG_256") ? 1 : 0;
-  return v != 0;
-}
-
 extern "C" {
 
 int him_instnorm_fwd(const float* x, const float* residual, float* y, float* mean, float* rstd, int planes,
@@ -264,7 +258,7 @@ int him_instnorm_fwd(const float* x, const float* residual, float* y, float* mea
   } else if (hw <= 4096) {
     hipLaunchKernelGGL((instnorm_fwd_kernel<256, 16>), dim3(planes), dim3(256), 0, st, x, residual, y, mean,
                        rstd, planes, hw, eps, act, slope);
-  } else if (hw < 32768 || big_plane_256()) {
+  } else if (hw < 32768) {
     hipLaunchKernelGGL((instnorm_fwd_kernel<256, 0>), dim3(planes), dim3(256), 0, st, x, residual, y, mean, rstd,
                        planes, hw, eps, act, slope);
   } else {
@@ -284,7 +278,7 @@ int him_instnorm_bwd(const float* x, const float* mean, const float* rstd, const
   } else if (hw <= 4096) {
     hipLaunchKernelGGL((instnorm_bwd_kernel<256, 16>), dim3(planes), dim3(256), 0, st, x, mean, rstd, dy, dx,
                        planes, hw, act, slope);
-  } else if (hw < 32768 || big_plane_256()) {
+  } else if (hw < 32768) {
     hipLaunchKernelGGL((instnorm_bwd_kernel<256, 0>), dim3(planes), dim3(256), 0, st, x, mean, rstd, dy, dx,
                        planes, hw, act, slope);
   } else {

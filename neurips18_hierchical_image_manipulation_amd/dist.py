@@ -60,10 +60,18 @@ class GradReducer(object):
     ``ranges``  list of (start, end) element ranges, one per parameter, in FORWARD order.
     """
 
-    def __init__(self, flat, ranges, bucket_bytes=64 << 20, group=None, force=False):
+    def __init__(self, flat, ranges, bucket_bytes=64 << 20, group=None, force=False, comm_stream=None, fake=False):
+        """``comm_stream``: the stream the collectives are enqueued on (default: a stream of this reducer's own).  The
+        trainers pass their optimizer streams -- idle during the backward pass, and the optimizer step that follows the
+        exchange runs there anyway -- so that N > 1 ranks run the SAME number of streams / hardware queues as one rank
+        (the step sits at the hardware-queue cliff documented in DESIGN.md: one more queue costs 10 ms per step).
+        ``fake``: single-GPU stand-in for the exchange (bench.py --fake-comm): every bucket is a device-to-device copy of
+        its bytes on the comm stream at the real trigger point -- the scheduling and HBM cost of the exchange without a
+        second GPU; gradients are left untouched."""
         self.flat, self.group = flat, group
+        self.fake = bool(fake)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.active = self.world > 1 or (force and dist.is_initialized())   # force: exercise the path on 1 rank
+        self.active = self.fake or self.world > 1 or (force and dist.is_initialized())   # force: exercise the path on 1 rank
         self.ranges = list(ranges)
         self.range_to_bucket = {}
         self.buckets = []            # (start, end, n_params) ; bucket 0 = LAST parameters (first ready in backward)
@@ -82,7 +90,8 @@ class GradReducer(object):
         if start is not None:
             self.buckets.append((start, end, n))
         self.on_gpu = flat.is_cuda
-        self.comm_stream = torch.cuda.Stream(device=flat.device) if self.on_gpu else None
+        self.comm_stream = (comm_stream or torch.cuda.Stream(device=flat.device)) if self.on_gpu else None
+        self.scratch = torch.empty(min(cap, flat.numel()) + 64, dtype=flat.dtype, device=flat.device) if self.fake else None
         self.pending = [0] * len(self.buckets)
         self.launched = [True] * len(self.buckets)
         self.works = []
@@ -132,12 +141,20 @@ class GradReducer(object):
             ev.record(torch.cuda.current_stream())
             # a bucket can hold gradients written on two streams (conv weight gradients on the side stream, BatchNorm
             # gamma / beta on the main one): the exchange waits for the triggering stream AND the side stream
-            from .ops import wgrad_streams
+            from .ops import wgrad_waitables
+            streams, events = wgrad_waitables(self.flat.device)
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
-                for side in wgrad_streams(self.flat.device):
+                for side in streams:
                     self.comm_stream.wait_stream(side)
-                if dist.get_backend(self.group) == 'nccl':       # RCCL: averaging collective
+                for done in events:
+                    self.comm_stream.wait_event(done)
+                if self.fake:                                    # stand-in: move the bucket's bytes once, on the comm stream
+                    n = e - s
+                    for o in range(0, n, self.scratch.numel()):
+                        m = min(self.scratch.numel(), n - o)
+                        self.scratch[:m].copy_(view[o:o + m])
+                elif dist.get_backend(self.group) == 'nccl':     # RCCL: averaging collective
                     dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group)
                 else:                                            # gloo on device tensors (tests): no AVG op
                     dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
@@ -204,20 +221,25 @@ def replica_checksum_equal(model):
     return bool(torch.equal(lo, hi))
 
 
-def attach_data_parallel(model, bucket_bytes=64 << 20, force=False, broadcast=True):
+def attach_data_parallel(model, bucket_bytes=64 << 20, force=False, broadcast=True, fake=False):
     """Give a mask2image / box2mask model per-network reducers (no-op for world size 1 unless ``force``).
     Rank 0's parameters / Adam state / buffers are broadcast first (see ``broadcast_replica_state``).
     BatchNorm layers keep per-rank batch statistics (the reference's DataParallel behaviour); only gradients are averaged."""
-    if not dist.is_initialized() or (dist.get_world_size() <= 1 and not force):
+    if not fake and (not dist.is_initialized() or (dist.get_world_size() <= 1 and not force)):
         return model
-    if broadcast and dist.get_world_size() > 1:
+    if broadcast and dist.is_initialized() and dist.get_world_size() > 1:
         broadcast_replica_state(model)
+    from . import ops
     for tag in ('G', 'D'):
         opt = getattr(model, 'optimizer_' + tag, None)   # box2mask trainer: optimizer_G is its ``optimizer``
         if opt is None:
             continue
         arena = opt.arena
-        red = GradReducer(arena.grad, [p._him_arena_range for p in arena.params], bucket_bytes, force=force)
+        # the collectives ride on the network's optimizer stream (see GradReducer): no extra stream for N > 1
+        dev = arena.grad.device
+        comm = (ops._opt_stream(dev) if tag == 'G' else ops._d_opt_stream(dev)) if arena.grad.is_cuda else None
+        red = GradReducer(arena.grad, [p._him_arena_range for p in arena.params], bucket_bytes, force=force,
+                          comm_stream=comm, fake=fake)
         red.attach(arena.params)
         setattr(model, 'reducer_' + tag, red)
     return model

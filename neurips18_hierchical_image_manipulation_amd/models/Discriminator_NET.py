@@ -72,11 +72,11 @@ class MultiscaleDiscriminator(nn.Module):
 
     def forward(self, input):
         if isinstance(input, ops.CondImage):
-            if _SCALE_STREAMS and self.num_D > 1:
+            if SCHED.d_scale_streams and self.num_D > 1:
                 input = input.cat()
             else:
                 return self._forward_split(input)
-        if _SCALE_STREAMS and input.is_cuda and self.num_D > 1:
+        if SCHED.d_scale_streams and input.is_cuda and self.num_D > 1:
             return self._forward_streams(input)
         result, x = [], input
         for i in range(self.num_D):
@@ -111,7 +111,7 @@ class MultiscaleDiscriminator(nn.Module):
         return result
 
 
-_SCALE_STREAMS = os.environ.get('HIM_D_SCALE_STREAMS', '0') != '0'
+from ..config import SCHED     # noqa: E402
 _STREAMS = {}
 
 

@@ -43,7 +43,7 @@ def _conv(l, x, pad_mode='zero', pad=None, norm=None):
     """``norm``: the normalisation applied right behind this conv; its mean subtraction makes the bias gradient exactly
     zero (see nn.run_layers), so the bias-gradient pass is skipped."""
     b = _pw(l.bias)
-    if b is not None and hn._DEAD_BIAS_SKIP and (isinstance(norm, InstanceNorm2d) or
+    if b is not None and hn.SCHED.dead_bias_skip and (isinstance(norm, InstanceNorm2d) or
                                                  (isinstance(norm, BatchNorm2d) and norm.training)):
         l.bias._him_dead_grad = True
         b = b.detach()
@@ -91,7 +91,7 @@ class DeconvResnetBlock(nn.Module):
         res = ops.upsample_bilinear2(res, self.shortcut[-1].align_corners)
         d = self.deep[1]
         b, nrm = _pw(d.bias), self.deep[2]
-        if b is not None and hn._DEAD_BIAS_SKIP and (isinstance(nrm, InstanceNorm2d) or nrm.training):
+        if b is not None and hn.SCHED.dead_bias_skip and (isinstance(nrm, InstanceNorm2d) or nrm.training):
             d.bias._him_dead_grad = True
             b = b.detach()
         elif b is not None and getattr(d.bias, '_him_dead_grad', False):

@@ -27,7 +27,7 @@ class GANLoss(nn.Module):
 
 
 # ReLU backward of the VGG chain folded into the kernels that produce the gradients (see Vgg19.forward); 0 = separate passes
-_GATED = os.environ.get('HIM_VGG_GATED', '1') != '0'
+from ..config import SCHED
 
 
 class VGGLoss(nn.Module):
@@ -45,7 +45,7 @@ class VGGLoss(nn.Module):
             return self.vgg(y)
 
     def forward(self, x, y, y_vgg=None):
-        gated = _GATED and x.requires_grad
+        gated = SCHED.vgg_gated and x.requires_grad
         x_vgg = self.vgg(x, gated=gated)
         if y_vgg is None:
             y_vgg = self.target_features(y)

@@ -13,20 +13,16 @@ import numpy as np
 import torch
 
 from .. import ops, synth
+from ..config import SCHED
 from ..nn import frozen_params
 from ..optim import FusedAdam
 from .base_model import BaseModel
 
 NULLVAL = 0.0
-_D_WGRAD_ROUTES = os.environ.get('HIM_D_WGRAD_ROUTES', '1') != '0'
-_REAL_FIRST = os.environ.get('HIM_REAL_FIRST', '0') != '0'
-_D_FIRST = os.environ.get('HIM_D_BACKWARD_FIRST', '1') != '0'
-_VGG_STREAM = os.environ.get('HIM_VGG_STREAM', '1') != '0'
-_D_SPLIT_INPUT = os.environ.get('HIM_D_SPLIT_INPUT', '1') != '0'
-# A/B switch, off: VGG's backward started on its stream BEFORE loss_D.backward() instead of behind it (see
-# optimize_parameters) -- removes a 5.4 ms window in which only the VGG stream works, and costs 0.7 ms per step (60.2 vs
-# 59.5 ms, three repetitions): the fused-Winograd kernels use the chip well alone and slow D's backward when they share it.
-_VGG_BWD_EARLY = os.environ.get('HIM_VGG_BACKWARD_EARLY', '0') != '0'
+# Schedule switches live in config.SCHED (run-time object; defaults = the shipped schedule).  vgg_backward_early (off):
+# VGG's backward started on its stream BEFORE loss_D.backward() instead of behind it (see optimize_parameters) -- removes a
+# 5.4 ms window in which only the VGG stream works, and costs 0.7 ms per step (60.2 vs 59.5 ms, three repetitions): the
+# fused-Winograd kernels use the chip well alone and slow D's backward when they share it.
 
 
 class ImagePool(object):
@@ -200,7 +196,7 @@ class Pix2PixHDModel_condImg(BaseModel):
         """True when the discriminators get (condition, image) as an ``ops.CondImage`` pair instead of their concatenation:
         no mask on the input, no image pool (it stores concatenated tensors), a condition at all."""
         ctx_only = self.opt.netG == 'global_twostream' and self.opt.which_encoder == 'ctx'
-        return _D_SPLIT_INPUT and not ctx_only and not self.mask_gan_input and self.opt.pool_size == 0
+        return SCHED.d_split_input and not ctx_only and not self.mask_gan_input and self.opt.pool_size == 0
 
     def _d_input(self, cond, image, mask):
         if self.opt.netG == 'global_twostream' and self.opt.which_encoder == 'ctx':
@@ -219,7 +215,7 @@ class Pix2PixHDModel_condImg(BaseModel):
         """D(real) + LSGAN loss and VGG(real) on the side stream (None when disabled).  ``inputs_ready``: event recorded
         on the main stream right after the input encoding -- the side stream waits for THAT, not for whatever the caller
         has enqueued on the main stream since (the generator forward)."""
-        if os.environ.get('HIM_REAL_AHEAD', '1') == '0':
+        if not SCHED.real_ahead:
             return None
         main = torch.cuda.current_stream(self.device)
         side = ops._real_stream(self.device)
@@ -281,21 +277,25 @@ class Pix2PixHDModel_condImg(BaseModel):
             ahead = self._real_branch_ahead(netD_cond, real_image, mask_cond, inputs_ready)
             self._wait_g_update()
             fake_image = self._generate(buf, input_mask, cond_image, mask_in)
-        elif _REAL_FIRST:      # A/B switch: round 2's issue order
+        elif SCHED.real_first:      # A/B switch: round 2's issue order
             ahead = self._real_branch_ahead(netD_cond, real_image, mask_cond, inputs_ready)
             fake_image = self._generate(buf, input_mask, cond_image, mask_in)
         else:
             fake_image = self._generate(buf, input_mask, cond_image, mask_in)
             ahead = self._real_branch_ahead(netD_cond, real_image, mask_cond, inputs_ready)
         if ahead is not None:
-            torch.cuda.current_stream(self.device).wait_stream(ahead['stream'])
+            from ..dist import timed_wait
+            # timed (bench.py exposed_comm_ms): the real-image stream waited for D's exchange + Adam inside
+            # _real_branch_ahead ('d_update_wait_real'); what of that reaches the step is bounded by this join
+            timed_wait(torch.cuda.current_stream(self.device), ahead['stream'],
+                       self.comm_timing['real_branch_join'] if self.comm_timing else None)
         if self.isTrain:
             self._wait_d_update()          # the previous step's D exchange + Adam (own stream) end before D is read here
             self._d_update_pending = False
         # VGG(fake) is independent of the discriminator passes on the fake image: it runs on a stream of its own next to
         # them (the small PatchGAN scales leave most of the chip idle); autograd replays its backward on that stream too.
         vgg_side = None
-        if not opt.no_vgg_loss and _VGG_STREAM:
+        if not opt.no_vgg_loss and SCHED.vgg_stream:
             main_s = torch.cuda.current_stream(self.device)
             vs = ops._vgg_stream(self.device)
             vs.wait_stream(main_s)
@@ -430,7 +430,7 @@ class Pix2PixHDModel_condImg(BaseModel):
         wg = ops._vgg_stream(self.device)
         routes = {main: wg, ops._real_stream(self.device): wg}
         try:
-            with ops.route_wgrads(routes if (_D_WGRAD_ROUTES and not first) else {}):
+            with ops.route_wgrads(routes if (SCHED.d_wgrad_routes and not first) else {}):
                 self.loss_D.backward(retain_graph=shared and first)
         finally:
             ops.SKIP_DGRAD.difference_update(self._d_first_weight_ids)
@@ -467,8 +467,8 @@ class Pix2PixHDModel_condImg(BaseModel):
                   mask_out=data['mask_out'], infer=infer)
         if 'obj_mask' in data:
             kw['obj_mask'] = data['obj_mask']
-        self._share_fake_pass = os.environ.get('HIM_SHARE_FAKE_PASS', '1') != '0'
-        self._vgg_bwd_early = _VGG_BWD_EARLY and _D_FIRST and not self.opt.no_gan
+        self._share_fake_pass = SCHED.share_fake_pass
+        self._vgg_bwd_early = SCHED.vgg_backward_early and SCHED.d_backward_first and not self.opt.no_gan
         self._vgg_early = None
         try:
             losses, generated = self.forward(**kw)
@@ -487,7 +487,7 @@ class Pix2PixHDModel_condImg(BaseModel):
         main = torch.cuda.current_stream(self.device)
         opt_stream = ops._opt_stream(self.device)
         from ..dist import timed_wait
-        if gan and _D_FIRST:
+        if gan and SCHED.d_backward_first:
             # loss_D.backward() FIRST.  Its graph hangs off the discriminator passes only (the fake is detached / gated), so
             # it can start as soon as those are enqueued: its data-gradient chains (main stream / real-image stream) and
             # weight gradients (weight-gradient stream) then fill the window in which the main stream otherwise waits for
@@ -581,13 +581,15 @@ class Pix2PixHDModel_condImg(BaseModel):
         """Make ``stream`` (default: the current one) wait for a discriminator update still running on its own stream."""
         if getattr(self, '_d_update_pending', False):
             from ..dist import timed_wait
+            key = 'd_update_wait' if stream is None else 'd_update_wait_real'
             timed_wait(stream or torch.cuda.current_stream(self.device), ops._d_opt_stream(self.device),
-                       self.comm_timing['d_update_wait'] if (self.comm_timing and stream is None) else None)
+                       self.comm_timing[key] if self.comm_timing else None)
 
     def start_comm_timing(self):
         """From now on every wait of a compute stream for the gradient exchange / a deferred optimizer step is bracketed
         by timing events (dist.timed_wait).  ``read_comm_timing`` turns them into milliseconds per step."""
-        self.comm_timing = {'g_update_tail': [], 'd_update_wait': [], 'g_exchange_wait': [], 'd_exchange_wait': []}
+        self.comm_timing = {'g_update_tail': [], 'd_update_wait': [], 'g_exchange_wait': [], 'd_exchange_wait': [],
+                            'd_update_wait_real': [], 'real_branch_join': []}
         if self.reducer_G is not None:
             self.reducer_G.timing = self.comm_timing['g_exchange_wait']
         if self.reducer_D is not None:
@@ -597,7 +599,9 @@ class Pix2PixHDModel_condImg(BaseModel):
         """ms per step a stream sat idle: ``g_exchange_wait`` = the optimizer stream waiting for G's all-reduce after
         the last weight gradient; ``g_update_tail`` = the main stream, after loss_D.backward(), waiting for G's exchange +
         Adam; ``d_exchange_wait`` = D's update stream waiting for D's all-reduce; ``d_update_wait`` = the NEXT step's
-        discriminator pass waiting for D's exchange + Adam.  Only the two main-stream figures delay the step."""
+        discriminator pass waiting for D's exchange + Adam on the MAIN stream -- normally ~0, because the real-image
+        stream has already waited for it: ``d_update_wait_real`` = that stream's idle time, of which at most
+        ``real_branch_join`` (the main stream waiting for the real-image branch, compute included) reaches the step."""
         torch.cuda.synchronize(self.device)
         out = {k: round(sum(a.elapsed_time(b) for a, b in v) / max(steps, 1), 4) for k, v in self.comm_timing.items()}
         self.comm_timing = None

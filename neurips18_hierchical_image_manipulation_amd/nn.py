@@ -20,7 +20,7 @@ class _Frozen(object):
     on = False
 
 
-_DEAD_BIAS_SKIP = os.environ.get('HIM_DEAD_BIAS_GRAD') is None     # set HIM_DEAD_BIAS_GRAD=1 to compute them anyway
+from .config import SCHED     # SCHED.dead_bias_skip = False computes the dead bias gradients anyway
 
 
 @contextlib.contextmanager
@@ -164,7 +164,7 @@ def run_layers(layers, x, final_residual=None, relu_gated=None):
             slope = getattr(act, 'slope', 0.0) if act is not None else 0.0
             epi = 'none' if norm is not None else aname
             w, b = l.effective_weight(), _pw(l.bias)
-            if b is not None and _DEAD_BIAS_SKIP and (isinstance(norm, InstanceNorm2d) or
+            if b is not None and SCHED.dead_bias_skip and (isinstance(norm, InstanceNorm2d) or
                                                       (isinstance(norm, BatchNorm2d) and norm.training)):
                 # A bias in front of a normalisation that subtracts the plane (batch) mean cancels exactly: its true
                 # gradient is identically zero and what autograd would produce is rounding noise (1e-9 of the net's
@@ -236,8 +236,9 @@ class ResnetBlock(nn.Module):
     def forward(self, x):
         cb = self.conv_block
         c1, c2 = cb[1], cb[5]
-        if (_DEAD_BIAS_SKIP and type(c1) is Conv2d and type(c2) is Conv2d and not _Frozen.on
-                and ops.resblock_supported(x, c1.weight, c2.weight)):
+        if (SCHED.dead_bias_skip and type(c1) is Conv2d and type(c2) is Conv2d and not _Frozen.on
+                and type(cb[2]) is InstanceNorm2d and type(cb[6]) is InstanceNorm2d and cb[2].eps == cb[6].eps
+                and type(cb[3]) is ReLU and ops.resblock_supported(x, c1.weight, c2.weight)):
             # the 1024-channel stack: both InstanceNorms ride in the Winograd transforms of the two convolutions
             for c in (c1, c2):
                 if c.bias is not None:

@@ -9,13 +9,15 @@ Weight gradients: parameters that live in a flat gradient arena (``optim.FlatAre
 of the arena, zeroed by ``zero_grad``) and autograd receives ``None`` -- no per-parameter add pass and no
 bucket copies for the RCCL all-reduce.
 """
+import contextlib
 import ctypes
 import os
+import threading
 
 import torch
 
-from ._cabi import (lib, HimConv2d, HimDeconv2d, HimResBlock, ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID, PAD_ZERO,
-                    PAD_REFLECT, HimError)
+from ._cabi import (lib, HimAlgo, HimConv2d, HimDeconv2d, HimResBlock, ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID,
+                    PAD_ZERO, PAD_REFLECT, HimError)
 
 ACTS = {'none': ACT_NONE, 'relu': ACT_RELU, 'lrelu': ACT_LRELU, 'tanh': ACT_TANH, 'sigmoid': ACT_SIGMOID}
 
@@ -54,7 +56,7 @@ def _direct(p):
 # other's partial last waves (every launch here has an imperfect tile count for 256 CUs).  ``join_side_stream`` makes
 # the current stream wait for them (called by FusedAdam.step / zero_grad and the reducer).
 _SIDE = {}
-_SIDE_ON = os.environ.get('HIM_WGRAD_STREAM', '1') != '0'
+from .config import SCHED
 
 
 def _side_stream(device):
@@ -117,27 +119,35 @@ def _d_opt_stream(device):
 # on the side stream, where its forward ran) then each get a weight-gradient stream of their own instead of queueing all
 # of D's weight gradients behind the generator's on the single side stream.
 _WGRAD_ROUTE = {}      # cuda_stream handle of the issuing stream -> torch.cuda.Stream that takes its weight gradients
-_WGRAD_USED = {}       # device -> set of extra streams that carried weight gradients since the last join
+# device -> {routed stream handle: event recorded behind the LAST weight-gradient launch routed there}.  Joins wait for
+# the EVENT, not for the stream: a routed stream (the VGG stream) goes on to carry other work, and neither the optimizers
+# nor the reducers should wait for that (an entry whose launches have finished costs a join nothing).
+_WGRAD_USED = {}
 
 
 class route_wgrads(object):
+    """Route the weight gradients issued from the given streams; restores the previous routes on exit (nestable)."""
+
     def __init__(self, routes):
         self.routes = {src.cuda_stream: dst for src, dst in routes.items()}
 
     def __enter__(self):
+        self.saved = {k: _WGRAD_ROUTE.get(k) for k in self.routes}
         _WGRAD_ROUTE.update(self.routes)
 
     def __exit__(self, *a):
-        for k in self.routes:
-            _WGRAD_ROUTE.pop(k, None)
+        for k, prev in self.saved.items():
+            if prev is None:
+                _WGRAD_ROUTE.pop(k, None)
+            else:
+                _WGRAD_ROUTE[k] = prev
         return False
 
 
-def wgrad_streams(device):
-    """Every stream that may hold unfinished weight-gradient launches of ``device``."""
-    out = [s for dev, s in _SIDE.items() if dev == device]
-    out += list(_WGRAD_USED.get(device, ()))
-    return out
+def wgrad_waitables(device):
+    """What a consumer of ``device``'s weight gradients must wait for: the side stream, and the event behind the last
+    launch on every stream weight gradients were routed to.  -> (streams, events)"""
+    return ([s for dev, s in _SIDE.items() if dev == device], list(_WGRAD_USED.get(device, {}).values()))
 
 
 def join_side_stream(device=None):
@@ -147,9 +157,8 @@ def join_side_stream(device=None):
     for dev, used in _WGRAD_USED.items():
         if device is None or dev == device:
             cur = torch.cuda.current_stream(dev)
-            for s in used:
-                if s.cuda_stream != cur.cuda_stream:
-                    cur.wait_stream(s)
+            for ev in used.values():
+                cur.wait_event(ev)
 
 
 class _wgrad_stream(object):
@@ -160,15 +169,16 @@ class _wgrad_stream(object):
         self.tensors = [t for t in tensors if t is not None]
 
     def __enter__(self):
-        if not _SIDE_ON:
+        self.on = SCHED.wgrad_stream
+        if not self.on:
             return None
         dev = self.tensors[0].device
         main = torch.cuda.current_stream(dev)
         side = _WGRAD_ROUTE.get(main.cuda_stream)
+        self.routed = side is not None
         if side is None:
             side = _side_stream(dev)
-        else:
-            _WGRAD_USED.setdefault(dev, set()).add(side)
+        self.side, self.dev = side, dev
         side.wait_stream(main)
         for t in self.tensors:
             t.record_stream(side)
@@ -177,7 +187,11 @@ class _wgrad_stream(object):
         return side
 
     def __exit__(self, *a):
-        if _SIDE_ON:
+        if self.on:
+            if self.routed:
+                ev = torch.cuda.Event()
+                ev.record(self.side)
+                _WGRAD_USED.setdefault(self.dev, {})[self.side.cuda_stream] = ev
             self.ctx.__exit__(*a)
         return False
 
@@ -223,14 +237,66 @@ def _notify(p):
 # ------------------------------------------------------------------------------------------------
 # convolution
 # ------------------------------------------------------------------------------------------------
-def _conv_desc(x, w, stride, pad, pad_mode, act, slope):
+# Kernel selection (include/him.h "Algorithm selection"): the library keeps no global state -- every descriptor carries a
+# HimAlgo.  This module keeps ONE current HimAlgo per host thread (``current_algo``): the process default is read from
+# the HIM_* environment once at import through ``him_algo_from_env`` (tools/ A/B runs; an empty environment = the
+# defaults), ``algo_scope`` / ``set_winograd_min_channels`` change the calling thread's copy.
+_ALGO_TLS = threading.local()
+_ALGO_DEFAULT = None
+
+
+def _default_algo():
+    global _ALGO_DEFAULT
+    if _ALGO_DEFAULT is None:
+        a = HimAlgo()
+        lib.him_algo_from_env(ctypes.byref(a))
+        _ALGO_DEFAULT = a
+    return _ALGO_DEFAULT
+
+
+def current_algo():
+    """The calling thread's HimAlgo (a live object: descriptors COPY it when they are built)."""
+    a = getattr(_ALGO_TLS, 'algo', None)
+    if a is None:
+        a = _ALGO_TLS.algo = HimAlgo.from_buffer_copy(_default_algo())
+    return a
+
+
+def resolved_algo(algo=None):
+    """dict of the concrete values a HimAlgo selects (zeros replaced by the library's defaults) -- for reports."""
+    out = HimAlgo()
+    lib.him_algo_resolve(ctypes.byref(algo if algo is not None else current_algo()), ctypes.byref(out))
+    return out.as_dict()
+
+
+@contextlib.contextmanager
+def algo_scope(**fields):
+    """Temporarily override fields of the calling thread's HimAlgo, e.g. ``algo_scope(wino_min_c=-1)`` (direct form),
+    ``algo_scope(ksplit_max=4)``, ``algo_scope(disable=ALGO_NO_FEWCH_MFMA)``."""
+    a = current_algo()
+    saved = HimAlgo.from_buffer_copy(a)
+    try:
+        for k, v in fields.items():
+            setattr(a, k, v)
+        yield a
+    finally:
+        ctypes.memmove(ctypes.byref(a), ctypes.byref(saved), ctypes.sizeof(HimAlgo))
+
+
+def _conv_desc(x, w, stride, pad, pad_mode, act, slope, frozen=False):
     B, Cin, H, W = x.shape
     Cout, Cin2, KH, KW = w.shape
     if Cin2 != Cin:
         raise HimError('conv2d: weight expects %d input channels, got %d' % (Cin2, Cin))
     OH = (H + 2 * pad - KH) // stride + 1
     OW = (W + 2 * pad - KW) // stride + 1
-    return HimConv2d(B, Cin, H, W, Cout, KH, KW, stride, pad, pad_mode, OH, OW, act, slope)
+    d = HimConv2d(B, Cin, H, W, Cout, KH, KW, stride, pad, pad_mode, OH, OW, act, slope, current_algo())
+    if frozen:
+        d.algo.disable |= _ALGO_FROZEN
+    return d
+
+
+_ALGO_FROZEN = 1 << 9
 
 
 # Weight panels: the MFMA kernels read the weights regrouped (include/him.h "Weight panels").  Weights change once
@@ -239,7 +305,6 @@ def _conv_desc(x, w, stride, pad, pad_mode, act, slope):
 # lazily when the parameter's version counter / storage moved (load_state_dict, torch optimizers).  Code that writes
 # weights behind torch's back (raw pointers, ``p.data.copy_``) must call ``invalidate_panels``.
 PANEL_FWD, PANEL_BWD_DATA = 0, 1
-_PANELS_ON = os.environ.get('HIM_NO_PANEL_CACHE') is None
 
 
 class _Panel(object):
@@ -247,14 +312,10 @@ class _Panel(object):
 
 
 def _panel_token(w):
-    return (w._version, w.data_ptr(), getattr(w, '_him_gen', 0), _WINO_GEN)
+    return (w._version, w.data_ptr(), getattr(w, '_him_gen', 0))
 
 
 def _build_panel(w, e):
-    nb = int((lib.him_deconv2d_panel_bytes if e.is_deconv else lib.him_conv2d_panel_bytes)(ctypes.byref(e.desc), e.kind))
-    if nb != e.nbytes:                       # the Winograd threshold moved: different panel layout
-        e.nbytes = nb
-        e.buf = torch.empty(max(nb // 4, 1), dtype=torch.float32, device=w.device)
     fn = lib.him_deconv2d_panel_build if e.is_deconv else lib.him_conv2d_panel_build
     fn(ctypes.byref(e.desc), e.kind, _p(w), _p(e.buf), e.nbytes, _stream())
     e.token = _panel_token(w)
@@ -265,7 +326,7 @@ def _build_panel(w, e):
 
 def _panel(w, d, kind, is_deconv):
     """Device pointer of the cached panel of parameter ``w`` for descriptor ``d`` (0: use the plain entry point)."""
-    if not _PANELS_ON or not isinstance(w, torch.nn.Parameter):
+    if not SCHED.panel_cache or not isinstance(w, torch.nn.Parameter):
         return 0
     if kind == PANEL_BWD_DATA and not is_deconv and lib.him_conv2d_bwd_data_shares_fwd_panel(ctypes.byref(d)):
         kind = PANEL_FWD        # separate-transform Winograd layers: ONE panel per weight serves both directions
@@ -274,11 +335,13 @@ def _panel(w, d, kind, is_deconv):
         cache = w.__dict__['_him_panels'] = {}
     # every descriptor field the panel LAYOUT can depend on (include/him.h "Weight panels": Winograd eligibility needs
     # pad 1 + planes >= 2x2 + an unchanged plane size for the data gradient; tiny heads switch on the output size)
+    # ... and the HimAlgo the panel is built with (Winograd thresholds decide the layout)
     if is_deconv:
-        key = (kind, d.stride, d.pad, d.out_pad)
+        key = (kind, d.stride, d.pad, d.out_pad, bytes(d.algo))
     else:
         key = (kind, d.stride, d.pad, d.pad_mode, d.H >= 2 and d.W >= 2, d.OH == d.H and d.OW == d.W,
-               d.B * d.OH * d.OW < 131072, d.B * d.Cin * d.H * d.W < (1 << 29), d.B * d.Cout * d.H * d.W < (1 << 29))
+               d.B * d.OH * d.OW < 131072, d.B * d.Cin * d.H * d.W < (1 << 29), d.B * d.Cout * d.H * d.W < (1 << 29),
+               bytes(d.algo))
     e = cache.get(key)
     if e is None:
         e = cache[key] = _Panel()
@@ -314,15 +377,13 @@ def invalidate_panels(params):
 
 
 def set_winograd_min_channels(c):
-    """3x3 stride-1 convs with >= c channels on both sides run as Winograd F(2x2,3x3) (c <= 0: off).  Cached panels
-    are keyed by the setting.  Returns the previous value."""
-    global _WINO_GEN
-    prev = int(lib.him_set_winograd_min_channels(int(c)))
-    _WINO_GEN += 1
-    return prev - (1 << 32) if prev >= (1 << 31) else prev
-
-
-_WINO_GEN = 0
+    """3x3 stride-1 convs with >= c channels on both sides run as Winograd F(2x2,3x3); c <= 0: EVERY Winograd form off.
+    Sets ``current_algo().wino_min_c`` of the calling thread (cached panels are keyed by the HimAlgo they were built
+    with); returns the previous setting (0 = the library default, 512)."""
+    a = current_algo()
+    prev = int(a.wino_min_c)
+    a.wino_min_c = -1 if c <= 0 else (0 if int(c) == 512 else int(c))
+    return prev if prev != 0 else 512
 
 
 class _Conv2d(torch.autograd.Function):
@@ -466,9 +527,6 @@ class _OneHotConv2d(torch.autograd.Function):
         return None, None, None, dw, db, None, None, None, None
 
 
-_ONEHOT_ON = os.environ.get('HIM_NO_ONEHOT_STEM') is None
-
-
 def mark_onehot(x, label, n_onehot):
     """Declare that channels [0, n_onehot) of ``x`` are the one-hot encoding of the id map ``label`` (B,1,H,W): the
     first convolution applied to ``x`` may then be evaluated from the ids (``_OneHotConv2d``)."""
@@ -483,7 +541,7 @@ def conv2d(x, w, b=None, stride=1, pad=0, pad_mode='zero', act='none', slope=0.2
     ``grad_premasked`` the caller guarantees that every consumer of this layer's output multiplies the gradient it
     sends back by (output > 0) -- this layer then skips its own ReLU backward pass; ``gate_dx`` makes this layer such a
     consumer for its input (dx = (x > 0) * dgrad, in the data-gradient kernel's epilogue)."""
-    oh = getattr(x, '_him_onehot', None) if _ONEHOT_ON else None
+    oh = getattr(x, '_him_onehot', None) if SCHED.onehot_stem else None
     if oh is not None and stride == 1 and not x.requires_grad:
         label, n_onehot = oh
         pm = PAD_REFLECT if pad_mode == 'reflect' else PAD_ZERO
@@ -609,7 +667,7 @@ class _Deconv2d(torch.autograd.Function):
             raise HimError('deconv2d: weight expects %d input channels, got %d' % (Cin2, Cin))
         OH = (H - 1) * stride - 2 * pad + KH + out_pad
         OW = (W - 1) * stride - 2 * pad + KW + out_pad
-        d = HimDeconv2d(B, Cin, H, W, Cout, KH, KW, stride, pad, out_pad, OH, OW, act, slope)
+        d = HimDeconv2d(B, Cin, H, W, Cout, KH, KW, stride, pad, out_pad, OH, OW, act, slope, current_algo())
         y = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device)
         nb = lib.him_deconv2d_fwd_ws(ctypes.byref(d))
         ws = _ws(nb, x)
@@ -688,7 +746,7 @@ class _ResBlock(torch.autograd.Function):
         x = x.contiguous()
         _chk(x, w1, b1, w2, b2)
         B, Cn, H, W = x.shape
-        d = HimResBlock(B, Cn, H, W, eps)
+        d = HimResBlock(B, Cn, H, W, eps, current_algo())
         cd = _conv_desc(x, w1, 1, 1, PAD_REFLECT, ACT_NONE, 0.0)
         p1, p2 = _panel(w1, cd, PANEL_FWD, False), _panel(w2, cd, PANEL_FWD, False)
         if not p1 or not p2:
@@ -742,19 +800,18 @@ class _ResBlock(torch.autograd.Function):
 # Off by default since round 3's 64x128 conv tiles: inside the multi-stream step the layer-by-layer block is 0.4 ms
 # faster (59.6 vs 60.0 ms, three repetitions each, profiles/r03_tile_shape_ab.txt) although the fused unit launches
 # fewer kernels and moves fewer bytes; HIM_RESBLOCK_FUSED=1 turns it on, tests/test_ops_gpu.py keeps it pinned.
-_RESBLOCK_ON = os.environ.get('HIM_RESBLOCK_FUSED', '0') != '0'
 
 
 def resblock_supported(x, w1, w2):
     """True when ``resnet_block`` can take (x, w1, w2): CUDA fp32, nn.Parameter weights (cached panels) and a shape in
     the separate-transform Winograd range (him_resblock_supported)."""
-    if not (_RESBLOCK_ON and _PANELS_ON and x.is_cuda and x.dim() == 4 and isinstance(w1, torch.nn.Parameter)
+    if not (SCHED.resblock_fused and SCHED.panel_cache and x.is_cuda and x.dim() == 4 and isinstance(w1, torch.nn.Parameter)
             and isinstance(w2, torch.nn.Parameter)):
         return False
     B, Cn, H, W = x.shape
     if tuple(w1.shape) != (Cn, Cn, 3, 3) or tuple(w2.shape) != (Cn, Cn, 3, 3):
         return False
-    return bool(lib.him_resblock_supported(ctypes.byref(HimResBlock(B, Cn, H, W, 1e-5))))
+    return bool(lib.him_resblock_supported(ctypes.byref(HimResBlock(B, Cn, H, W, 1e-5, current_algo()))))
 
 
 def resnet_block(x, w1, b1, w2, b2, eps=1e-5):

@@ -158,11 +158,14 @@ class FusedAdam(object):
                 # Parameter ORDER comes from the file's own param_groups: torch >= 1.6 keys the state by index, but the
                 # reference's era (torch 0.3 / 0.4) keys it by id(p) -- memory addresses, also listed per group -- whose
                 # numeric order says nothing about the parameter order.  A parameter without an entry (never received a
-                # gradient) gets zero moments, as torch does.
+                # gradient) gets zero moments.  DEVIATION from torch, warned about below: torch would start such a
+                # parameter at step 0 (bias corrections 1-b1, 1-b2 on its first update); this optimizer has ONE fused step
+                # count, so its first update uses the corrections of step N+1 -- (1-b1)/sqrt(1-b2) times smaller.
                 order = [pid for g in sd['param_groups'] for pid in g['params']]
                 if len(order) != len(a.params):
                     raise ValueError('optimizer state lists %d parameters, the arena holds %d' % (len(order), len(a.params)))
-                unknown = [k for k in st.keys() if k not in set(order)]
+                known = set(order)
+                unknown = [k for k in st.keys() if k not in known]
                 if unknown:
                     raise ValueError('optimizer state has entries no param_group lists: %s' % unknown[:4])
                 ms, vs, steps = [], [], set()
@@ -180,6 +183,12 @@ class FusedAdam(object):
                     steps.add(int(float(e['step'])))
                 if len(steps) != 1:
                     raise ValueError('per-parameter step counts differ (%s): one fused step count only' % sorted(steps))
+                missing = sum(1 for pid in order if pid not in st)
+                if missing:
+                    import warnings
+                    warnings.warn('%d of %d parameters have no Adam state in the file: they start from zero moments at the '
+                                  'shared step count %d (torch would restart them at step 0)'
+                                  % (missing, len(order), next(iter(steps))))
                 self.load_moments(ms, vs, steps.pop())
             for g, s in zip(self.param_groups, sd['param_groups']):
                 for k in ('lr', 'betas', 'eps'):

@@ -42,6 +42,59 @@ def test_descriptor_validation_without_gpu():
         _cabi.lib.him_l1_mean_fwd(0, 0, 16, 0, 0, 0, 0)
 
 
+def test_kernel_selection_is_a_pure_function_of_the_descriptor():
+    """include/him.h "Algorithm selection": no mutable global state, no environment on any path.  (1) the only getenv
+    calls of csrc/ sit inside him_algo_from_env; (2) a zero HimAlgo resolves to the documented defaults; (3) the size
+    queries follow the descriptor's HimAlgo -- evaluated concurrently from two host threads with different settings."""
+    import threading
+    from neurips18_hierchical_image_manipulation_amd import _cabi
+    csrc = os.path.join(ROOT, 'neurips18_hierchical_image_manipulation_amd', 'csrc')
+    for fn in sorted(os.listdir(csrc)):
+        if not fn.endswith(('.hip', '.inc', '.h')):
+            continue
+        src = open(os.path.join(csrc, fn)).read()
+        if 'getenv' not in src:
+            continue
+        assert fn == 'him_conv.hip', 'getenv outside him_conv.hip: %s' % fn
+        body = src[src.index('void him_algo_from_env('):]
+        body = body[:body.index('\n}\n') + 3]
+        assert src.count('getenv') == body.count('getenv'), 'getenv outside him_algo_from_env()'
+        assert 'static' not in body
+    for fn in sorted(os.listdir(csrc)):      # no latched / mutable function-local or file-scope state either
+        if fn.endswith(('.hip', '.inc')):
+            for ln in open(os.path.join(csrc, fn)).read().split('\n'):
+                if re.match(r'^\s*static\s+(int|bool|long|unsigned|size_t|float|double)\s+\w+\s*(=|;)', ln):
+                    raise AssertionError('mutable static in %s: %s' % (fn, ln.strip()))
+    out = _cabi.HimAlgo()
+    _cabi.lib.him_algo_resolve(None, ctypes.byref(out))
+    assert out.as_dict() == dict(wino_min_c=512, wino_fused_min_c=64, wino_fused_max_c=512, wino4_min_c=256, ksplit_max=8,
+                                 tile_wb=_cabi.TILE_64x128, tile_nb=_cabi.TILE_64x128, wino_tblock=64, wgrad_splits=0,
+                                 disable=0)
+
+    def desc(**algo):
+        d = _cabi.HimConv2d(8, 1024, 16, 32, 1024, 3, 3, 1, 1, 1, 16, 32, 0, 0.0)
+        for k, v in algo.items():
+            setattr(d.algo, k, v)
+        return d
+    wino, direct = desc(), desc(wino_min_c=-1)
+    ws_w, ws_d = (int(_cabi.lib.him_conv2d_fwd_ws(ctypes.byref(d))) for d in (wino, direct))
+    assert ws_w > ws_d > 0      # V / M tensors + the 16-position panel vs the regrouped 3x3 weights
+    assert int(_cabi.lib.him_conv2d_panel_bytes(ctypes.byref(wino), 0)) == 16 * 1024 * 1024 * 4
+    assert int(_cabi.lib.him_conv2d_panel_bytes(ctypes.byref(direct), 0)) == 9 * 1024 * 1024 * 4
+    assert _cabi.lib.him_conv2d_bwd_data_shares_fwd_panel(ctypes.byref(wino)) == 1
+    assert _cabi.lib.him_conv2d_bwd_data_shares_fwd_panel(ctypes.byref(direct)) == 0
+    bad = []
+
+    def worker(d, want):
+        for _ in range(2000):
+            if int(_cabi.lib.him_conv2d_fwd_ws(ctypes.byref(d))) != want:
+                bad.append(want)
+    ts = [threading.Thread(target=worker, args=a) for a in ((wino, ws_w), (direct, ws_d))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not bad
+
+
 def test_state_dict_keys_match_oracle_for_every_generator():
     from oracle import ref_cpu
     from neurips18_hierchical_image_manipulation_amd.models import Pix2Pix_NET as P

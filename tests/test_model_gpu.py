@@ -90,8 +90,9 @@ def test_tiny_twostream_forward_matches_reference():
     assert_close('two-stream generator output', fake, torch.from_numpy(g['fake0']), rtol=1e-4)
 
 
-ENVELOPE_K = 3.0      # free-running drift bound = K x the reference's own thread-count drift (chaos_envelope.json)
-WINO_DECADE = 10.0    # Winograd-on runs: at most one decade (= one step of the ~10x/step amplification) beyond it
+ENVELOPE_K = 3.0      # free-running drift bound = K x the reference's own summation-order drift (chaos_envelope.json)
+ENVELOPE_HARD = 5.0   # ... and NO step of either run beyond this multiple of it (round-3 worst: 1.87 direct form, 2.31
+                      # Winograd-on, both at C2; gpurun_out/free_run_*.json)
 
 
 def _envelope(key, steps, which=('_threads', '_convalg')):
@@ -117,14 +118,15 @@ def _envelope(key, steps, which=('_threads', '_convalg')):
     return np.maximum(worst[:steps], floor)
 
 
-def _free_run(tag, **switches):
-    """tools/free_run.py in a subprocess (the library reads its kernel-selection switches once per process)."""
+def _free_run(tag, **algo):
+    """tools/free_run.py in a subprocess (a fresh process per 20-step full-size run); kernel selection = PINNED_ALGO with
+    the given fields replaced, handed over explicitly -- no HIM_* variable reaches the child."""
     import subprocess
     import sys
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
     env = {k: v for k, v in os.environ.items() if not k.startswith('HIM_')}
-    env.update({k: str(v) for k, v in switches.items()})
-    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'free_run.py'), tag], stdout=subprocess.PIPE,
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'free_run.py'), tag, '--algo',
+                        json.dumps(dict(PINNED_ALGO, **algo))], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True, timeout=1200, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith('FREE_RUN ')][-1]
@@ -134,16 +136,16 @@ def _free_run(tag, **switches):
 def _free_running_vs_envelope(tag, key):
     """Two free-running runs against the reference's golden trajectory, both measured in units of the summation-order
     envelope E(s) (_envelope):
-      * Winograd OFF (HIM_NO_WINOGRAD, HIM_NO_WINO_FUSED: every conv in the direct form): the HIP path is then 'the
+      * Winograd OFF (HimAlgo.wino_min_c = -1: every conv in the direct form): the HIP path is then 'the
         reference on another summation order';
       * Winograd ON (the shipped configuration; F(2x2,3x3) adds ~1e-6 of transform rounding to the wide 3x3 layers).
-      Both: step 0 at 1e-5, the MEDIAN over the later steps of deviation / E(s) within K = 3, no step beyond one decade.
+      Both: step 0 at 1e-5, the MEDIAN over the later steps of deviation / E(s) within K = 3, EVERY step within 5.
     Round-3 measurement (gpurun_out/free_run_*.json, also against the thread-count-only samples): the Winograd-off and
     the Winograd-on run sit at the SAME distance (both <= 3.1 x the thread-count-only envelope at C2, step for step
     sometimes one, sometimes the other ahead) -- the transforms are not what separates the HIP trajectory from the
     reference's; a different summation order in every convolution is, and the reference's own native-convolution run
     shows the same distance from its oneDNN run."""
-    off = _free_run(tag, HIM_NO_WINOGRAD=1, HIM_NO_WINO_FUSED=1)
+    off = _free_run(tag, wino_min_c=-1)
     on = _free_run(tag)
     r_off, r_on = np.array(off['rel_per_step']), np.array(on['rel_per_step'])
     env = _envelope(key, len(r_on))
@@ -154,15 +156,16 @@ def _free_running_vs_envelope(tag, key):
                        winograd_off=r_off.tolist(), winograd_on=r_on.tolist(),
                        ratio_off=(r_off / env).tolist(), ratio_on=(r_on / env).tolist(),
                        ratio_off_vs_thread_count_only=(r_off / env_thr).tolist(),
-                       ratio_on_vs_thread_count_only=(r_on / env_thr).tolist(), K=ENVELOPE_K, wino_decade=WINO_DECADE), f)
+                       ratio_on_vs_thread_count_only=(r_on / env_thr).tolist(), K=ENVELOPE_K, K_hard=ENVELOPE_HARD,
+                       algo=on.get('algo'), algo_direct_form=off.get('algo'), schedule=on.get('schedule')), f)
     assert r_off[0] < 1e-5 and r_on[0] < 1e-5, (r_off[0], r_on[0])
-    # Every code change is a new draw of the chaotic trajectory (round 3: the same build step for step anywhere between
-    # 0.1x and 7.4x the envelope), amplified ~10x per step: the statement that holds is "typically inside K x the
-    # envelope, never more than one decade = one step of amplification beyond it".
+    # Every code change is a new draw of the chaotic trajectory, amplified ~10x per step.  Two bounds per run: the MEDIAN
+    # ratio over the later steps within K = 3, and a HARD per-step bound -- no single step of either run (direct form and
+    # Winograd) beyond ENVELOPE_HARD x the envelope (round 3 asserted one decade; the recorded worst is 2.31).
     for name, r in (('Winograd-off', r_off), ('Winograd-on', r_on)):
         ratio = r / env
         assert np.median(ratio[1:]) <= ENVELOPE_K, '%s run: median ratio to the summation-order envelope %s' % (name, ratio.tolist())
-        assert ratio.max() <= WINO_DECADE, '%s run: more than a decade outside the envelope: %s' % (name, ratio.tolist())
+        assert ratio.max() <= ENVELOPE_HARD, '%s run: a step beyond %.0fx the envelope: %s' % (name, ENVELOPE_HARD, ratio.tolist())
 
 
 def test_c1_full_size_free_running_trajectory_vs_reference():
@@ -258,7 +261,7 @@ def _post_step_state_errors(model, om, before):
 # formulas evaluated in float64 FROM THE HIP GRADIENT ITSELF and the adopted moments, so the comparison isolates the fused
 # Adam kernel (betas, bias corrections, lr, the arena walk, the side-stream join) from the gradient's own rounding: moments
 # 5e-6, update 1e-3 relative L2 per tensor.
-# WINOGRAD.  TYPICAL at K = 2 is asserted on the DIRECT-FORM build (him_set_winograd_min_channels(0): every convolution
+# WINOGRAD.  TYPICAL at K = 2 is asserted on the DIRECT-FORM run (HimAlgo.wino_min_c < 0: every convolution
 # as an implicit GEMM = 'the reference on another summation order'; measured <= 1.5 on every C1 tensor).  The shipped
 # build evaluates the 1024-channel ResnetBlocks and the VGG convolutions as Winograd F(2x2,3x3), whose fp32 rounding is a
 # few times the direct form's: the generated image is that much further from its float64 value, more decisions within
@@ -266,14 +269,30 @@ def _post_step_state_errors(model, om, before):
 # discriminator's FIRST layer, which reads the image -- show it in every step: measured lower-quartile ratios 2.6
 # (G head), 2.2 (last up-convolutions), 5.8 (D scale-0 layer 0: 5.8e-5 against the 1e-5 floor; every other D tensor
 # stays at the 3e-6 baseline).  That is the price of 2.25x fewer multiplies, two orders below the 5e-3 event level every
-# fp32 step carries anyway; the Winograd-on runs assert K_TYPICAL_WINOGRAD = 8 and record the ratios.
-PARITY_K_TYPICAL, PARITY_K_TYPICAL_WINOGRAD, PARITY_K_EVENT, PARITY_FLOOR = 2.0, 8.0, 10.0, 1e-5
-ADAM_TOL = dict(exp_avg=5e-6, exp_avg_sq=5e-6, delta=1e-3)
+# fp32 step carries anyway; the Winograd-on runs assert K_TYPICAL_WINOGRAD = 4 (round 3: 8) and record the ratios.
+# Round 4: every K is <= 2x the worst value recorded so far (gpurun_out/teacher_forced_*.json of rounds 3 / 4): TYPICAL
+# 1.88 direct form / 2.29 Winograd; EVENTS 6.8 (C4, D/scale0_layer0) -- K_EVENT stays one decade, but the C1 run is
+# repeated on a SECOND, independent batch sequence so that one draw of the event lottery cannot decide; losses 9e-7;
+# Adam moments 1.5e-7, update 2.7e-5.  In addition to the lower quartile, the MEDIAN over the steps is bounded (2x the
+# quartile's K against the oracle's median) for every tensor whose oracle distances are unimodal: a defect present in
+# half of the steps cannot pass (see the comment at the assertion for the bimodal discriminator tensors).
+PARITY_K_TYPICAL, PARITY_K_TYPICAL_WINOGRAD, PARITY_K_EVENT, PARITY_FLOOR = 2.0, 4.0, 10.0, 1e-5
+PARITY_LOSS_TOL = 5e-6
+ADAM_TOL = dict(exp_avg=1e-6, exp_avg_sq=1e-6, delta=2.5e-4)    # measured worst over 20 C1 steps: 1.7e-7 / 8.3e-8 / 1.25e-4
+# Kernel selection is PINNED for the parity runs (it decides the fp32 summation order: split-K depth, tile shape, which
+# layers take a Winograd form) and recorded in every report -- not whatever a process environment would select.
+PINNED_ALGO = dict(wino_min_c=512, wino_fused_min_c=64, wino_fused_max_c=512, ksplit_max=8, tile_wb=4, tile_nb=4,
+                   wino_tblock=64, wgrad_splits=0, disable=0)
 
 
 def _quartile(vals):
     v = sorted(vals)
     return v[(len(v) - 1) // 4]
+
+
+def _median(vals):
+    v = sorted(vals)
+    return v[(len(v) - 1) // 2]
 
 
 def _adam_arithmetic_errors(model, before, moments_before, t_before):
@@ -306,21 +325,27 @@ def _adam_arithmetic_errors(model, before, moments_before, t_before):
     return worst
 
 
-def _teacher_forced(tag, steps, loss_tol=2e-5, anchor=None, golden=None, batch_fn=None, plumbing_tol=None,
-                    winograd=True, k_typical=None, out_tag=None):
+def _teacher_forced(tag, steps, loss_tol=PARITY_LOSS_TOL, anchor=None, golden=None, batch_fn=None, plumbing_tol=None,
+                    winograd=True, k_typical=None, out_tag=None, fp64_steps=None, batch_seed=0):
     """``plumbing_tol``: the run pins flag plumbing (which terms enter which loss) on a toy net without a committed
     anchor: every gradient tensor within that absolute relative-L2 bound of the fp32 oracle's (a mis-routed loss term is
-    an O(1) error), no event statistics."""
+    an O(1) error), no event statistics.  ``fp64_steps``: the float64 step (gradient bounds) runs on the first that many
+    steps only -- later steps assert the losses and the Adam arithmetic.  ``batch_seed``: offset of the batch sequence."""
+    from neurips18_hierchical_image_manipulation_amd import ops
+    algo = dict(PINNED_ALGO)
+    if not winograd:     # every convolution in the direct form (HimAlgo.wino_min_c < 0)
+        algo['wino_min_c'] = -1
+        k_typical = PARITY_K_TYPICAL if k_typical is None else k_typical
+    with ops.algo_scope(**algo):
+        return _teacher_forced_run(tag, steps, loss_tol, anchor, golden, batch_fn, plumbing_tol,
+                                   PARITY_K_TYPICAL_WINOGRAD if k_typical is None else k_typical, out_tag,
+                                   steps if fp64_steps is None else fp64_steps, batch_seed)
+
+
+def _teacher_forced_run(tag, steps, loss_tol, anchor, golden, batch_fn, plumbing_tol, k_typical, out_tag, fp64_steps,
+                        batch_seed):
     import fp64_anchor as fa
-    from neurips18_hierchical_image_manipulation_amd import synth, ops
-    if not winograd:     # every convolution in the direct form (him_set_winograd_min_channels(<= 0)); restored below
-        prev_wino = ops.set_winograd_min_channels(0)
-        try:
-            return _teacher_forced(tag, steps, loss_tol, anchor, golden, batch_fn, plumbing_tol, True,
-                                   PARITY_K_TYPICAL if k_typical is None else k_typical, out_tag)
-        finally:
-            ops.set_winograd_min_channels(prev_wino)
-    k_typical = PARITY_K_TYPICAL_WINOGRAD if k_typical is None else k_typical
+    from neurips18_hierchical_image_manipulation_amd import synth, ops, config
     g = golden if golden is not None else load_golden(tag)
     flags = g['flags'] if isinstance(g['flags'], dict) else json.loads(str(g['flags']))
     B, H, W = int(g['B']), int(g['H']), int(g['W'])
@@ -339,13 +364,16 @@ def _teacher_forced(tag, steps, loss_tol=2e-5, anchor=None, golden=None, batch_f
             moments_before[tg] = {k: ((opt.state[p]['exp_avg'].clone(), opt.state[p]['exp_avg_sq'].clone()) if p in opt.state
                                       else (torch.zeros_like(p), torch.zeros_like(p))) for k, p in net.named_parameters()}
             t_before[tg] = int(next(iter(opt.state.values()))['step']) if opt.state else 0
-        b = batch_fn(s) if batch_fn else synth.make_batch(s, 0, B, H, W, flags.get('label_nc', 35), color)
+        b = batch_fn(s) if batch_fn else synth.make_batch(s + batch_seed, 0, B, H, W, flags.get('label_nc', 35), color)
         got = model.optimize_parameters(b)
         model.sync()
         ref = om.optimize_parameters(b)
         lrel = max(abs(float(got[k].detach()) - ref[k]) / max(abs(ref[k]), 1e-12) for k in NAMES)
         worst_loss = max(worst_loss, lrel)
         adam_log.append(_adam_arithmetic_errors(model, before, moments_before, t_before))
+        log.append((s, lrel))
+        if om64 is not None and s >= fp64_steps:      # losses + Adam arithmetic only from here on
+            continue
         q_hip, q32 = _hip_quantities(model, before), fa.oracle_quantities(om, before)
         net_scale = {t: max(v['grad'].abs().max().item() for k, v in q32.items() if k.startswith(t)) for t in 'GD'}
         for name in dead:
@@ -362,46 +390,63 @@ def _teacher_forced(tag, steps, loss_tol=2e-5, anchor=None, golden=None, batch_f
                                     'delta': fa.rel_l2(q_hip[n]['delta'], q64[n]['delta'])} for n in live})
             e_32_steps.append({n: {'grad': fa.rel_l2(q32[n]['grad'], q64[n]['grad']),
                                    'delta': fa.rel_l2(q32[n]['delta'], q64[n]['delta'])} for n in live})
-        log.append((s, lrel))
     adam_worst = {k: max(a[k] for a in adam_log) for k in ADAM_TOL}
     os.makedirs(OUT, exist_ok=True)
-    report = dict(tag=tag, loss_rel_per_step=log, adam_arithmetic_worst=adam_worst, adam_tol=ADAM_TOL)
+    report = dict(tag=tag, loss_rel_per_step=log, loss_tol=loss_tol, adam_arithmetic_worst=adam_worst, adam_tol=ADAM_TOL,
+                  batch_seed=batch_seed, algo=ops.resolved_algo(), schedule=config.SCHED.as_dict())
     bad = [('adam ' + k, adam_worst[k], ADAM_TOL[k]) for k in ADAM_TOL if not adam_worst[k] <= ADAM_TOL[k]]
     if om64 is None:
         report.update(mode='plumbing', worst_grad_vs_fp32_oracle=vs_oracle, plumbing_tol=plumbing_tol)
         if not vs_oracle <= plumbing_tol:
             bad.append(('gradient vs oracle', vs_oracle, plumbing_tol))
-    else:
+    elif e_hip_steps:
         names = list(e_hip_steps[0].keys())
         oracle_steps = list(e_32_steps)                       # the oracle's distances: the live run ...
         if anchor is not None:                                # ... and the committed anchor of the configuration
             rec = fa.load_anchor()[anchor]['steps']
             assert set(rec[0]['tensors'].keys()) == set(names), 'anchor fixture lists other tensors than the model'
             oracle_steps += [st['tensors'] for st in rec]
-        typical, events = [], []
-        if steps >= 6:
+        typical, typical_med, events = [], [], []
+        if len(e_hip_steps) >= 6:
             for n in names:
                 th = _quartile([st[n]['grad'] for st in e_hip_steps])
                 to = max(_quartile([st[n]['grad'] for st in oracle_steps]), PARITY_FLOOR)
                 typical.append((th / to, n, th, to))
                 if not th <= k_typical * to:
                     bad.append(('typical', n, th, k_typical * to))
+                # MEDIAN bound: asserted where the oracle's own distances are unimodal (upper quartile within 10x of the
+                # lower one: every generator tensor).  The discriminator's tensors are bimodal on BOTH sides -- baseline
+                # 3e-6 or an event of 1e-4..5e-3 in about every second step (round 4, C1: HIP 5 of 8 steps, oracle 4 of 8)
+                # -- so their median is a coin toss between the two modes; it is recorded, and stream races are caught by
+                # test_multi_stream_schedule_is_bit_identical_to_the_serial_one instead.
+                os_ = sorted(st[n]['grad'] for st in oracle_steps)
+                unimodal = os_[(3 * (len(os_) - 1)) // 4] <= 10.0 * max(os_[(len(os_) - 1) // 4], PARITY_FLOOR)
+                mh = _median([st[n]['grad'] for st in e_hip_steps])
+                mo = max(_median(os_), PARITY_FLOOR)
+                typical_med.append((mh / mo, n, mh, mo, unimodal))
+                if unimodal and not mh <= 2.0 * k_typical * mo:
+                    bad.append(('typical (median)', n, mh, 2.0 * k_typical * mo))
             typical.sort(reverse=True)
+            typical_med.sort(reverse=True)
         for net in 'GD':
             mh = max((st[n]['grad'], s, n) for s, st in enumerate(e_hip_steps) for n in names if n.startswith(net))
             mo = max(max(st[n]['grad'] for st in oracle_steps for n in names if n.startswith(net)), PARITY_FLOOR)
             events.append((mh[0] / mo, net, mh[0], mh[1], mh[2], mo))
             if not mh[0] <= PARITY_K_EVENT * mo:
                 bad.append(('event', net, mh[0], PARITY_K_EVENT * mo))
-        med = lambda xs: sorted(xs)[(len(xs) - 1) // 2]                                            # noqa: E731
+        med = _median
         per_step = [dict(step=s, loss_rel=log[s][1],
                          **{'%s_%s_%s' % (net, q, who): med([st[n][q] for n in names if n.startswith(net)])
                             for net in 'GD' for q in ('grad', 'delta')
-                            for who, st in (('hip', e_hip_steps[s]), ('oracle', e_32_steps[s]))}) for s in range(steps)]
+                            for who, st in (('hip', e_hip_steps[s]), ('oracle', e_32_steps[s]))})
+                    for s in range(len(e_hip_steps))]
         report.update(mode='fp64 anchor', K_typical=k_typical, K_event=PARITY_K_EVENT, floor=PARITY_FLOOR,
                       anchor=anchor or 'live only', oracle_step_samples=len(oracle_steps),
                       typical_columns=['ratio', 'tensor', 'hip_lower_quartile', 'oracle_lower_quartile_or_floor'],
-                      typical_worst=typical[:25],
+                      typical_worst=typical[:25], typical_median_worst=typical_med[:25], fp64_steps=len(e_hip_steps),
+                      grad_distance_from_fp64=dict(tensors=names,
+                                                   hip=[[st[n]['grad'] for n in names] for st in e_hip_steps],
+                                                   oracle_live=[[st[n]['grad'] for n in names] for st in e_32_steps]),
                       event_columns=['ratio', 'net', 'hip_max', 'step', 'tensor', 'oracle_max_or_floor'], events=events,
                       median_over_tensors_per_step=per_step)
     with open(os.path.join(OUT, 'teacher_forced_%s.json' % (out_tag or tag)), 'w') as f:
@@ -411,17 +456,20 @@ def _teacher_forced(tag, steps, loss_tol=2e-5, anchor=None, golden=None, batch_f
     return report
 
 
-def test_c1_teacher_forced_8_step_loss_and_gradient_parity():
-    """8 steps of BASELINE config 1 along the oracle's trajectory: every step starts from the oracle's exact state,
-    so the comparison isolates one step's forward + backward + Adam update (post-step moments and parameter deltas are
-    compared with the oracle's before the next adoption)."""
-    _teacher_forced('c1_traj', 8, anchor='c1')
+def test_c1_teacher_forced_20_step_loss_and_gradient_parity():
+    """north_star verbatim: G / D losses against the CPU reference over 20 steps (asserted at 5e-6 relative per step; the
+    bar is 1e-3) of BASELINE config 1 along the oracle's trajectory -- every step starts from the oracle's exact state, so
+    the comparison isolates one step's forward + backward + Adam update; the first 6 steps also run the float64 step:
+    every gradient tensor (TYPICAL lower quartile + median, EVENTS), all 20 the Adam arithmetic."""
+    _teacher_forced('c1_traj', 20, anchor='c1', fp64_steps=6)
 
 
-def test_c1_teacher_forced_direct_form_gradient_parity():
-    """The same run with every Winograd form switched off (him_set_winograd_min_channels(0)): all convolutions in the
-    direct form, i.e. 'the reference on another summation order' -- the per-tensor TYPICAL bound at K = 2."""
-    _teacher_forced('c1_traj', 6, anchor='c1', winograd=False, out_tag='c1_traj_direct_form')
+def test_c1_teacher_forced_direct_form_second_batch_sequence():
+    """Every Winograd form switched off (HimAlgo.wino_min_c < 0: all convolutions in the direct form, i.e. 'the reference
+    on another summation order' -- the per-tensor TYPICAL bound at K = 2) on an INDEPENDENT batch sequence: a second draw
+    of the fp32 event lottery on both sides, so that one draw cannot decide the EVENTS bound (the oracle's yard-stick =
+    this run's live float64 distances + the committed anchor of the first sequence)."""
+    _teacher_forced('c1_traj', 6, anchor='c1', winograd=False, batch_seed=1000, out_tag='c1_traj_direct_form_seed2')
 
 
 def test_tiny_global_teacher_forced_20_steps():
@@ -429,9 +477,11 @@ def test_tiny_global_teacher_forced_20_steps():
 
 
 def test_c2_teacher_forced_loss_and_gradient_parity():
-    """The benchmark workload itself (512x256, bs 8, 3 D scales): one step from the oracle's state, compared
-    in losses, every gradient tensor, both Adam moments and the parameter update (the CPU oracle needs a few minutes)."""
-    _teacher_forced('c2_traj', 1, anchor='c2')
+    """The benchmark workload itself (512x256, bs 8, 3 D scales): SIX steps along the oracle's trajectory, each from the
+    oracle's state, compared in losses, every gradient tensor against the float64 step (per-tensor TYPICAL bound -- lower
+    quartile and median over the six steps -- and EVENTS), both Adam moments and the parameter update.  This is where the
+    C2-only launch shapes (split-K 8, grids (540,8,1), (1128,4,1) ...) are pinned per tensor."""
+    _teacher_forced('c2_traj', 6, anchor='c2')
 
 
 def test_tiny_twostream_teacher_forced_parity():
@@ -501,6 +551,41 @@ def test_backward_G_backward_D_equal_optimize_parameters():
         assert torch.equal(p, q)
     for p, q in zip(a.netD.parameters(), b.netD.parameters()):
         assert torch.equal(p, q)
+
+
+def _run_steps(flags, B, H, W, steps, **sched):
+    from neurips18_hierchical_image_manipulation_amd import synth, config
+    with config.schedule(**sched):
+        m = build(flags)
+        losses = []
+        for s in range(steps):
+            ld = m.optimize_parameters(synth.make_batch(s, 0, B, H, W, flags.get('label_nc', 35)))
+            losses.append([float(ld[k]) for k in NAMES])
+        m.sync()
+        torch.cuda.synchronize()
+        return losses, [p.detach().clone() for p in list(m.netG.parameters()) + list(m.netD.parameters())]
+
+
+@pytest.mark.parametrize('tag', ['c1_traj', 'c2_traj'])
+def test_multi_stream_schedule_is_bit_identical_to_the_serial_one(tag):
+    """Stream races show up as nondeterminism.  The shipped schedule (six streams: weight gradients, real-image branch,
+    VGG(fake), loss_D.backward() first, both optimizer steps deferred into the next step, panels rebuilt in place) changes
+    NO arithmetic, so full-size training steps must end in bit-identical losses and parameters to (a) a second run of
+    itself and (b) the SERIAL schedule (config.SERIAL: every helper stream off, the reference's backward order, one
+    stream) -- at sizes where the kernels of different streams really overlap."""
+    from neurips18_hierchical_image_manipulation_amd import config
+    g = load_golden(tag)
+    flags = json.loads(str(g['flags']))
+    B, H, W = int(g['B']), int(g['H']), int(g['W'])
+    steps = 4 if tag == 'c1_traj' else 3
+    la, pa = _run_steps(flags, B, H, W, steps)
+    lb, pb = _run_steps(flags, B, H, W, steps)
+    ls, ps = _run_steps(flags, B, H, W, steps, **config.SERIAL)
+    assert la == lb, 'the default schedule is not run-to-run deterministic'
+    assert all(torch.equal(a, b) for a, b in zip(pa, pb)), 'parameters differ between two runs of the default schedule'
+    assert la == ls, 'losses differ between the multi-stream and the serial schedule: %s vs %s' % (la[-1], ls[-1])
+    bad = [i for i, (a, b) in enumerate(zip(pa, ps)) if not torch.equal(a, b)]
+    assert not bad, '%d parameter tensors differ between the multi-stream and the serial schedule' % len(bad)
 
 
 def test_cpu_tensor_into_hip_op_fails_loudly():
@@ -585,7 +670,8 @@ def test_bench_launcher_spawns_the_ranks_it_is_asked_for():
     # per-rank event-timed waits for the exchange (what shows overlap on a real multi-GPU run)
     ex = out['exposed_comm_ms']
     assert len(ex['per_rank']) == 2 and set(ex['per_rank'][0]) == {'g_update_tail', 'd_update_wait', 'g_exchange_wait',
-                                                                   'd_exchange_wait'}
+                                                                   'd_exchange_wait', 'd_update_wait_real',
+                                                                   'real_branch_join'}
     assert all(v >= 0 for e in ex['per_rank'] for v in e.values()) and ex['main_stream_max'] >= 0
     # asking for 2 GPUs inside a 1-rank launcher environment must fail loudly, not print a 1-rank number
     env1 = dict(env, RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29411')

@@ -405,6 +405,52 @@ def test_winograd_conv3x3_fwd_bwd(case):
         ops.set_winograd_min_channels(prev)
 
 
+def test_library_is_reentrant():
+    """include/him.h "Algorithm selection": two host threads drive the C ABI concurrently -- each on its own HIP stream,
+    one with the Winograd forms ON (threshold 16 channels), the other with every Winograd form OFF -- through the
+    per-thread HimAlgo of ops.current_algo().  Every result must be bit-identical to the same thread's setting run alone
+    (a process-global switch, as round 3's him_set_winograd_min_channels was, would mix the two kernel families)."""
+    import threading
+    ops = _ops()
+    x = _rand(2, 64, 16, 32, seed=1).to(DEV)
+    w = _rand(64, 64, 3, 3, seed=2, scale=(64 * 9) ** -0.5).to(DEV)
+    gy = _rand(2, 64, 16, 32, seed=4).to(DEV)
+
+    def one(setting):
+        prev = ops.set_winograd_min_channels(setting)
+        try:
+            xd, wd = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+            y = ops.conv2d(xd, wd, None, 1, 1, 'reflect', 'none', 0.2)
+            gx, gw = torch.autograd.grad(y, (xd, wd), gy)
+            return y.detach(), gx, gw
+        finally:
+            ops.set_winograd_min_channels(prev)
+    alone = {s: one(s) for s in (16, 0)}
+    assert not torch.equal(alone[16][0], alone[0][0]), 'the two settings must select different kernels'
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(setting):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for _ in range(25):
+                    got = one(setting)
+                    stream.synchronize()
+                    for a, b in zip(got, alone[setting]):
+                        if not torch.equal(a, b):
+                            errors.append('setting %d: result differs from the single-threaded run' % setting)
+                            return
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+    ts = [threading.Thread(target=worker, args=(s,)) for s in (16, 0)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    torch.cuda.synchronize()
+    assert not errors, errors
+    assert ops.resolved_algo()['wino_min_c'] == 512          # the main thread's HimAlgo was never touched
+
+
 ONEHOT_CASES = [
     # B, NC, Cdense, H, W, Cout, k, pad_mode
     (2, 35, 3, 24, 40, 64, 7, 'reflect'),     # GlobalGenerator stem (one-hot 35 + cond image 3)
@@ -490,15 +536,13 @@ def test_vgg_loss_gated_relu_backward_is_identical(shape):
     x = _rand(*shape, seed=11)
     y = _rand(*shape, seed=12)
     got = {}
+    from neurips18_hierchical_image_manipulation_amd import config
     for gated in (True, False):
-        losses._GATED = gated
-        try:
+        with config.schedule(vgg_gated=gated):
             xd = x.to(DEV).requires_grad_(True)
             loss = crit(xd, y.to(DEV))
             (gx,) = torch.autograd.grad(loss, xd)
             got[gated] = (float(loss), gx.cpu())
-        finally:
-            losses._GATED = True
     assert got[True][0] == got[False][0]
     assert torch.equal(got[True][1], got[False][1])
     vgg = ref_cpu.Vgg19()
@@ -572,15 +616,14 @@ def test_fused_resnet_block_matches_layerwise_path_and_torch(shape):
     blk.to(DEV)
     w1, w2 = blk.conv_block[1].weight, blk.conv_block[5].weight
 
+    from neurips18_hierchical_image_manipulation_amd import config
+
     def run(fused):
-        prev, ops._RESBLOCK_ON = ops._RESBLOCK_ON, fused
-        try:
+        with config.schedule(resblock_fused=fused):
             xd = x.detach().to(DEV).requires_grad_(True)
             assert ops.resblock_supported(xd, w1, w2) == fused
             y = blk(xd)
             return (y,) + torch.autograd.grad(y, (xd, w1, w2), gy.to(DEV))
-        finally:
-            ops._RESBLOCK_ON = prev
     fused, plain = run(True), run(False)
     for name, a, b in zip(('out', 'dx', 'dw1', 'dw2'), fused, plain):
         assert_close('fused vs layer-wise ' + name, a, b, rtol=2e-5)

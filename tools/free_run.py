@@ -2,10 +2,11 @@
 """Free-running training trajectory of a golden configuration on the HIP path, printed as one JSON line
 (per-step max relative loss deviation from tests/golden/<tag>.npz = the REAL reference's trajectory).
 
-    python tools/free_run.py c2_traj [steps]
+    python tools/free_run.py c2_traj [steps] [--algo '{"wino_min_c": -1, "ksplit_max": 8, ...}']
 
-Run as a subprocess by tests/test_model_gpu.py so that kernel-selection switches that the library reads once from the
-environment (HIM_NO_WINOGRAD, HIM_NO_WINO_FUSED, ...) can differ between runs of one test session."""
+Run as a subprocess by tests/test_model_gpu.py (a fresh process and allocator per 20-step full-size run).  Kernel
+selection = the HimAlgo given by --algo (fields of include/him.h HimAlgo; the parity suite pins every field explicitly)
+on top of the process default; the resolved HimAlgo and the schedule are part of the output."""
 import json
 import os
 import sys
@@ -16,8 +17,15 @@ import numpy as np  # noqa: E402
 
 
 def main():
-    from neurips18_hierchical_image_manipulation_amd import synth
+    from neurips18_hierchical_image_manipulation_amd import synth, ops, config
     from neurips18_hierchical_image_manipulation_amd.models import create_model
+    algo = {}
+    if '--algo' in sys.argv:
+        i = sys.argv.index('--algo')
+        algo = json.loads(sys.argv[i + 1])
+        del sys.argv[i:i + 2]
+    for k, v in algo.items():
+        setattr(ops.current_algo(), k, int(v))
     tag = sys.argv[1]
     g = np.load(os.path.join(ROOT, 'tests', 'golden', tag + '.npz'), allow_pickle=False)
     flags = json.loads(str(g['flags']))
@@ -35,6 +43,7 @@ def main():
     got = np.array(got, np.float64)
     rel = np.abs(got - ref[:steps]) / np.maximum(np.abs(ref[:steps]), 1e-12)
     print('FREE_RUN ' + json.dumps(dict(tag=tag, switches={k: v for k, v in os.environ.items() if k.startswith('HIM_')},
+                                       algo=ops.resolved_algo(), schedule=config.SCHED.as_dict(),
                                        rel_per_step=rel.max(axis=1).tolist(), rel=rel.tolist(), got=got.tolist())))
 
 

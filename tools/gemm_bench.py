@@ -23,11 +23,11 @@ def main():
     c = torch.empty(16, M, N, device='cuda')
     st = torch.cuda.current_stream().cuda_stream
     for _ in range(3):
-        lib.him_winograd_gemm(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, K, N, st)
+        lib.him_winograd_gemm(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, K, N, None, st)
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(iters):
-        lib.him_winograd_gemm(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, K, N, st)
+        lib.him_winograd_gemm(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, K, N, None, st)
     e.record()
     e.synchronize()
     ms = s.elapsed_time(e) / iters
