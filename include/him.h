@@ -281,6 +281,18 @@ int him_conv2d_fwd_panel(const HimConv2d* d, const float* x, const void* panel, 
                          void* ws, size_t ws_bytes, void* stream);
 int him_conv2d_bwd_data_panel(const HimConv2d* d, const float* dy, const void* panel, float* dx, void* ws,
                               size_t ws_bytes, void* stream);
+/* Separate-transform Winograd layers (the 1024-channel ResnetBlock convolutions, models/layer_util.py:333-378): the
+ * transformed input V = B^T x B of the forward, [16][Cin][tiles] floats, is also the column operand of the layer's weight
+ * gradient dU = dM V^T.  A trainer that keeps it between forward and backward (67 MB per conv at config C2; this build is
+ * sized for 288 GB) saves the weight gradient's own transposed input transform, and the weight-gradient GEMM reads both
+ * operands K-contiguous.  *_keep_bytes: 0 when the descriptor has no such tensor (use the plain entry points).
+ * him_conv2d_fwd_panel_keep == him_conv2d_fwd_panel that leaves V in `keep` (NULL: not kept);
+ * him_conv2d_bwd_weight_kept == him_conv2d_bwd_weight with `keep` in place of x (same workspace size). */
+size_t him_conv2d_fwd_keep_bytes(const HimConv2d* d);
+int him_conv2d_fwd_panel_keep(const HimConv2d* d, const float* x, const void* panel, const float* bias, float* y, float* keep,
+                              void* ws, size_t ws_bytes, void* stream);
+int him_conv2d_bwd_weight_kept(const HimConv2d* d, const float* keep, const float* dy, float* dw, float* dbias, int accumulate,
+                               void* ws, size_t ws_bytes, void* stream);
 /* Data gradient GATED by the ReLU that produced this layer's input x: dx[i] = x[i] > 0 ? dgrad(dy)[i] : 0  -- the
  * activation backward of the PREVIOUS layer (models/layer_util.py:380-411 Vgg19: conv -> ReLU -> conv chains) done in
  * this launch's epilogue instead of a separate pass over dx.  `panel` (him_conv2d_panel_build, kind BWD_DATA) or `w`. */
@@ -373,6 +385,12 @@ int him_l1_multi_fwd(const float* const* a, const float* const* b, const size_t*
                      size_t ws_bytes, void* stream);
 int him_l1_multi_bwd(const float* const* a, const float* const* b, const size_t* n, int npairs, const float* g,
                      float* const* da, int accumulate, void* stream);
+/* Scalar loss arithmetic on device scalars (pix2pixHD_condImg_model.py:218-251: the per-scale GAN-loss sums, `* lambda_feat`;
+ * train_mask2image.py:68-76: (D_fake + D_real) * 0.5, G_GAN + G_GAN_Feat + G_VGG):  out[0] = scale * sum_i weights[i] * terms[i][0],
+ * summed left to right, every product and sum rounded to fp32 (the reference's chain of one-element tensor ops, in ONE
+ * launch).  terms / dterms / weights are HOST arrays of n <= 8 entries; bwd: dterms[i][0] = g[0] * scale * weights[i]. */
+int him_lincomb_fwd(const float* const* terms, const float* weights, int n, float scale, float* out, void* stream);
+int him_lincomb_bwd(const float* g, const float* weights, int n, float scale, float* const* dterms, void* stream);
 int him_mse_const_fwd(const float* x, size_t n, float target, float* out, void* ws, size_t ws_bytes,
                       void* stream);
 int him_mse_const_bwd(const float* x, size_t n, float target, const float* g, float* dx, int accumulate,

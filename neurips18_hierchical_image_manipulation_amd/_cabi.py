@@ -79,6 +79,9 @@ _SIGS = {
     'him_conv2d_fwd_panel': (c_int, [_CONV, P, P, P, P, P, c_size_t, P]),
     'him_conv2d_bwd_data_panel': (c_int, [_CONV, P, P, P, P, c_size_t, P]),
     'him_conv2d_bwd_data_gated': (c_int, [_CONV, P, P, P, P, P, P, c_size_t, P]),
+    'him_conv2d_fwd_keep_bytes': (c_size_t, [_CONV]),
+    'him_conv2d_fwd_panel_keep': (c_int, [_CONV, P, P, P, P, P, P, c_size_t, P]),
+    'him_conv2d_bwd_weight_kept': (c_int, [_CONV, P, P, P, P, c_int, P, c_size_t, P]),
     'him_deconv2d_panel_bytes': (c_size_t, [_DECONV, c_int]),
     'him_deconv2d_panel_build': (c_int, [_DECONV, c_int, P, P, c_size_t, P]),
     'him_deconv2d_fwd_panel': (c_int, [_DECONV, P, P, P, P, P, c_size_t, P]),
@@ -128,6 +131,8 @@ _SIGS = {
     'him_l1_multi_ws': (c_size_t, [c_int]),
     'him_l1_multi_fwd': (c_int, [P, P, P, c_int, P, P, c_size_t, P]),
     'him_l1_multi_bwd': (c_int, [P, P, P, c_int, P, P, c_int, P]),
+    'him_lincomb_fwd': (c_int, [P, P, c_int, c_float, P, P]),
+    'him_lincomb_bwd': (c_int, [P, P, c_int, c_float, P, P]),
     'him_mse_const_fwd': (c_int, [P, c_size_t, c_float, P, P, c_size_t, P]),
     'him_mse_const_bwd': (c_int, [P, c_size_t, c_float, P, P, c_int, P]),
     'him_resblock_supported': (C.c_uint, [_RESB]),

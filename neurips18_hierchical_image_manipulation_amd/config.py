@@ -34,6 +34,7 @@ class Schedule(object):
         'panel_cache': ('HIM_PANEL_CACHE', True, 'weight panels cached on the parameter, rebuilt after Adam'),
         'resblock_fused': ('HIM_RESBLOCK_FUSED', False, 'ResnetBlock with the norms inside the Winograd transforms'),
         'dead_bias_skip': ('HIM_DEAD_BIAS_SKIP', True, 'no bias gradient in front of a mean-subtracting norm'),
+        'keep_wino_input': ('HIM_KEEP_WINO_INPUT', True, "forward keeps the Winograd-transformed input for the layer's weight gradient"),
     }
     # negative spellings kept for the recorded A/B command lines of rounds 2-3
     LEGACY_OFF = {'HIM_NO_ONEHOT_STEM': 'onehot_stem', 'HIM_NO_PANEL_CACHE': 'panel_cache',

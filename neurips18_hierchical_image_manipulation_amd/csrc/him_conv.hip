@@ -183,9 +183,25 @@ static int launch_gconv(const HimAlgo& a, const GConvP& p, hipStream_t st) {
     return check_launch("gconv_fewin_tiled");
   }
   if (p.fast) {
-    // the fast kernel gathers through a buffer resource: 31-bit byte offsets (larger tensors: split the batch)
-    if ((unsigned long long)p.B * p.C2 * p.SH * p.SW * 4ull >= (1ull << 31))
-      return fail(HIM_E_UNSUPPORTED, "conv: source tensor of %llu bytes >= 2 GiB", (unsigned long long)p.B * p.C2 * p.SH * p.SW * 4ull);
+    // The fast kernel gathers through a buffer resource: 31-bit byte offsets.  A larger source tensor (C2 at >= 64 images
+    // per GPU on the 64-channel full-resolution planes) is launched in batch slices, each below 2 GiB -- the images of a
+    // batch are independent in the forward and the data gradient.
+    const unsigned long long img_bytes = (unsigned long long)p.C2 * p.SH * p.SW * 4ull;
+    if ((unsigned long long)p.B * img_bytes >= (1ull << 31)) {
+      if (p.wbatch || p.ksplit > 1 || img_bytes >= (1ull << 31))
+        return fail(HIM_E_UNSUPPORTED, "conv: source tensor of %llu bytes >= 2 GiB cannot be sliced along the batch",
+                    (unsigned long long)p.B * img_bytes);
+      const int per = (int)(((1ull << 31) - 1) / img_bytes);
+      for (int b0 = 0; b0 < p.B; b0 += per) {
+        GConvP q = p;
+        q.B = std::min(per, p.B - b0);
+        q.src = p.src + (size_t)b0 * p.C2 * p.SH * p.SW;
+        q.dst = p.dst + (size_t)b0 * p.M * p.DH * p.DW;
+        const int rcq = launch_gconv(a, q, st);
+        if (rcq) return rcq;
+      }
+      return HIM_OK;
+    }
     // HimAlgo::tile_wb (batched Winograd GEMMs) / tile_nb (direct-form convs); transposed weight tiles: 64x128 only
     const int tile_override = p.atrans ? HIM_TILE_64x128 : (p.wbatch ? a.tile_wb : a.tile_nb);
     const int ks = p.ksplit > 1 ? p.ksplit : 1;
@@ -460,11 +476,11 @@ static int wino_batched_gemm(const HimAlgo& a, const float* A, const float* Bm, 
 // dst[B][Mout][OH][OW] = act(winograd-conv(src[B][Csrc][H][W], U) + bias); ws holds V and Mo
 static int run_wino_conv(const HimAlgo& a, int B, int Csrc, int H, int W, int Mout, int OH, int OW, int po, bool reflect,
                          const float* src, const float* U, const float* bias, int act, float slope, float* dst,
-                         float* ws, hipStream_t st, bool fold = false, bool atrans = false) {
+                         float* ws, hipStream_t st, bool fold = false, bool atrans = false, float* keep = nullptr) {
   WinoGeom gi = wino_geom(B, Csrc, H, W, OH, OW, po);
   gi.fold = fold ? 1 : 0;
-  float* V = ws;
-  float* Mo = V + (size_t)16 * Csrc * gi.Tp;
+  float* V = keep ? keep : ws;     // keep: the caller's buffer for the transformed input (him_conv2d_fwd_panel_keep)
+  float* Mo = ws + (size_t)16 * Csrc * gi.Tp;
   const int tb = wino_tblock(a);
   const dim3 gin(cdiv(gi.Tp, tb), Csrc);
   if (reflect) hipLaunchKernelGGL((wino_input_kernel<true>), gin, dim3(tb), 0, st, src, V, gi);
@@ -479,6 +495,8 @@ static int run_wino_conv(const HimAlgo& a, int B, int Csrc, int H, int W, int Mo
                      act, slope);
   return check_launch("wino_output");
 }
+
+#include "him_conv_wino4.inc"
 
 #include "him_conv_wgrad.inc"
 
@@ -542,7 +560,7 @@ static size_t conv_wino_wgrad_floats(const HimConv2d* d) {
 // generic weight gradient: dW[M][C*KH*KW] from dy[B][M][OH][OW] and x[B][C][H][W]
 static int run_wgrad(const HimAlgo& a, const float* dy, const float* x, float* dw, int M, int C, int B, int H, int W, int OH,
                      int OW, int KH, int KW, int stride, int pad, int pad_mode, int accumulate, void* ws,
-                     size_t ws_bytes, hipStream_t st) {
+                     size_t ws_bytes, hipStream_t st, const float* kept_v = nullptr) {
   WGradP p;
   p.dy = dy;
   p.x = x;
@@ -574,13 +592,23 @@ static int run_wgrad(const HimAlgo& a, const float* dy, const float* x, float* d
     float* dM = Vt + (size_t)16 * C * gx.Tp;         // [16][M][Tp]
     float* dU = dM + (size_t)16 * M * gx.Tp;         // [16][M][C]
     const int tb = wino_tblock(a);
-    const dim3 gin(cdiv(C, tb), gx.Tp);
-    if (pad_mode == HIM_PAD_REFLECT) hipLaunchKernelGGL((wino_input_t_kernel<true>), gin, dim3(tb), 0, st, x, Vt, gx);
-    else hipLaunchKernelGGL((wino_input_t_kernel<false>), gin, dim3(tb), 0, st, x, Vt, gx);
-    hipLaunchKernelGGL(wino_dy_kernel, dim3(cdiv(gx.Tp, tb), M), dim3(tb), 0, st, dy, dM, gd);
-    int rcw = check_launch("wino_wgrad_transforms");
-    if (rcw) return rcw;
-    rcw = wino_batched_gemm(a, dM, Vt, dU, M, gx.Tp, C, st);
+    int rcw;
+    if (kept_v) {
+      // the forward's transformed input V[16][C][Tp] IS the column operand (tiles = the reduction index, contiguous):
+      // no transposed input transform, both GEMM operands K-contiguous (him_bgemm.inc, layouts (0, 0))
+      hipLaunchKernelGGL(wino_dy_kernel, dim3(cdiv(gx.Tp, tb), M), dim3(tb), 0, st, dy, dM, gd);
+      rcw = check_launch("wino_dy");
+      if (rcw) return rcw;
+      rcw = launch_bgemm(dM, kept_v, dU, M, gx.Tp, C, 16, 4, 0, 0, false, st);
+    } else {
+      const dim3 gin(cdiv(C, tb), gx.Tp);
+      if (pad_mode == HIM_PAD_REFLECT) hipLaunchKernelGGL((wino_input_t_kernel<true>), gin, dim3(tb), 0, st, x, Vt, gx);
+      else hipLaunchKernelGGL((wino_input_t_kernel<false>), gin, dim3(tb), 0, st, x, Vt, gx);
+      hipLaunchKernelGGL(wino_dy_kernel, dim3(cdiv(gx.Tp, tb), M), dim3(tb), 0, st, dy, dM, gd);
+      rcw = check_launch("wino_wgrad_transforms");
+      if (rcw) return rcw;
+      rcw = wino_batched_gemm(a, dM, Vt, dU, M, gx.Tp, C, st);
+    }
     if (rcw) return rcw;
     hipLaunchKernelGGL(wino_wgrad_out_kernel, dim3(cdiv(C, 256), M), dim3(256), 0, st, (const float*)dU, dw, M, C,
                        accumulate);
@@ -844,7 +872,17 @@ static bool wino_fused_dgrad_ok(const HimConv2d* d) {
   return d->pad_mode == HIM_PAD_ZERO && d->OH == d->H && d->OW == d->W &&
          wino_fused_ok(d->algo, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad, d->B, d->H, d->W);
 }
+// F(4x4,3x3) for frozen-weight layers (him_conv_wino4.inc); checked BEFORE the F(2x2,3x3) forms
+static bool wino4_fwd_ok(const HimConv2d* d) {
+  return wino4_shape_ok(d->algo, d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad, d->pad_mode, d->B, d->H, d->W);
+}
+static bool wino4_dgrad_ok(const HimConv2d* d) {
+  return d->OH == d->H && d->OW == d->W &&
+         wino4_shape_ok(d->algo, d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad, d->pad_mode, d->B, d->H, d->W);
+}
 static size_t fprop_ws_bytes(const HimConv2d* d) {
+  if (wino4_fwd_ok(d))
+    return (wino4_panel_floats(d->Cout, d->Cin) + wino4_ws_floats(d->B, d->Cout, d->Cin, d->H, d->W)) * sizeof(float) + 256;
   if (wino_fused_fwd_ok(d)) return wino_fused_panel_floats(d->Cout, d->Cin) * sizeof(float) + 256;
   if (wino_fwd_ok(d))
     return ((size_t)16 * d->Cout * d->Cin + wino_conv_floats(d->B, d->Cin, d->Cout, d->OH, d->OW)) * sizeof(float) + 256;
@@ -857,13 +895,27 @@ static size_t fprop_ws_bytes(const HimConv2d* d) {
 // floats of the regrouped weight panel the forward kernel reads (0: it reads the raw weights)
 static size_t fprop_panel_floats(const HimConv2d* d) {
   if (small_split_ok(d) || d->Cout <= 4 || !use_fast(d->algo, d->Cout, d->Cin)) return 0;
+  if (wino4_fwd_ok(d)) return wino4_panel_floats(d->Cout, d->Cin);
   if (wino_fused_fwd_ok(d)) return wino_fused_panel_floats(d->Cout, d->Cin);
   if (wino_fwd_ok(d)) return (size_t)16 * d->Cout * d->Cin;
   return (size_t)d->Cout * d->KH * d->KW * pad16(d->Cin);
 }
 // panel == nullptr: regroup the weights into the workspace on every call; build_only: write the panel to ws and return
 static int run_fprop(const HimConv2d* d, const float* x, const float* w, const float* bias, float* y, void* ws,
-                     size_t ws_bytes, hipStream_t st, const float* panel = nullptr, bool build_only = false) {
+                     size_t ws_bytes, hipStream_t st, const float* panel = nullptr, bool build_only = false,
+                     float* keep = nullptr) {
+  if (wino4_fwd_ok(d)) {
+    const size_t pf = wino4_panel_floats(d->Cout, d->Cin);
+    const size_t need = build_only ? pf * sizeof(float) : fprop_ws_bytes(d);
+    if (!ws || ws_bytes < need) return fail(HIM_E_WORKSPACE, "conv fwd needs %zu ws bytes, got %zu", need, ws_bytes);
+    float* U = (float*)ws;
+    if (!panel) {
+      hipLaunchKernelGGL((wino4_weight_kernel<0>), dim3(cdiv(d->Cin, 256), d->Cout), dim3(256), 0, st, w, U, d->Cout, d->Cin);
+      int rc = check_launch("wino4_weight");
+      if (rc || build_only) return rc;
+    }
+    return run_wino4_conv(d->B, d->Cin, d->H, d->W, d->Cout, x, panel ? panel : U, bias, d->act, d->slope, y, U + pf, st);
+  }
   if (wino_fused_fwd_ok(d)) {
     if (!panel) {
       const size_t need = wino_fused_panel_floats(d->Cout, d->Cin) * sizeof(float);
@@ -887,7 +939,8 @@ static int run_fprop(const HimConv2d* d, const float* x, const float* w, const f
       if (rc || build_only) return rc;
     }
     return run_wino_conv(d->algo, d->B, d->Cin, d->H, d->W, d->Cout, d->OH, d->OW, 1, d->pad_mode == HIM_PAD_REFLECT, x,
-                         panel ? panel : U, bias, d->act, d->slope, y, U + (size_t)16 * d->Cout * d->Cin, st);
+                         panel ? panel : U, bias, d->act, d->slope, y, U + (size_t)16 * d->Cout * d->Cin, st, false, false,
+                         keep);
   }
   GConvP g;
   fill_fprop(g, d, x, w, bias, y);
@@ -964,6 +1017,8 @@ static int dgrad_ksplit(const HimConv2d* d) {
   return fast_ksplit(d->algo, d->Cin, N, d->KH * d->KW * (pad16(d->Cout) / 16));
 }
 static size_t dgrad_ws_bytes(const HimConv2d* d) {
+  if (wino4_dgrad_ok(d))
+    return (wino4_panel_floats(d->Cin, d->Cout) + wino4_ws_floats(d->B, d->Cin, d->Cout, d->H, d->W)) * sizeof(float) + 256;
   if (wino_fused_dgrad_ok(d)) return wino_fused_panel_floats(d->Cin, d->Cout) * sizeof(float) + 256;
   if (wino_dgrad_ok(d)) return wino_dgrad_floats(d) * sizeof(float) + 256;
   size_t n = (size_t)d->Cin * pad16(d->Cout) * d->KH * d->KW + 64;
@@ -975,6 +1030,7 @@ static size_t dgrad_ws_bytes(const HimConv2d* d) {
   return n * sizeof(float) + 256;
 }
 static size_t dgrad_panel_floats(const HimConv2d* d) {
+  if (wino4_dgrad_ok(d)) return wino4_panel_floats(d->Cin, d->Cout);
   if (wino_fused_dgrad_ok(d)) return wino_fused_panel_floats(d->Cin, d->Cout);
   if (wino_dgrad_ok(d)) return (size_t)16 * d->Cin * d->Cout;
   return (size_t)d->Cin * (use_fast(d->algo, d->Cin, d->Cout) ? pad16(d->Cout) : d->Cout) * d->KH * d->KW;
@@ -985,6 +1041,18 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
                      bool build_only = false, const float* relu_mask = nullptr, bool* mask_done = nullptr) {
   const size_t need = build_only ? dgrad_panel_floats(d) * sizeof(float) : dgrad_ws_bytes(d);
   if (!ws || ws_bytes < need) return fail(HIM_E_WORKSPACE, "dgrad needs %zu ws bytes, got %zu", need, ws_bytes);
+  if (wino4_dgrad_ok(d)) {   // frozen weights, zero padding: the convolution of gy with the rotated / transposed filter
+    const size_t pf = wino4_panel_floats(d->Cin, d->Cout);
+    float* U = (float*)ws;
+    if (!panel) {
+      hipLaunchKernelGGL((wino4_weight_kernel<1>), dim3(cdiv(d->Cout, 256), d->Cin), dim3(256), 0, st, w, U, d->Cin, d->Cout);
+      int rcu = check_launch("wino4_weight");
+      if (rcu || build_only) return rcu;
+    }
+    if (mask_done) *mask_done = relu_mask != nullptr;   // the gate rides in the output transform
+    return run_wino4_conv(d->B, d->Cout, d->OH, d->OW, d->Cin, gy, panel ? panel : U, bias, act, slope, out, U + pf, st,
+                          relu_mask);
+  }
   if (wino_fused_dgrad_ok(d)) {   // zero-padded 3x3 stride-1: the convolution of gy with the flipped / transposed filter
     if (!panel) {
       hipLaunchKernelGGL((wino_fused_weight_kernel<1>), dim3(cdiv(d->Cout, 256), d->Cin), dim3(256), 0, st, w, (float*)ws,
@@ -1242,6 +1310,7 @@ size_t him_conv2d_panel_bytes(const HimConv2d* d, int kind) {
 
 int him_conv2d_bwd_data_shares_fwd_panel(const HimConv2d* d) {
   if (!d || check_conv(d)) return 0;
+  if (wino4_fwd_ok(d) || wino4_dgrad_ok(d)) return 0;
   return (!wino_fused_dgrad_ok(d) && wino_dgrad_ok(d) && !wino_fused_fwd_ok(d) && wino_fwd_ok(d)) ? 1 : 0;
 }
 
@@ -1296,6 +1365,46 @@ int him_conv2d_bwd_data_gated(const HimConv2d* d, const float* dy, const float* 
   hipLaunchKernelGGL(relu_gate_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 8192)), dim3(256), 0,
                      (hipStream_t)stream, x, dx, n);
   return check_launch("relu_gate");
+}
+
+// ---- kept Winograd input transform (include/him.h) ----
+static bool fwd_keep_ok(const HimConv2d* d) {
+  if (check_conv(d) || wino4_fwd_ok(d) || wino_fused_fwd_ok(d) || !wino_fwd_ok(d)) return false;
+  if (!wino_wgrad_ok(d->algo, d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad, d->H, d->W) || d->OH != d->H || d->OW != d->W)
+    return false;
+  const WinoGeom g = wino_geom(d->B, d->Cin, d->H, d->W, d->OH, d->OW, 1);
+  return !algo_off(d->algo, HIM_ALGO_NO_BGEMM) && bgemm_shape_ok(d->Cout, g.Tp, d->Cin, 16);
+}
+size_t him_conv2d_fwd_keep_bytes(const HimConv2d* d) {
+  if (!d || !fwd_keep_ok(d)) return 0;
+  const WinoGeom g = wino_geom(d->B, d->Cin, d->H, d->W, d->OH, d->OW, 1);
+  return (size_t)16 * d->Cin * g.Tp * sizeof(float);
+}
+int him_conv2d_fwd_panel_keep(const HimConv2d* d, const float* x, const void* panel, const float* bias, float* y, float* keep,
+                              void* ws, size_t ws_bytes, void* stream) {
+  int rc = check_conv(d);
+  if (rc) return rc;
+  if (!panel || !fprop_panel_floats(d)) return fail(HIM_E_INVALID, "conv fwd: no panel for this descriptor");
+  if (keep && !fwd_keep_ok(d)) return fail(HIM_E_UNSUPPORTED, "conv fwd: this layer has no transformed input to keep");
+  return run_fprop(d, x, nullptr, bias, y, ws, ws_bytes, (hipStream_t)stream, (const float*)panel, false, keep);
+}
+int him_conv2d_bwd_weight_kept(const HimConv2d* d, const float* keep, const float* dy, float* dw, float* dbias, int accumulate,
+                               void* ws, size_t ws_bytes, void* stream) {
+  int rc = check_conv(d);
+  if (rc) return rc;
+  if (!keep || !fwd_keep_ok(d)) return fail(HIM_E_INVALID, "conv bwd_weight_kept: no kept transform for this descriptor");
+  if (dw) {
+    rc = run_wgrad(d->algo, dy, nullptr, dw, d->Cout, d->Cin, d->B, d->H, d->W, d->OH, d->OW, d->KH, d->KW, d->stride, d->pad,
+                   d->pad_mode, accumulate, ws, ws_bytes, (hipStream_t)stream, keep);
+    if (rc) return rc;
+  }
+  if (dbias) {
+    const size_t off = wgrad_slab_bytes(d->algo, d->Cout, d->Cin, d->KH, d->KW, d->B * d->OH * d->OW, conv_wino_wgrad_floats(d));
+    if (ws_bytes < off) return fail(HIM_E_WORKSPACE, "bwd_weight ws too small");
+    rc = run_bias_grad(dy, dbias, d->B, d->Cout, d->OH * d->OW, accumulate, (char*)ws + off, ws_bytes - off,
+                       (hipStream_t)stream);
+  }
+  return rc;
 }
 
 size_t him_conv2d_bwd_weight_ws(const HimConv2d* d) {

@@ -147,6 +147,25 @@ static int nblocks(size_t n) {
 using namespace him;
 #define ST ((hipStream_t)stream)
 
+
+struct LinComb {
+  const float* t[8];
+  float* d[8];
+  float w[8];
+  int n;
+  float scale;
+};
+__global__ void lincomb_fwd_kernel(const LinComb p, float* __restrict__ out) {
+  if (threadIdx.x) return;
+  float acc = 0.f;
+  for (int i = 0; i < p.n; ++i) acc = __fadd_rn(acc, __fmul_rn(p.w[i], p.t[i][0]));
+  out[0] = __fmul_rn(acc, p.scale);
+}
+__global__ void lincomb_bwd_kernel(const LinComb p, const float* __restrict__ g) {
+  const int i = threadIdx.x;
+  if (i < p.n && p.d[i]) p.d[i][0] = __fmul_rn(__fmul_rn(g[0], p.scale), p.w[i]);
+}
+
 extern "C" {
 
 size_t him_reduce_ws(size_t n) {
@@ -240,6 +259,39 @@ int him_mse_const_bwd(const float* x, size_t n, float target, const float* g, fl
   hipLaunchKernelGGL(mse_bwd_kernel, dim3(nb), dim3(256), 0, ST, x, n, target, g, (float)(1.0 / (double)n), dx,
                      accumulate);
   return check_launch("mse_const_bwd");
+}
+
+
+// ---- scalar linear combinations of device scalars: the loss arithmetic of models/pix2pixHD_condImg_model.py:218-251 and
+// train_mask2image.py:68-76 ((D_fake + D_real) * 0.5, G_GAN + G_GAN_Feat + G_VGG, the per-scale GAN-loss sums, x * lambda)
+// as ONE launch forward and ONE backward instead of a chain of one-element ATen kernels.  out = scale * fl(sum_i fl(w_i t_i)),
+// summed left to right with every product and sum rounded to fp32 (no contraction) -- the reference's own order.
+int him_lincomb_fwd(const float* const* terms, const float* weights, int n, float scale, float* out, void* stream) {
+  if (n <= 0 || n > 8 || !terms || !weights || !out) return fail(HIM_E_INVALID, "lincomb: 1..8 terms");
+  LinComb p;
+  for (int i = 0; i < 8; ++i) {
+    p.t[i] = i < n ? terms[i] : nullptr;
+    p.w[i] = i < n ? weights[i] : 0.f;
+    p.d[i] = nullptr;
+  }
+  p.n = n;
+  p.scale = scale;
+  hipLaunchKernelGGL(lincomb_fwd_kernel, dim3(1), dim3(64), 0, ST, p, out);
+  return check_launch("lincomb_fwd");
+}
+/* dterms[i][0] = g[0] * scale * weights[i]  (NULL entries skipped) */
+int him_lincomb_bwd(const float* g, const float* weights, int n, float scale, float* const* dterms, void* stream) {
+  if (n <= 0 || n > 8 || !g || !weights || !dterms) return fail(HIM_E_INVALID, "lincomb: 1..8 terms");
+  LinComb p;
+  for (int i = 0; i < 8; ++i) {
+    p.t[i] = nullptr;
+    p.w[i] = i < n ? weights[i] : 0.f;
+    p.d[i] = i < n ? dterms[i] : nullptr;
+  }
+  p.n = n;
+  p.scale = scale;
+  hipLaunchKernelGGL(lincomb_bwd_kernel, dim3(1), dim3(64), 0, ST, p, g);
+  return check_launch("lincomb_bwd");
 }
 
 }  // extern "C"

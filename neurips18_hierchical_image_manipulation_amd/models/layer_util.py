@@ -66,6 +66,9 @@ class Vgg19(nn.Module):
         if not requires_grad:
             for p in self.parameters():
                 p.requires_grad = False
+                # the weights never change: descriptors of these layers carry HIM_ALGO_FROZEN_WEIGHTS (Winograd
+                # F(4x4,3x3) for the >= 256-channel convolutions, panels built once per run)
+                p._him_frozen = True
 
     def load_torchvision_state_dict(self, sd):
         """Accepts torchvision's ``features.<idx>.{weight,bias}`` naming."""

@@ -335,29 +335,35 @@ class Pix2PixHDModel_condImg(BaseModel):
                 pred_fake = self.netD.forward(self._d_input(netD_cond, fake_image, mask_cond))
         loss_G_GAN = self.criterionGAN(pred_fake, True)
 
-        loss_G_GAN_Feat = torch.zeros(1, device=self.device)
+        loss_G_GAN_Feat = None
         if not opt.no_ganFeat_loss:
             feat_weights = 4.0 / (opt.n_layers_D + 1)
             D_weights = 1.0 / opt.num_D
             pairs = [(pred_fake[i][j], pred_real[i][j]) for i in range(opt.num_D) for j in range(len(pred_fake[i]) - 1)]
             # D_weights * feat_weights * L1 * lambda_feat per term (reference :235-242), folded into one weight vector
             w = float(np.float32(np.float32(D_weights * feat_weights)) * np.float32(opt.lambda_feat))
-            loss_G_GAN_Feat = loss_G_GAN_Feat + ops.l1_weighted_sum(pairs, [w] * len(pairs))
+            loss_G_GAN_Feat = ops.l1_weighted_sum(pairs, [w] * len(pairs))
 
-        loss_G_VGG = torch.zeros(1, device=self.device)
+        loss_G_VGG = None
         if vgg_side is not None:
             torch.cuda.current_stream(self.device).wait_stream(ops._vgg_stream(self.device))
-            loss_G_VGG = vgg_side * opt.lambda_feat
+            loss_G_VGG = ops.lincomb([vgg_side], [opt.lambda_feat])
             if getattr(self, '_vgg_bwd_early', False):
                 # optimize_parameters() differentiates this term on its own, from ``vgg_side`` on the VGG stream and BEFORE
                 # loss_D.backward() (see there): the value stays in loss_G, the graph does not
                 self._vgg_early = (vgg_side, fake_image)
                 loss_G_VGG = loss_G_VGG.detach()
         elif not opt.no_vgg_loss:
-            loss_G_VGG = self.criterionVGG(fake_image, real_image,
-                                           ahead['y_vgg'] if ahead is not None else None) * opt.lambda_feat
+            loss_G_VGG = ops.lincomb([self.criterionVGG(fake_image, real_image,
+                                                        ahead['y_vgg'] if ahead is not None else None)], [opt.lambda_feat])
         if opt.lambda_rec > 0:
-            loss_G_GAN_Feat = loss_G_GAN_Feat + self.criterionFeat(fake_image, real_image) * opt.lambda_rec
+            rec = self.criterionFeat(fake_image, real_image)
+            loss_G_GAN_Feat = ops.lincomb([rec] if loss_G_GAN_Feat is None else [loss_G_GAN_Feat, rec],
+                                          [opt.lambda_rec] if loss_G_GAN_Feat is None else [1.0, opt.lambda_rec])
+        if loss_G_GAN_Feat is None:
+            loss_G_GAN_Feat = torch.zeros(1, device=self.device)
+        if loss_G_VGG is None:
+            loss_G_VGG = torch.zeros(1, device=self.device)
 
         # kept on the device (the reference does four blocking .cpu() copies here every step, :253-256)
         self._visuals = (fake_image.detach(), real_image, input_mask, cond_image)
@@ -392,10 +398,12 @@ class Pix2PixHDModel_condImg(BaseModel):
     # the optimisation step: train_mask2image.py:68-86
     # ------------------------------------------------------------------------------------------
     def combine_losses(self, losses):
-        losses = [torch.mean(x) if not isinstance(x, int) else x for x in losses]
+        # torch.mean over the (DataParallel) replica axis: one process per GPU holds ONE value per loss -- a view, no kernel
+        losses = [(x.reshape(()) if x.numel() == 1 else torch.mean(x)) if not isinstance(x, int) else x for x in losses]
         loss_dict = dict(zip(self.loss_names, losses))
-        self.loss_D = (loss_dict['D_fake'] + loss_dict['D_real']) * 0.5
-        self.loss_G = loss_dict['G_GAN'] + loss_dict['G_GAN_Feat'] + loss_dict['G_VGG']
+        # (D_fake + D_real) * 0.5 and G_GAN + G_GAN_Feat + G_VGG (train_mask2image.py:70-71), one launch each
+        self.loss_D = ops.lincomb([loss_dict['D_fake'], loss_dict['D_real']], scale=0.5)
+        self.loss_G = ops.lincomb([loss_dict['G_GAN'], loss_dict['G_GAN_Feat'], loss_dict['G_VGG']])
         return loss_dict
 
     def _run_backward_G(self, last=False, extra_root=None):

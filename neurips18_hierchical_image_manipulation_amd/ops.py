@@ -392,7 +392,7 @@ class _Conv2d(torch.autograd.Function):
         ctx.set_materialize_grads(False)   # an undefined gradient stays None: backward returns early
         x = x.contiguous()
         _chk(x, w, b)
-        d = _conv_desc(x, w, stride, pad, pad_mode, act, slope)
+        d = _conv_desc(x, w, stride, pad, pad_mode, act, slope, frozen=bool(getattr(w, '_him_frozen', False)))
         if premasked and act != ACT_RELU:
             raise HimError('conv2d: only a ReLU gate can be applied by the producers of the output gradient')
         ctx.premasked, ctx.gate_dx = bool(premasked), bool(gate_dx)
@@ -400,12 +400,20 @@ class _Conv2d(torch.autograd.Function):
         nb = lib.him_conv2d_fwd_ws(ctypes.byref(d))
         ws = _ws(nb, x)
         pan = _panel(w, d, PANEL_FWD, False)
-        if pan:
+        keep = None
+        if pan and SCHED.keep_wino_input and ctx.needs_input_grad[1] and _direct(w):
+            # separate-transform Winograd layer whose weight gradient will be taken: keep the transformed input
+            nk = int(lib.him_conv2d_fwd_keep_bytes(ctypes.byref(d)))
+            if nk:
+                keep = torch.empty(nk // 4, dtype=torch.float32, device=x.device)
+        if keep is not None:
+            lib.him_conv2d_fwd_panel_keep(ctypes.byref(d), _p(x), pan, _p(b), _p(y), _p(keep), _p(ws), nb, _stream())
+        elif pan:
             lib.him_conv2d_fwd_panel(ctypes.byref(d), _p(x), pan, _p(b), _p(y), _p(ws), nb, _stream())
         else:
             lib.him_conv2d_fwd(ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), _p(ws), nb, _stream())
         ctx.d = d
-        ctx.x, ctx.w, ctx.b = x, w, b
+        ctx.x, ctx.w, ctx.b, ctx.keep = x, w, b, keep
         ctx.gslice = getattr(x, '_him_grad_slice', None)
         # the OUTPUT must go through save_for_backward: a plain ctx attribute closes a tensor -> grad_fn -> ctx -> tensor
         # cycle through C++ that no collector sees, and with it the whole upstream graph of every step leaks
@@ -457,10 +465,14 @@ class _Conv2d(torch.autograd.Function):
         if need_w or need_b:
             nb = lib.him_conv2d_bwd_weight_ws(ctypes.byref(d))
             if need_w and _direct(w) and (not need_b or _direct(b)):
-                with _wgrad_stream(x, dz):
+                with _wgrad_stream(x, dz, ctx.keep):
                     ws = _ws(nb, x)
-                    lib.him_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dz), _p(w.grad),
-                                              _p(b.grad) if need_b else 0, 1, _p(ws), nb, _stream())
+                    if ctx.keep is not None:
+                        lib.him_conv2d_bwd_weight_kept(ctypes.byref(d), _p(ctx.keep), _p(dz), _p(w.grad),
+                                                       _p(b.grad) if need_b else 0, 1, _p(ws), nb, _stream())
+                    else:
+                        lib.him_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dz), _p(w.grad),
+                                                  _p(b.grad) if need_b else 0, 1, _p(ws), nb, _stream())
                     _notify(w)
                     if need_b:
                         _notify(b)
@@ -469,6 +481,7 @@ class _Conv2d(torch.autograd.Function):
                 dw = torch.empty_like(w) if need_w else None
                 db = torch.empty_like(b) if need_b else None
                 lib.him_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dz), _p(dw), _p(db), 0, _p(ws), nb, st)
+        ctx.keep = None
         return dx, dw, db, None, None, None, None, None, None, None
 
 
@@ -1466,6 +1479,45 @@ def l1_weighted_sum(pairs, weights, gate_relu=False):
     if wvec is None:
         wvec = _WVEC_CACHE[key] = torch.tensor(key[1], dtype=torch.float32, device=dev)
     return _L1WeightedSum.apply(wvec, bool(gate_relu), *([a for a, _ in pairs] + [b.detach() for _, b in pairs]))
+
+
+class _LinComb(torch.autograd.Function):
+    """scale * sum_i w_i * t_i over one-element tensors as ONE node / ONE launch each way (him_lincomb_*): the scalar loss
+    arithmetic of the trainer, which as torch expressions was ~45 one-element ATen kernels per step."""
+
+    @staticmethod
+    def forward(ctx, weights, scale, *terms):
+        ctx.set_materialize_grads(False)
+        n = len(terms)
+        ts = [t.contiguous() for t in terms]
+        _chk(*ts)
+        if any(t.numel() != 1 for t in ts):
+            raise HimError('lincomb: one-element tensors only')
+        ctx.weights, ctx.scale, ctx.shapes = tuple(float(w) for w in weights), float(scale), [t.shape for t in ts]
+        out = torch.empty((), dtype=torch.float32, device=ts[0].device)
+        ptrs = (ctypes.c_void_p * n)(*[_p(t) for t in ts])
+        ws = (ctypes.c_float * n)(*ctx.weights)
+        lib.him_lincomb_fwd(ptrs, ws, n, ctx.scale, _p(out), _stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n = len(ctx.weights)
+        if g is None:
+            return (None,) * (n + 2)
+        g = g.contiguous()
+        need = ctx.needs_input_grad[2:]
+        outs = [torch.empty(s, dtype=torch.float32, device=g.device) if nd else None for s, nd in zip(ctx.shapes, need)]
+        ptrs = (ctypes.c_void_p * n)(*[_p(o) for o in outs])
+        ws = (ctypes.c_float * n)(*ctx.weights)
+        lib.him_lincomb_bwd(_p(g), ws, n, ctx.scale, ptrs, _stream())
+        return (None, None) + tuple(outs)
+
+
+def lincomb(terms, weights=None, scale=1.0):
+    """scale * (w_0 t_0 + w_1 t_1 + ...), left to right in fp32, over one-element tensors (default weights: 1)."""
+    terms = list(terms)
+    return _LinComb.apply(tuple(weights) if weights is not None else (1.0,) * len(terms), scale, *terms)
 
 
 class _MSEConst(torch.autograd.Function):

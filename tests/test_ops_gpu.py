@@ -405,6 +405,71 @@ def test_winograd_conv3x3_fwd_bwd(case):
         ops.set_winograd_min_channels(prev)
 
 
+WINO4_CASES = [
+    # B, Cin, H, W, Cout   (frozen weights, zero padding, planes multiples of 4, >= 256 channels on both sides)
+    (2, 256, 16, 32, 256),       # VGG conv3_x family
+    (1, 256, 8, 12, 512),        # conv4_1 family: rectangular, 6 tiles padded to 128
+    (3, 512, 4, 4, 512),         # one tile per image
+    (8, 256, 64, 128, 256),      # conv3_2..3_4 at the benchmark size (C2)
+    (8, 512, 32, 64, 512),       # conv4_2..4_4 at the benchmark size
+]
+
+
+@pytest.mark.parametrize('case', WINO4_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_winograd_f4x4_frozen_conv_fwd_and_gated_dgrad(case):
+    """Winograd F(4x4,3x3) of the frozen-weight layers (him_conv_wino4.inc: 36-position transforms + the LDS-DMA batched
+    GEMM): conv + bias + ReLU forward and the ReLU-gated data gradient against the fp32 torch reference of the SAME op.
+    Tolerance 3e-5 of max|ref| (F(4x4)'s transform constants cost ~3e-6 per convolution); the same call
+    WITHOUT the frozen mark must take the F(2x2) / direct kernels and agree to 2e-5."""
+    ops = _ops()
+    B, Cin, H, W, Cout = case
+    x = _rand(B, Cin, H, W, seed=1)
+    xin = torch.relu(x).requires_grad_(True)                  # the layer's input is a ReLU output (VGG chain)
+    w = _rand(Cout, Cin, 3, 3, seed=2, scale=(Cin * 9) ** -0.5)
+    b = _rand(Cout, seed=3, scale=0.1)
+    # full-size cases: no ReLU on THIS layer's output -- among 16 M outputs a handful land within rounding of 0, their ReLU
+    # decision flips between two fp32 summation orders and moves the data gradient by O(|gy w|) there (as in
+    # test_winograd_conv3x3_fwd_bwd); the gate on the INPUT (identical data on both sides) stays
+    act = 'relu' if B * H * W < 4096 else 'none'
+    y_ref = _ref_conv(xin, w, b, 1, 1, 'zero', act)
+    gy = _rand(*y_ref.shape, seed=4)
+    (gx_ref,) = torch.autograd.grad(y_ref, xin, gy)
+    gx_ref = gx_ref * (xin.detach() > 0)                      # gate_dx: dx = (x > 0) * dgrad
+    got = {}
+    for frozen in (True, False):
+        wd = torch.nn.Parameter(w.to(DEV), requires_grad=False)
+        if frozen:
+            wd._him_frozen = True
+        xd = xin.detach().to(DEV).requires_grad_(True)
+        y = ops.conv2d(xd, wd, b.to(DEV), 1, 1, 'zero', act, 0.2, gate_dx=True)
+        (gx,) = torch.autograd.grad(y, xd, gy.to(DEV))
+        assert_close('fwd frozen=%s' % frozen, y, y_ref, rtol=3e-5 if frozen else 2e-5)
+        assert_close('gated dgrad frozen=%s' % frozen, gx, gx_ref, rtol=3e-5 if frozen else 2e-5)
+        got[frozen] = y.detach()
+    assert not torch.equal(got[True], got[False]), 'the frozen mark must select the F(4x4) kernels'
+
+
+def test_conv_source_tensor_above_2_gib_is_sliced_along_the_batch():
+    """Buffer-resource addressing caps ONE launch's source tensor at 2 GiB (31-bit byte offsets); C2 at >= 64 images per
+    GPU crosses it on the 64-channel full-resolution planes.  The dispatch then slices the batch: forward and
+    data gradient of a 66 x 64 x 256 x 512 input (2.2 GiB) against the torch reference on three of its images."""
+    ops = _ops()
+    B, C, H, W = 66, 64, 256, 512
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(B, C, H, W, device=DEV, generator=g).requires_grad_(True)
+    w = (_rand(C, C, 3, 3, seed=2) * (C * 9) ** -0.5).to(DEV)
+    assert x.numel() * 4 >= (1 << 31)
+    y = ops.conv2d(x, w, None, 1, 1, 'zero', 'none', 0.2)
+    gy = torch.randn(y.shape, device=DEV, generator=g)
+    (gx,) = torch.autograd.grad(y, x, gy)
+    for b in (0, 31, 32, 65):
+        xr = x.detach()[b:b + 1].cpu().requires_grad_(True)
+        yr = F.conv2d(xr, w.cpu(), None, 1, 1)
+        (gr,) = torch.autograd.grad(yr, xr, gy[b:b + 1].cpu())
+        assert_close('fwd image %d' % b, y[b:b + 1], yr, rtol=2e-5)
+        assert_close('dgrad image %d' % b, gx[b:b + 1], gr, rtol=2e-5)
+
+
 def test_library_is_reentrant():
     """include/him.h "Algorithm selection": two host threads drive the C ABI concurrently -- each on its own HIP stream,
     one with the Winograd forms ON (threshold 16 channels), the other with every Winograd form OFF -- through the
