@@ -140,10 +140,10 @@ def dominant_kernel_roofline(device, bs, ntiles):
     [16] x (1024 x 1024) x (1024 x ntiles) with ntiles = B * H/2 * W/2 (C2: 8x8x16 = 1024, 34.36 GFLOP EXECUTED per
     launch; the direct form of the same conv is 77.31 GFLOP: Winograd does 2.25x fewer multiplies).  18 forward + 18
     data-gradient + 18 weight-gradient launches of this shape per step.
-    `achieved` = executed FLOP / `avg_launch_ms`, the average duration of ONE launch: issued through the C ABI
-    (him_winograd_gemm = exactly the kernel / grid the conv launches) between two HIP events on the launch stream with
-    the device drained before each launch (`avg_launch_ms_back_to_back`: 20 launches between one event pair -- the tails
-    overlap, 3-4 % shorter).  `source: "microbench"`: these are NOT the launches inside the timed training step, which
+    `achieved` = executed FLOP / `avg_launch_ms`, the average over 20 launches issued back to back through the C ABI
+    (him_winograd_gemm = exactly the kernel / grid the conv launches) between two HIP events on the launch stream -- the
+    protocol of the committed rocprofv3 trace (round 3's `frac` used one launch per event pair with the device drained in
+    between, 3-4 % more flattering; that figure stays as `avg_launch_ms_single_drained`).  `source: "microbench"`: these are NOT the launches inside the timed training step, which
     share the GPU with other streams; `rocprof` quotes the committed rocprofv3 kernel trace (profiles/
     r<NN>_dominant_kernel_rocprof.json, written by tools/collect_profiles.sh): the same launch isolated -- which
     `avg_launch_ms` must agree with -- and its average inside the traced step.  MFMA-bound: algorithmic bytes = the three
@@ -163,8 +163,8 @@ def dominant_kernel_roofline(device, bs, ntiles):
     gemm = lambda: lib.him_winograd_gemm(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, K, N, None, st)  # noqa: E731
     for _ in range(3):
         gemm()
-    ms_b2b = _event_ms(gemm, 20)
-    ms = _event_ms_isolated(gemm, 20)
+    ms = _event_ms(gemm, 20)              # 20 launches back to back between ONE event pair: what a kernel trace averages
+    ms_single = _event_ms_isolated(gemm, 20)
     flops = 2.0 * 16 * M * K * N
     ach = flops / (ms * 1e-3) / 1e12
     # the whole conv launch, as the trainer runs it (Parameter weight: cached Winograd panel)
@@ -192,15 +192,19 @@ def dominant_kernel_roofline(device, bs, ntiles):
                        avg_launch_ms_in_step=kt.get('in_step_avg_launch_ms'),
                        frac_isolated=kt.get('frac_of_f32_mfma_peak'), frac_in_step=kt.get('in_step_frac_of_f32_mfma_peak'))
     return dict(bound='mfma', source='microbench',
-                kernel='batched Winograd GEMM [16]x(1024x1024)x(1024x%d) on the fp32-MFMA conv kernel '
-                       '(ResnetBlock conv3x3 1024->1024, bs %d)' % (N, bs),
+                kernel='batched Winograd GEMM [16]x(1024x1024)x(1024x%d), bgemm_kernel (fp32 MFMA, LDS-DMA operands; '
+                       'ResnetBlock conv3x3 1024->1024, bs %d)' % (N, bs),
                 achieved=round(ach, 2), peak=PEAK_F32_MFMA, unit='TFLOP/s', frac=round(ach / PEAK_F32_MFMA, 4),
-                frac_is='achieved / peak with achieved = flop_per_launch / avg_launch_ms (ONE launch between two HIP '
-                        'events on the launch stream, device drained before each); rocprof.* = the committed rocprofv3 '
-                        'kernel trace: the same launch isolated, and its average inside the traced training step',
+                frac_is='achieved / peak with achieved = flop_per_launch / avg_launch_ms, avg_launch_ms = 20 launches '
+                        'back to back between two HIP events on the launch stream (the protocol of the committed rocprofv3 '
+                        'trace of tools/gemm_bench.py, rocprof.avg_launch_ms_isolated, which it must agree with up to the '
+                        '2-6 % lower clock of a profiled run); avg_launch_ms_single_drained = one launch per event pair with '
+                        'the device drained in between; rocprof.*_in_step = the same launches inside the traced training step',
+
                 traffic=traffic, traffic_unit='bytes/launch (PMC, corrected)', traffic_source=traffic_src,
                 algorithmic_bytes=16 * 4 * (M * K + K * N + M * N),
-                flop_per_launch=flops, avg_launch_ms=round(ms, 4), avg_launch_ms_back_to_back=round(ms_b2b, 4),
+                flop_per_launch=flops, avg_launch_ms=round(ms, 4), avg_launch_ms_single_drained=round(ms_single, 4),
+                frac_single_drained=round(flops / (ms_single * 1e-3) / 1e12 / PEAK_F32_MFMA, 4),
                 rocprof=rocprof,
                 conv_launch=dict(ms=round(cms, 4), direct_form_gflop=round(direct / 1e9, 2),
                                  direct_form_equivalent_tflops=round(direct / (cms * 1e-3) / 1e12, 1),

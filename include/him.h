@@ -80,6 +80,7 @@ const char* him_last_error(void);
 #define HIM_ALGO_GENERIC_CONV (1u << 7)     /* generic implicit-GEMM kernels instead of the buffer-load fast path */
 #define HIM_ALGO_NO_RESBLOCK_FUSED (1u << 8)/* him_resblock_supported() answers 0 */
 #define HIM_ALGO_NO_BGEMM (1u << 10)        /* batched Winograd GEMMs on the conv kernel instead of the LDS-DMA GEMM kernel */
+#define HIM_ALGO_NO_ONEHOT_RLE (1u << 11)   /* one-hot stem weight gradient per pixel (round-1 kernel) instead of per run of equal class */
 #define HIM_ALGO_FROZEN_WEIGHTS (1u << 9)   /* the layer's weights never change (VGG19 of the perceptual loss,
                                                models/layer_util.py:380-411): forward / data gradient may use Winograd
                                                F(4x4,3x3), whose 36-position panel is built once per run */
@@ -102,7 +103,7 @@ void him_algo_resolve(const HimAlgo* in, HimAlgo* out);
 /* Development aid for tools/: zero-fills *a, then applies the HIM_* environment overrides (HIM_NO_WINOGRAD,
  * HIM_WINO_MIN_C, HIM_NO_WINO_FUSED, HIM_WINO_FUSED_MIN_C / _MAX_C, HIM_WINO4_MIN_C, HIM_KSPLIT_MAX, HIM_NO_SPLITK,
  * HIM_GCONV_TILE[_WB|_NB], HIM_WINO_TBLOCK, HIM_WGRAD_SPLITS, HIM_NO_DFOLD, HIM_WINO_PADDED_DGRAD, HIM_NO_SMALL_WIN,
- * HIM_NO_FEWOUT_TILED, HIM_NO_FEWIN_TILED, HIM_NO_FEWCH_MFMA, HIM_GENERIC_CONV, HIM_NO_RESBLOCK_FUSED, HIM_NO_BGEMM).  The ONLY place
+ * HIM_NO_FEWOUT_TILED, HIM_NO_FEWIN_TILED, HIM_NO_FEWCH_MFMA, HIM_GENERIC_CONV, HIM_NO_RESBLOCK_FUSED, HIM_NO_BGEMM, HIM_NO_ONEHOT_RLE).  The ONLY place
  * the library reads the environment; nothing else calls it. */
 void him_algo_from_env(HimAlgo* a);
 

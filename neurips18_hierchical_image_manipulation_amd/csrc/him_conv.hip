@@ -1270,7 +1270,8 @@ void him_algo_from_env(HimAlgo* a) {
       {"HIM_WINO_PADDED_DGRAD", HIM_ALGO_WINO_PADDED_DGRAD}, {"HIM_NO_SMALL_WIN", HIM_ALGO_NO_SMALL_WIN},
       {"HIM_NO_FEWOUT_TILED", HIM_ALGO_NO_FEWOUT_TILED}, {"HIM_NO_FEWIN_TILED", HIM_ALGO_NO_FEWIN_TILED},
       {"HIM_NO_FEWCH_MFMA", HIM_ALGO_NO_FEWCH_MFMA},   {"HIM_GENERIC_CONV", HIM_ALGO_GENERIC_CONV},
-      {"HIM_NO_RESBLOCK_FUSED", HIM_ALGO_NO_RESBLOCK_FUSED}, {"HIM_NO_BGEMM", HIM_ALGO_NO_BGEMM}};
+      {"HIM_NO_RESBLOCK_FUSED", HIM_ALGO_NO_RESBLOCK_FUSED}, {"HIM_NO_BGEMM", HIM_ALGO_NO_BGEMM},
+      {"HIM_NO_ONEHOT_RLE", HIM_ALGO_NO_ONEHOT_RLE}};
   for (const auto& f : flags)
     if (getenv(f.k)) a->disable |= f.bit;
 }
@@ -1499,7 +1500,26 @@ int him_conv2d_onehot_bwd_weight(const HimConv2d* d, const float* label, int n_o
   p.reflect = d->pad_mode == HIM_PAD_REFLECT;
   p.Cout = d->Cout;
   p.npix = d->B * HW;
-  if (dw) {
+  if (dw && onehot_rle_ok(d, NC)) {   // run-length form (him_conv_onehot.inc): dy read once, cost per run of equal class
+    int nbands, rows_per;
+    onehot_rle_geom(d, &nbands, &rows_per);
+    const int nblk = d->B * nbands;
+    const size_t lds = onehot_rle_lds_bytes(d, NC);
+#define HIM_OH_RLE(KSv)                                                                                              \
+  {                                                                                                                  \
+    (void)hipFuncSetAttribute((const void*)onehot_wgrad_rle_kernel<KSv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((onehot_wgrad_rle_kernel<KSv>), dim3(nblk, d->Cout / 8), dim3(512), lds, st, p, dy, part, nbands, \
+                       rows_per);                                                                                    \
+  }
+    if (d->KH == 7) HIM_OH_RLE(7)
+    else if (d->KH == 5) HIM_OH_RLE(5)
+    else HIM_OH_RLE(3)
+#undef HIM_OH_RLE
+    hipLaunchKernelGGL(onehot_wgrad_reduce_kernel, dim3(cdiv((long long)KK * NC * d->Cout, 256)), dim3(256), 0, st,
+                       (const float*)part, dw, nblk, d->Cout, d->Cin, NC, KK, accumulate);
+    rc = check_launch("onehot_wgrad_rle");
+    if (rc) return rc;
+  } else if (dw) {
     int nsx, nyc, rows_per;
     onehot_wgrad_geom(d, &nsx, &nyc, &rows_per);
     const int nblk = d->B * nsx * nyc;
@@ -1518,6 +1538,8 @@ int him_conv2d_onehot_bwd_weight(const HimConv2d* d, const float* label, int n_o
                        (const float*)part, dw, nblk, d->Cout, d->Cin, NC, KK, accumulate);
     rc = check_launch("onehot_wgrad");
     if (rc) return rc;
+  }
+  if (dw) {
     if (Cd > 0) {
       float* dwd = xd + ((size_t)d->B * Cd * HW + 63) / 64 * 64;
       float* wws = dwd + ((size_t)d->Cout * Cd * KK + 63) / 64 * 64;

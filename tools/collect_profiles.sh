@@ -25,7 +25,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES 
   d=$OUT/pmc_$(echo $grp | cut -d' ' -f1)
   rocprofv3 --pmc $grp --kernel-trace -f csv -d $d -- python $ROOT/tools/gemm_bench.py 10 > $d.log 2>&1
 done
-python $ROOT/tools/pmc_collect.py gconv_fast_kernel 2048 $OUT/${TAG}_pmc_dominant_kernel.json $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_TCC_HIT_sum $OUT/pmc_SQ_WAVE_CYCLES > $OUT/pmc_collect.log 2>&1
+python $ROOT/tools/pmc_collect.py bgemm_kernel 1024 $OUT/${TAG}_pmc_dominant_kernel.json $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_TCC_HIT_sum $OUT/pmc_SQ_WAVE_CYCLES > $OUT/pmc_collect.log 2>&1
 rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_TCC_HIT_sum $OUT/pmc_SQ_WAVE_CYCLES
 # 3. the two few-channel weight gradients VERDICT r2 named (head 64->3, one-hot stem): kernel trace + FETCH / WRITE passes
 python $ROOT/tools/worst_kernels_bench.py 10 > $OUT/worst_kernels_bench.log 2>&1

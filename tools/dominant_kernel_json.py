@@ -1,7 +1,8 @@
 #!/usr/bin/env python
-"""profiles/r<NN>_dominant_kernel_rocprof.json: the dominant launch (batched Winograd GEMM, gconv_fast_kernel<2,2,1,2,0,false>
-on a grid of 16 * (1024/64) * (1024/128) = 2048 workgroups; until round 3's tile change <2,2,2,2,0,false> on 1024) as rocprofv3 --kernel-trace saw it (a) alone, in the trace of
-tools/gemm_bench.py, and (b) inside the traced training step of bench.py.
+"""profiles/r<NN>_dominant_kernel_rocprof.json: the dominant launch (batched Winograd GEMM; round 4: bgemm_kernel<0,1> -- and
+<1,1> for the data gradients on the forward panel, <0,0> for the weight gradients on the kept input transform -- on a grid
+of 16 * (1024/128)^2 = 1024 workgroups; rounds 2-3: gconv_fast_kernel on 2048 / 1024) as rocprofv3 --kernel-trace saw it
+(a) alone, in the trace of tools/gemm_bench.py, and (b) inside the traced training step of bench.py.
 Usage: python tools/dominant_kernel_json.py <gemm_trace dir|db> <bench_trace dir|db> <out.json>"""
 import glob
 import json
@@ -10,7 +11,8 @@ import sqlite3
 import sys
 
 PEAK, FLOP = 157.3, 2.0 * 16 * 1024 ** 3
-KERNEL, GRID = 'gconv_fast_kernel<2, 2, 1, 2, 0, false>', 2048     # + the <.., 3, false> form of the data gradients (transposed panel)
+KERNELS, GRID = ('bgemm_kernel<0, 1>', 'bgemm_kernel<1, 1>', 'bgemm_kernel<0, 0>'), 1024
+KERNEL = 'bgemm_kernel<0,1> / <1,1> / <0,0>'
 
 
 def durations(path, need_adam):
@@ -22,7 +24,7 @@ def durations(path, need_adam):
         adam = [r[2] for r in rows if 'adam_kernel' in r[0]]
         lo, hi = adam[len(adam) // 3], adam[-1]
         rows = [r for r in rows if r[1] >= lo and r[2] <= hi]
-    sel = [r[2] - r[1] for r in rows if (KERNEL in r[0] or KERNEL.replace('0, false', '3, false') in r[0])
+    sel = [r[2] - r[1] for r in rows if any(k in r[0] for k in KERNELS)
            and r[3] // max(r[6], 1) == GRID and r[4] == 1 and r[5] == 1]
     return sel
 
@@ -30,7 +32,7 @@ def durations(path, need_adam):
 def main():
     iso, step = durations(sys.argv[1], False), durations(sys.argv[2], True)
     iso = iso[3:] if len(iso) > 6 else iso        # warm-up launches of the microbench
-    out = dict(N=1024, kernel='%s grid %d' % (KERNEL.replace(', ', ','), GRID), launches=len(iso),
+    out = dict(N=1024, kernel='%s grid %d' % (KERNEL, GRID), launches=len(iso),
                avg_launch_ms=round(sum(iso) / len(iso) / 1e6, 4),
                executed_tflops=round(FLOP / (sum(iso) / len(iso) * 1e-9) / 1e12, 2))
     out['frac_of_f32_mfma_peak'] = round(out['executed_tflops'] / PEAK, 4)
