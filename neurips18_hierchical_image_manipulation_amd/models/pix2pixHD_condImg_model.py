@@ -581,8 +581,22 @@ class Pix2PixHDModel_condImg(BaseModel):
         """Make the current stream wait for a generator update still running on the optimizer stream."""
         if getattr(self, '_g_update_pending', False):
             from ..dist import timed_wait
-            timed_wait(torch.cuda.current_stream(self.device), ops._opt_stream(self.device),
-                       self.comm_timing['g_update_tail'] if self.comm_timing else None)
+            cur = torch.cuda.current_stream(self.device)
+            ev = getattr(self.optimizer_G, 'updated', None) if SCHED.panel_pipeline else None
+            if ev is None:
+                timed_wait(cur, ops._opt_stream(self.device), self.comm_timing['g_update_tail'] if self.comm_timing else None)
+            else:
+                # wait for the Adam kernel only: the weight panels are rebuilt behind it in forward order and every conv
+                # waits for ITS panel's event (ops._panel), so the forward runs down the net behind the rebuild pass
+                sink = self.comm_timing['g_update_tail'] if self.comm_timing else None
+                if sink is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(cur)
+                    cur.wait_event(ev)
+                    e1.record(cur)
+                    sink.append((e0, e1))
+                else:
+                    cur.wait_event(ev)
             self._g_update_pending = False
 
     def _wait_d_update(self, stream=None):

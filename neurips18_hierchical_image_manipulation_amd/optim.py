@@ -108,6 +108,10 @@ class FusedAdam(object):
         for (s, e, lr, b1, b2, eps) in self._runs():
             lib.him_adam_step(a.data.data_ptr() + 4 * s, a.grad.data_ptr() + 4 * s, self.exp_avg.data_ptr() + 4 * s,
                               self.exp_avg_sq.data_ptr() + 4 * s, e - s, lr, b1, b2, eps, self.step_count, _stream())
+        # everything that reads the RAW parameters may start here; every cached weight panel carries its own event
+        # (ops._panel waits for it), so a consumer need not wait for the whole rebuild pass below
+        self.updated = torch.cuda.Event()
+        self.updated.record(torch.cuda.current_stream(a.data.device))
         from .ops import refresh_panels
         refresh_panels(a.params)               # regrouped weight panels of the conv kernels follow the update
 
