@@ -35,6 +35,7 @@ class Schedule(object):
         'resblock_fused': ('HIM_RESBLOCK_FUSED', False, 'ResnetBlock with the norms inside the Winograd transforms'),
         'dead_bias_skip': ('HIM_DEAD_BIAS_SKIP', True, 'no bias gradient in front of a mean-subtracting norm'),
         'panel_pipeline': ('HIM_PANEL_PIPELINE', False, "the next generator forward waits for G's Adam kernel and, per layer, for that layer's rebuilt weight panel -- not for the whole panel rebuild pass"),
+        'lincomb': ('HIM_LINCOMB', True, 'scalar loss arithmetic as one launch (him_lincomb) instead of one-element ATen ops'),
         'keep_wino_input': ('HIM_KEEP_WINO_INPUT', True, "forward keeps the Winograd-transformed input for the layer's weight gradient"),
     }
     # negative spellings kept for the recorded A/B command lines of rounds 2-3

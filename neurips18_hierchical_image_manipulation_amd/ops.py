@@ -1517,6 +1517,12 @@ class _LinComb(torch.autograd.Function):
 def lincomb(terms, weights=None, scale=1.0):
     """scale * (w_0 t_0 + w_1 t_1 + ...), left to right in fp32, over one-element tensors (default weights: 1)."""
     terms = list(terms)
+    if not SCHED.lincomb:          # the same expression as a chain of one-element torch ops (A/B switch)
+        ws = list(weights) if weights is not None else [1.0] * len(terms)
+        acc = 0
+        for w, t in zip(ws, terms):
+            acc = acc + (t if w == 1.0 else t * w)
+        return acc if scale == 1.0 else acc * scale
     return _LinComb.apply(tuple(weights) if weights is not None else (1.0,) * len(terms), scale, *terms)
 
 

@@ -489,7 +489,11 @@ def test_c2_teacher_forced_loss_and_gradient_parity():
 
 
 def test_tiny_twostream_teacher_forced_parity():
-    _teacher_forced('tiny_twostream', 6, k_typical=2.0)     # measured 0.22
+    # 12 steps: on the toy nets (4x4 latent planes) an fp32 "event" strikes about every third step on either side and a
+    # 6-step run can be all events for one of them (seen once in the full suite: HIP 6 of 6 at 1e-4, the same code standalone
+    # 3 of 6 at the 2e-6 baseline -- the trajectory follows the oracle's thread-dependent rounding); the lower quartile of
+    # 12 is the third smallest
+    _teacher_forced('tiny_twostream', 12, k_typical=2.0)
 
 
 def test_local_enhancer_matches_reference():

@@ -34,6 +34,13 @@ for grp in "FETCH_SIZE" "WRITE_SIZE"; do
   rocprofv3 --pmc $grp --kernel-trace -f csv -d $d -- python $ROOT/tools/worst_kernels_bench.py 5 > $d.log 2>&1
 done
 python $ROOT/tools/pmc_collect.py wgrad_fewch_mfma_kernel 0 $OUT/${TAG}_pmc_wgrad_fewch.json $OUT/pmcw_FETCH_SIZE $OUT/pmcw_WRITE_SIZE > $OUT/pmcw_collect.log 2>&1
-python $ROOT/tools/pmc_collect.py onehot_wgrad_kernel 0 $OUT/${TAG}_pmc_onehot_wgrad.json $OUT/pmcw_FETCH_SIZE $OUT/pmcw_WRITE_SIZE >> $OUT/pmcw_collect.log 2>&1
+python $ROOT/tools/pmc_collect.py onehot_wgrad_rle_kernel 0 $OUT/${TAG}_pmc_onehot_wgrad.json $OUT/pmcw_FETCH_SIZE $OUT/pmcw_WRITE_SIZE >> $OUT/pmcw_collect.log 2>&1
 rm -rf $OUT/pmcw_FETCH_SIZE $OUT/pmcw_WRITE_SIZE
+# 4. the fused Winograd kernel (VGG conv1_2 shape: 8 x 64 x 256 x 512 -> 64, grid 4096), stand-alone microbenchmark binary
+for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+  d=$OUT/pmcf_$(echo $grp | cut -d' ' -f1)
+  rocprofv3 --pmc $grp --kernel-trace -f csv -d $d -- $ROOT/tools/micro/wino_micro 8 64 256 512 64 0 5 > $d.log 2>&1
+done
+python $ROOT/tools/pmc_collect.py wino_fused_kernel 0 $OUT/${TAG}_pmc_wino_fused.json $OUT/pmcf_FETCH_SIZE $OUT/pmcf_WRITE_SIZE $OUT/pmcf_TCC_HIT_sum $OUT/pmcf_SQ_WAVE_CYCLES $OUT/pmcf_SQ_LDS_BANK_CONFLICT > $OUT/pmcf_collect.log 2>&1
+rm -rf $OUT/pmcf_FETCH_SIZE $OUT/pmcf_WRITE_SIZE $OUT/pmcf_TCC_HIT_sum $OUT/pmcf_SQ_WAVE_CYCLES $OUT/pmcf_SQ_LDS_BANK_CONFLICT
 cd $ROOT
