@@ -219,6 +219,8 @@ def step_flop_accounting(ms_per_step, bs):
     terms = {
         'winograd_resnet_stack_54_launches': 54 * (77.309 - 34.360) / 1e3,            # F(2x2,3x3): 2.25x fewer multiplies
         'winograd_vgg_3_passes': 3 * (f_v - 0.45) * bs / 1e3 * (1 - 1 / 2.25),        # every VGG conv but conv1_1
+        # round 4: conv3_2..3_4, conv4_1..4_4, conv5_1 (65.2 of VGG's 94.7 GFLOP per image) as F(4x4,3x3): 1/4 instead of 1/2.25
+        'winograd_f4x4_frozen_vgg_layers': 3 * 65.2 * bs / 1e3 * (1 / 2.25 - 1 / 4.0),
         'stem_from_label_ids_fwd_and_wgrad': 2 * 2.0 * 64 * 35 * 49 * (bs * 256 * 512) / 1e12,
         'discriminator_passes_7_instead_of_9': 2 * f_d * bs / 1e3,   # shared fake pass; no D weight gradients in loss_G
     }

@@ -24,8 +24,20 @@ def durations(path, need_adam):
         adam = [r[2] for r in rows if 'adam_kernel' in r[0]]
         lo, hi = adam[len(adam) // 3], adam[-1]
         rows = [r for r in rows if r[1] >= lo and r[2] <= hi]
-    sel = [r[2] - r[1] for r in rows if any(k in r[0] for k in KERNELS)
-           and r[3] // max(r[6], 1) == GRID and r[4] == 1 and r[5] == 1]
+    hit = [r for r in rows if any(k in r[0] for k in KERNELS) and r[3] // max(r[6], 1) == GRID and r[4] == 1 and r[5] == 1]
+    sel = [r[2] - r[1] for r in hit]
+    # UNION of the launches' intervals: the data- and weight-gradient GEMMs of a layer run CONCURRENTLY on two streams (each
+    # then takes twice as long, two progress at once); union time / launches = the wall-clock the chip spends per GEMM
+    union, end = 0, -1
+    for r in sorted(hit, key=lambda r: r[1]):
+        lo, hi = max(r[1], end), r[2]
+        if hi > lo:
+            union += hi - lo
+        end = max(end, r[2])
+    durations.union_ns = union
+    durations.by_kernel = {}
+    for r in hit:
+        durations.by_kernel.setdefault(r[0].split('(')[0].strip(), []).append(r[2] - r[1])
     return sel
 
 
@@ -41,6 +53,11 @@ def main():
         out.update(in_step_launches=len(step), in_step_avg_launch_ms=round(avg / 1e6, 4),
                    in_step_executed_tflops=round(FLOP / (avg * 1e-9) / 1e12, 2))
         out['in_step_frac_of_f32_mfma_peak'] = round(out['in_step_executed_tflops'] / PEAK, 4)
+        out['in_step_avg_launch_ms_by_kernel'] = {k: round(sum(v) / len(v) / 1e6, 4) for k, v in durations.by_kernel.items()}
+        # wall-clock per GEMM = union of the (partly concurrent) launch intervals / launches
+        un = durations.union_ns / len(step)
+        out.update(in_step_union_ms_per_launch=round(un / 1e6, 4),
+                   in_step_union_frac_of_f32_mfma_peak=round(FLOP / (un * 1e-9) / 1e12 / PEAK, 4))
     out['command'] = ('rocprofv3 --kernel-trace --stats -- python tools/gemm_bench.py 20 (isolated) and rocprofv3 --kernel-trace '
                       '-- python bench.py --steps 6 --warmup 3 (in step); tools/collect_profiles.sh')
     with open(sys.argv[3], 'w') as f:
