@@ -87,9 +87,9 @@ const char* him_last_error(void);
 
 typedef struct HimAlgo {
   int wino_min_c;       /* 3x3 s1 p1 layers with Cin and Cout >= this run as separate-transform Winograd F(2x2,3x3);
-                           0 = default (512); < 0: EVERY Winograd form off (all convolutions in the direct form) */
+                           0 = default (256); < 0: EVERY Winograd form off (all convolutions in the direct form) */
   int wino_fused_min_c; /* lower end of the fused single-launch Winograd kernel's channel range; 0 = default (64); < 0: off */
-  int wino_fused_max_c; /* upper end; 0 = default (512) */
+  int wino_fused_max_c; /* upper end; 0 = default (255) */
   int wino4_min_c;      /* FROZEN_WEIGHTS layers with Cin and Cout >= this run as F(4x4,3x3); 0 = default (256); < 0: off */
   int ksplit_max;       /* cap of the split-K factor; 0 = default (8) */
   int tile_wb, tile_nb; /* HIM_TILE_*: batched Winograd GEMMs / direct-form convolutions */
@@ -229,7 +229,7 @@ int him_conv2d_onehot_bwd_weight(const HimConv2d* d, const float* label, int n_o
  * *_panel_bytes returns 0 when that kernel reads the raw weights (Cout <= 4 heads, Cin < 16 stems):
  * use the plain entry point.  Workspace sizes are those of the plain entry points.
  * -------------------------------------------------------------------------------------------*/
-/* 3x3 stride-1 pad-1 convs with Cin and Cout >= HimAlgo.wino_min_c channels (default 512) run as Winograd F(2x2,3x3):
+/* 3x3 stride-1 pad-1 convs with Cin and Cout >= HimAlgo.wino_min_c channels (default 256) run as Winograd F(2x2,3x3):
  * transforms + ONE batched fp32-MFMA GEMM over the 16 transform positions (2.25x fewer multiplies; fp32 rounding differs
  * from the direct form at the 1e-6 level).  The data and weight gradients of those layers use the same scheme.  Workspace
  * / panel sizes follow the descriptor's HimAlgo: a cached panel belongs to the HimAlgo it was built with. */

@@ -95,9 +95,11 @@ __device__ __forceinline__ unsigned lds_addr_u(const void* p) {
 
 // ---- HimAlgo accessors: a zero field selects the default (include/him.h "Algorithm selection").  Kernel selection is a
 // pure function of (descriptor, HimAlgo): no statics, no environment.
-inline int algo_wino_min_c(const HimAlgo& a) { return a.wino_min_c == 0 ? 512 : a.wino_min_c; }          // <= 0: off
+// round 4: 256 (was 512) -- with the LDS-DMA GEMM kernel (64 KB LDS, shares a CU) the separate-transform pipeline beats the
+// one-workgroup-per-CU fused kernel from 256 channels inside a multi-stream step (box2mask 477 -> 486 images/s, C4 neutral)
+inline int algo_wino_min_c(const HimAlgo& a) { return a.wino_min_c == 0 ? 256 : a.wino_min_c; }          // <= 0: off
 inline int algo_wino_fused_min_c(const HimAlgo& a) { return a.wino_fused_min_c == 0 ? 64 : a.wino_fused_min_c; }
-inline int algo_wino_fused_max_c(const HimAlgo& a) { return a.wino_fused_max_c == 0 ? 512 : a.wino_fused_max_c; }
+inline int algo_wino_fused_max_c(const HimAlgo& a) { return a.wino_fused_max_c == 0 ? 255 : a.wino_fused_max_c; }
 inline int algo_wino4_min_c(const HimAlgo& a) { return a.wino4_min_c == 0 ? 256 : a.wino4_min_c; }
 inline int algo_ksplit_max(const HimAlgo& a) { return a.ksplit_max <= 0 ? 8 : a.ksplit_max; }
 inline int algo_tblock(const HimAlgo& a) { return (a.wino_tblock == 128 || a.wino_tblock == 256) ? a.wino_tblock : 64; }

@@ -411,7 +411,8 @@ __global__ __launch_bounds__(256) void reflect_extend_kernel(const float* __rest
 #include "him_conv_wino.inc"
 
 // ---- Winograd host side -------------------------------------------------------------------------------------------
-// wide 3x3 stride-1 pad-1 layers only: below ~512 channels the x4 transform traffic eats the 2.25x multiply saving
+// wide 3x3 stride-1 pad-1 layers only (HimAlgo::wino_min_c, default 256 since round 4): below that the x4 transform traffic eats
+// the 2.25x multiply saving and the fused single-launch kernel takes over
 static bool wino_shape_ok(const HimAlgo& a, int Cout, int Cin, int KH, int KW, int stride, int pad, int H, int W) {
   const int mc = algo_wino_min_c(a);
   return mc > 0 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin >= mc && Cout >= mc && (Cin % 16) == 0 &&
@@ -857,7 +858,8 @@ static bool wino_fwd_ok(const HimConv2d* d) {
 // Upper end of the fused kernel's channel range.  Inside the training step (weight panels streamed from HBM, 67 MB per
 // 1024-channel layer) the ResnetBlock forward is faster on the separate-transform pipeline: 10.4 vs 11.8 ms generator
 // forward, 121.4 vs 118.9 images/s (A/B with HimAlgo::wino_fused_max_c) -- although the isolated kernel, whose panel stays
-// in the Infinity Cache between launches, measures 197 vs 188 TFLOP/s equivalent: the default range ends at 512 channels.
+// in the Infinity Cache between launches, measures 197 vs 188 TFLOP/s equivalent.  Round 4: with the LDS-DMA GEMM kernel the separate pipeline wins from 256 channels (the
+// default range of the fused kernel ends at 255).
 static bool wino_fused_ok(const HimAlgo& a, int Co, int Ci, int KH, int KW, int stride, int pad, int B, int H, int W) {
   const int mc = algo_wino_fused_min_c(a);
   // HimAlgo::wino_min_c < 0 turns EVERY Winograd form off (parity runs in the direct form)

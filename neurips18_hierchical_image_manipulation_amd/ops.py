@@ -379,11 +379,11 @@ def invalidate_panels(params):
 def set_winograd_min_channels(c):
     """3x3 stride-1 convs with >= c channels on both sides run as Winograd F(2x2,3x3); c <= 0: EVERY Winograd form off.
     Sets ``current_algo().wino_min_c`` of the calling thread (cached panels are keyed by the HimAlgo they were built
-    with); returns the previous setting (0 = the library default, 512)."""
+    with); returns the previous setting (0 = the library default, 256)."""
     a = current_algo()
     prev = int(a.wino_min_c)
-    a.wino_min_c = -1 if c <= 0 else (0 if int(c) == 512 else int(c))
-    return prev if prev != 0 else 512
+    a.wino_min_c = -1 if c <= 0 else (0 if int(c) == 256 else int(c))
+    return prev if prev != 0 else 256
 
 
 class _Conv2d(torch.autograd.Function):

@@ -513,7 +513,7 @@ def test_library_is_reentrant():
     [t.join() for t in ts]
     torch.cuda.synchronize()
     assert not errors, errors
-    assert ops.resolved_algo()['wino_min_c'] == 512          # the main thread's HimAlgo was never touched
+    assert ops.resolved_algo()['wino_min_c'] == 256          # the main thread's HimAlgo was never touched
 
 
 ONEHOT_CASES = [
