@@ -405,6 +405,14 @@ def main():
         batches = [{k: v.to(device) for k, v in synth.make_batch(s, rank, bs, H, W, wl['label_nc'], wl['color']).items()}
                    for s in range(4)]
 
+        # resident before the timed region: the event tells the step that these device tensors are complete, so the input
+        # encoding need not wait for whatever the previous step still has queued on the main stream (models/
+        # pix2pixHD_condImg_model.py: optimize_parameters, 'ready_event')
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(device))
+        for b in batches:
+            b['ready_event'] = ready
+
         def step(i):
             return model.optimize_parameters(batches[i % 4])
 

@@ -90,7 +90,8 @@ typedef struct HimAlgo {
                            0 = default (256); < 0: EVERY Winograd form off (all convolutions in the direct form) */
   int wino_fused_min_c; /* lower end of the fused single-launch Winograd kernel's channel range; 0 = default (64); < 0: off */
   int wino_fused_max_c; /* upper end; 0 = default (255) */
-  int wino4_min_c;      /* FROZEN_WEIGHTS layers with Cin and Cout >= this run as F(4x4,3x3); 0 = default (256); < 0: off */
+  int wino4_min_c;      /* FROZEN_WEIGHTS layers with Cin and Cout >= this AND at least 64 output tiles of 4x4 in the batch
+                           (B*H*W >= 1024) run as F(4x4,3x3); 0 = default (256); < 0: off */
   int ksplit_max;       /* cap of the split-K factor; 0 = default (8) */
   int tile_wb, tile_nb; /* HIM_TILE_*: batched Winograd GEMMs / direct-form convolutions */
   int wino_tblock;      /* threads per workgroup of the Winograd transform kernels: 64 (default), 128, 256 */

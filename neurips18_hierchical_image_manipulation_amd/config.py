@@ -36,6 +36,10 @@ class Schedule(object):
         'dead_bias_skip': ('HIM_DEAD_BIAS_SKIP', True, 'no bias gradient in front of a mean-subtracting norm'),
         'panel_pipeline': ('HIM_PANEL_PIPELINE', False, "the next generator forward waits for G's Adam kernel and, per layer, for that layer's rebuilt weight panel -- not for the whole panel rebuild pass"),
         'lincomb': ('HIM_LINCOMB', True, 'scalar loss arithmetic as one launch (him_lincomb) instead of one-element ATen ops'),
+        'd_update_early': ('HIM_D_UPDATE_EARLY', False, "D's exchange + Adam step start inside loss_G.backward(), as soon as the gradient has passed back through the discriminator (its last reader of the step), instead of after the generator's whole backward"),
+        'inputs_on_real_stream': ('HIM_INPUTS_ON_REAL_STREAM', False, "input encoding on the real-image stream: with D updated early, the NEXT step's encoding + D(real) + VGG(real) run under this step's generator backward / Adam instead of behind them"),
+        'real_vgg_first': ('HIM_REAL_VGG_FIRST', False, "real-image stream: VGG(real) in front of the wait for D's update and D(real)"),
+        'zero_grad_side': ('HIM_ZERO_GRAD_SIDE', False, 'optimize_parameters() zeroes the gradient arenas on the weight-gradient stream before the forward pass (under it) instead of on the main stream in front of the backward pass'),
         'keep_wino_input': ('HIM_KEEP_WINO_INPUT', True, "forward keeps the Winograd-transformed input for the layer's weight gradient"),
     }
     # negative spellings kept for the recorded A/B command lines of rounds 2-3
@@ -57,7 +61,8 @@ SCHED = Schedule()
 
 # every stream of the step switched off: the reference's own order on ONE stream
 SERIAL = dict(wgrad_stream=False, d_wgrad_routes=False, real_ahead=False, d_backward_first=False, vgg_stream=False,
-              vgg_backward_early=False, d_scale_streams=False)
+              vgg_backward_early=False, d_scale_streams=False, d_update_early=False, inputs_on_real_stream=False,
+              zero_grad_side=False, real_vgg_first=False)
 
 
 @contextlib.contextmanager

@@ -5,6 +5,7 @@
 Added by this build (named by the task, absent from the reference): ``backward_G`` / ``backward_D`` /
 ``optimize_parameters`` -- thin wrappers around exactly the lines ``train_mask2image.py:68-86`` runs inline.
 """
+import contextlib
 import os
 import random
 from collections import OrderedDict
@@ -223,16 +224,22 @@ class Pix2PixHDModel_condImg(BaseModel):
             side.wait_event(inputs_ready)
         else:
             side.wait_stream(main)
-        self._wait_d_update(side)
         out = {'stream': side, 'y_vgg': None}
         # --sn_D: every discriminator forward moves the persisted power-iteration vectors, so the three passes must run
         # in the reference's order (fake-detached, real, fake): only the VGG features of the real image run ahead
         with_d = not getattr(self.opt, 'sn_D', False)
+        vgg_first = SCHED.real_vgg_first and not self.opt.no_vgg_loss
+        with torch.cuda.stream(side):
+            if vgg_first:
+                # VGG(real) depends on the inputs alone (frozen weights): in front of the wait for D's update it can run
+                # as soon as this stream is free, i.e. under the PREVIOUS step's backward passes
+                out['y_vgg'] = self.criterionVGG.target_features(real_image)
+        self._wait_d_update(side)
         with torch.cuda.stream(side):
             if with_d:
                 out['pred_real'] = self.discriminate(netD_cond, real_image, mask_cond, False)
                 out['loss_D_real'] = self.criterionGAN(out['pred_real'], True)
-            if not self.opt.no_vgg_loss:
+            if not self.opt.no_vgg_loss and not vgg_first:
                 out['y_vgg'] = self.criterionVGG.target_features(real_image)
         # these tensors were allocated on the side stream and are read on the main one
         for feats in out.get('pred_real', ()):
@@ -255,22 +262,43 @@ class Pix2PixHDModel_condImg(BaseModel):
 
     def forward(self, label, inst, image, feat, mask_in, mask_out, infer=False, obj_mask=None):
         opt = self.opt
-        input_mask, inst_map, real_image, _, cond_image = self.encode_input(label, inst, image, feat, mask_in=mask_in,
-                                                                           obj_mask=obj_mask)
-        buf, n_label, n_cond, mask_in = self._enc
-        netD_cond = input_mask if self.no_imgCond else buf
-        mask_cond = mask_in if not self.use_soft_mask else self._dev(mask_out)
+        main = torch.cuda.current_stream(self.device)
+        # The input encoding and the real-image branch touch neither network's CURRENT-step gradients nor the generator:
+        # on the real-image stream they depend only on the inputs and on D's previous update.  With D updated inside
+        # loss_G.backward() (optimize_parameters), step N+1's encoding + D(real) + VGG(real) run under step N's generator
+        # backward, Adam and panel rebuild -- the 2.5 ms at the step boundary in which no matrix kernel ran (r04t trace).
+        enc_side = None
+        if self.isTrain and SCHED.real_ahead and SCHED.inputs_on_real_stream:
+            enc_side = ops._real_stream(self.device)
+            ready, self._inputs_ready_event = getattr(self, '_inputs_ready_event', None), None
+            on_device = any(torch.is_tensor(t) and t.is_cuda for t in (label, inst, image, mask_in, mask_out, obj_mask))
+            if ready is not None:
+                enc_side.wait_event(ready)       # the caller's promise: the device tensors are complete at this event
+            elif on_device:
+                enc_side.wait_stream(main)       # device tensors of unknown origin: whatever the current stream holds
+        with torch.cuda.stream(enc_side) if enc_side is not None else contextlib.nullcontext():
+            input_mask, inst_map, real_image, _, cond_image = self.encode_input(label, inst, image, feat, mask_in=mask_in,
+                                                                               obj_mask=obj_mask)
+            buf, n_label, n_cond, mask_in = self._enc
+            netD_cond = input_mask if self.no_imgCond else buf
+            mask_cond = mask_in if not self.use_soft_mask else self._dev(mask_out)
+            if self._d_split():
+                # the pooled condition of the PatchGAN scales: once per step, before the streams fork (every pass reads it)
+                ops.cond_pyramid(netD_cond, opt.num_D)
+            inputs_ready = torch.cuda.Event()
+            inputs_ready.record(torch.cuda.current_stream(self.device))
+        if enc_side is not None:
+            main.wait_event(inputs_ready)
+            for t in (buf, input_mask, inst_map, real_image, cond_image, mask_in, mask_cond) + tuple(
+                    getattr(netD_cond, '_him_pyramid', ())):
+                if torch.is_tensor(t):
+                    t.record_stream(main)        # allocated on the real-image stream, read on the main one
 
         # Everything that depends only on the REAL image (its discriminator pass and its VGG features) is independent
         # of the generator: it runs on a side stream next to the generator forward and fills the matrix pipe where the
         # one-tile-per-CU ResnetBlock launches leave it idle.
         # The generator forward is enqueued FIRST: the host needs ~2.5 ms to issue the ~80 launches of the real branch,
         # and the main stream would sit idle for that long at the start of every step (r02 trace) if they went first.
-        if self._d_split():
-            # the pooled condition of the PatchGAN scales: once per step, before the streams fork (every pass reads it)
-            ops.cond_pyramid(netD_cond, opt.num_D)
-        inputs_ready = torch.cuda.Event()
-        inputs_ready.record(torch.cuda.current_stream(self.device))
         if getattr(self, '_g_update_pending', False):
             # the previous step left G's exchange + Adam + panel rebuild running on the optimizer stream: the real-image
             # branch (no generator weights) is enqueued first and runs next to them, the generator waits
@@ -476,6 +504,26 @@ class Pix2PixHDModel_condImg(BaseModel):
         if 'obj_mask' in data:
             kw['obj_mask'] = data['obj_mask']
         self._share_fake_pass = SCHED.share_fake_pass
+        # device-resident batches may carry 'ready_event' (torch.cuda.Event recorded behind the kernels / copies that
+        # produced them): the input encoding then waits for THAT instead of for the whole current stream (forward())
+        self._inputs_ready_event = data.get('ready_event') if hasattr(data, 'get') else None
+        gan = not self.opt.no_gan
+        zero_ev = None
+        if SCHED.zero_grad_side and SCHED.wgrad_stream:
+            # both arenas zeroed on the weight-gradient stream NOW, under the forward pass (nothing reads the gradients until
+            # the backward pass; the weight-gradient kernels follow on the same stream) -- the fill used to sit on the main
+            # stream between the losses and the first backward kernel
+            main0 = torch.cuda.current_stream(self.device)
+            ws = ops._side_stream(self.device)
+            ws.wait_stream(main0)             # the caller may have read / written .grad on the current stream
+            ws.wait_stream(ops._opt_stream(self.device))      # the previous step's Adam kernels (and exchanges) read them
+            ws.wait_stream(ops._d_opt_stream(self.device))
+            with torch.cuda.stream(ws):
+                self.optimizer_G.zero_grad()
+                if gan:
+                    self.optimizer_D.zero_grad()
+                zero_ev = torch.cuda.Event()
+                zero_ev.record(ws)
         self._vgg_bwd_early = SCHED.vgg_backward_early and SCHED.d_backward_first and not self.opt.no_gan
         self._vgg_early = None
         try:
@@ -488,11 +536,14 @@ class Pix2PixHDModel_condImg(BaseModel):
         # step (and its all-reduce) is deferred behind loss_D.backward() -- legal because loss_D's graph holds no
         # generator parameter (the fake is detached / gated) -- so the 730 MB gradient exchange and G's Adam step hide
         # under D's backward.
-        gan = not self.opt.no_gan
-        self.optimizer_G.zero_grad()
-        if gan:
-            self.optimizer_D.zero_grad()
         main = torch.cuda.current_stream(self.device)
+        if zero_ev is None:
+            self.optimizer_G.zero_grad()
+            if gan:
+                self.optimizer_D.zero_grad()
+        else:
+            main.wait_event(zero_ev)          # autograd's own accumulations / routed weight gradients follow the fill
+            ops._vgg_stream(self.device).wait_event(zero_ev)      # D's weight gradients may be routed there
         opt_stream = ops._opt_stream(self.device)
         from ..dist import timed_wait
         if gan and SCHED.d_backward_first:
@@ -524,14 +575,15 @@ class Pix2PixHDModel_condImg(BaseModel):
                 self.reducer_G.begin()
             if early is not None:
                 main.wait_stream(ops._vgg_stream(self.device))
+            # D's exchange + Adam: from INSIDE loss_G.backward(), the moment the gradient has passed back through the
+            # discriminator to the fake image (ops._GradSwitch.backward, autograd's thread) -- nothing reads D's weights
+            # after that, so the update (and with it the next step's real-image branch, which waits for nothing else) no
+            # longer queues behind the generator's whole backward.  Without a shared fake pass: after the backward, as before.
+            if SCHED.d_update_early and self._fake_gate is not None:
+                self._fake_gate['on_open_backward'] = self._d_update
             self._run_backward_G(last=True, extra_root=early)
-            d_stream = ops._d_opt_stream(self.device)
-            d_stream.wait_stream(main)
-            with torch.cuda.stream(d_stream):
-                if self.reducer_D is not None:
-                    self.reducer_D.finish()
-                self.optimizer_D.step()
-            self._d_update_pending = True
+            if self._fake_gate is None or self._fake_gate.pop('on_open_backward', None) is not None or not SCHED.d_update_early:
+                self._d_update()
             # G's exchange + Adam + panel rebuild (5 GB of HBM traffic, no matrix work) on their own stream, NOT waited for
             # here: the next step's input encoding and real-image branch do not touch G and run next to them; the next
             # generator forward waits (forward()); anything else that reads parameters calls sync() first.
@@ -576,6 +628,17 @@ class Pix2PixHDModel_condImg(BaseModel):
         self.loss_G = self.loss_D = None
         self._fake_gate = None
         return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in loss_dict.items()}
+
+    def _d_update(self):
+        """D's gradient exchange (data parallel) + Adam step + panel rebuild on D's optimizer stream, after everything the
+        CALLING thread's current stream holds (the discriminator's data gradients) and D's weight gradients."""
+        d_stream = ops._d_opt_stream(self.device)
+        d_stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(d_stream):
+            if self.reducer_D is not None:
+                self.reducer_D.finish()
+            self.optimizer_D.step()
+        self._d_update_pending = True
 
     def _wait_g_update(self):
         """Make the current stream wait for a generator update still running on the optimizer stream."""

@@ -214,7 +214,14 @@ class _GradSwitch(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return (g if (g is not None and ctx.state['open']) else None), None
+        if g is None or not ctx.state['open']:
+            return None, None
+        # everything downstream of this node (the discriminator) has finished its part of this backward pass: a trainer
+        # may hang work on that moment (Pix2PixHDModel_condImg: D's Adam step, whose weights nobody reads any more)
+        cb = ctx.state.pop('on_open_backward', None)
+        if cb is not None:
+            cb()
+        return g, None
 
 
 def _wkey(w):

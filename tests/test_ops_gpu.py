@@ -407,9 +407,10 @@ def test_winograd_conv3x3_fwd_bwd(case):
 
 WINO4_CASES = [
     # B, Cin, H, W, Cout   (frozen weights, zero padding, planes multiples of 4, >= 256 channels on both sides)
-    (2, 256, 16, 32, 256),       # VGG conv3_x family
-    (1, 256, 8, 12, 512),        # conv4_1 family: rectangular, 6 tiles padded to 128
-    (3, 512, 4, 4, 512),         # one tile per image
+    (2, 256, 16, 32, 256),       # VGG conv3_x family: 64 tiles, padded to 128 GEMM columns
+    (3, 256, 16, 24, 512),       # conv4_1 family: rectangular, 72 tiles padded to 128
+    (1, 256, 8, 12, 512),        # 6 tiles: BELOW the 64-tile rule (the padded GEMMs would execute more than the direct
+    (3, 512, 4, 4, 512),         # form) -- the frozen mark must NOT change the kernel selection here
     (8, 256, 64, 128, 256),      # conv3_2..3_4 at the benchmark size (C2)
     (8, 512, 32, 64, 512),       # conv4_2..4_4 at the benchmark size
 ]
@@ -446,7 +447,10 @@ def test_winograd_f4x4_frozen_conv_fwd_and_gated_dgrad(case):
         assert_close('fwd frozen=%s' % frozen, y, y_ref, rtol=3e-5 if frozen else 2e-5)
         assert_close('gated dgrad frozen=%s' % frozen, gx, gx_ref, rtol=3e-5 if frozen else 2e-5)
         got[frozen] = y.detach()
-    assert not torch.equal(got[True], got[False]), 'the frozen mark must select the F(4x4) kernels'
+    if B * (H // 4) * (W // 4) >= 64:
+        assert not torch.equal(got[True], got[False]), 'the frozen mark must select the F(4x4) kernels'
+    else:
+        assert torch.equal(got[True], got[False]), 'F(4x4) selected for fewer than 64 tiles (him_conv_wino4.inc: wino4_shape_ok)'
 
 
 def test_conv_source_tensor_above_2_gib_is_sliced_along_the_batch():

@@ -15,5 +15,5 @@ python $ROOT/tools/stream_view.py $OUT/bench_trace > $OUT/${TAG}_bench_stream_vi
 python $ROOT/tools/timeline.py $OUT/bench_trace > $OUT/${TAG}_bench_timeline.txt 2>&1
 for f in $(find $OUT/bench_trace -name "*.db" -size -30M); do cp $f $OUT/bench_trace.db; done
 python $ROOT/tools/step_phases.py $OUT/bench_trace.db 80 > $OUT/${TAG}_bench_step_phases.txt 2>&1
-rm -rf $OUT/bench_trace $OUT/bench_trace.db
+rm -rf $OUT/bench_trace
 cd $ROOT
