@@ -320,6 +320,21 @@ int him_instnorm_fwd(const float* x, const float* residual, float* y, float* mea
 int him_instnorm_bwd(const float* x, const float* mean, const float* rstd, const float* dy, float* dx,
                      int planes, int hw, int act, float slope, void* stream);
 
+/* Conv2d -> InstanceNorm2d(affine=False) [-> ReLU / LeakyReLU] [+ residual] as ONE call: the encoder / PatchGAN block of
+ * models/Pix2Pix_NET.py:74-92 and models/Discriminator_NET.py:64-96 (`nn.Conv2d`, `norm_layer`, activation in sequence).
+ *   y_raw (B,Cout,OH,OW) = conv(x) + bias (kept: the InstanceNorm backward reads it), z = act((y_raw - mean) * rstd)
+ *   [+ residual], mean / rstd [B*Cout].  `d->act` must be HIM_ACT_NONE (the activation follows the norm).
+ * Few-tile layers that the forward launches with split-K (him_conv2d_in_act_fused(d) == 1: the PatchGAN blocks, the
+ * generator's last down-convolutions) hand the raw split-K slabs to the InstanceNorm kernel, which sums them in the finish
+ * pass's order, adds the bias, writes y_raw, reduces the statistics and writes z in one pass: the split-K finish launch
+ * and one read of y_raw disappear, every output is bit-identical to him_conv2d_fwd + him_instnorm_fwd.  All other
+ * descriptors run exactly those two launches behind this entry.  `panel` (HIM_PANEL_FWD) or `w`; workspace =
+ * him_conv2d_fwd_ws(d).  Backward: him_instnorm_bwd(y_raw, ...) then the conv's him_conv2d_bwd_*. */
+int him_conv2d_in_act_fused(const HimConv2d* d);
+int him_conv2d_in_act_fwd(const HimConv2d* d, const float* x, const float* w, const void* panel, const float* bias,
+                          float* y_raw, const float* residual, float* z, float* mean, float* rstd, float eps, int act,
+                          float slope, void* ws, size_t ws_bytes, void* stream);
+
 /* dz = dy * act'(.) expressed through the activation OUTPUT y (ReLU/LeakyReLU/Tanh epilogues). */
 int him_act_bwd(const float* y, const float* dy, float* dz, size_t n, int act, float slope, void* stream);
 /* out = a + b  (gradient fan-in, residual adds) */

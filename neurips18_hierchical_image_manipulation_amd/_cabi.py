@@ -105,6 +105,8 @@ _SIGS = {
     'him_class_mask': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'him_bce_mean_bwd': (c_int, [P, P, c_size_t, P, P, P]),
     'him_instnorm_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_float, c_int, c_float, P]),
+    'him_conv2d_in_act_fused': (C.c_uint, [_CONV]),
+    'him_conv2d_in_act_fwd': (c_int, [_CONV, P, P, P, P, P, P, P, P, P, c_float, c_int, c_float, P, c_size_t, P]),
     'him_instnorm_bwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_float, P]),
     'him_act_bwd': (c_int, [P, P, P, c_size_t, c_int, c_float, P]),
     'him_add': (c_int, [P, P, P, c_size_t, P]),

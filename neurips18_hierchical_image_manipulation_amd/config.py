@@ -40,6 +40,7 @@ class Schedule(object):
         'inputs_on_real_stream': ('HIM_INPUTS_ON_REAL_STREAM', False, "input encoding on the real-image stream: with D updated early, the NEXT step's encoding + D(real) + VGG(real) run under this step's generator backward / Adam instead of behind them"),
         'real_vgg_first': ('HIM_REAL_VGG_FIRST', False, "real-image stream: VGG(real) in front of the wait for D's update and D(real)"),
         'zero_grad_side': ('HIM_ZERO_GRAD_SIDE', False, 'optimize_parameters() zeroes the gradient arenas on the weight-gradient stream before the forward pass (under it) instead of on the main stream in front of the backward pass'),
+        'conv_in_fused': ('HIM_CONV_IN_FUSED', True, 'Conv2d -> InstanceNorm [-> act] blocks through him_conv2d_in_act_fwd: split-K layers hand their slabs to the InstanceNorm kernel (no finish pass)'),
         'keep_wino_input': ('HIM_KEEP_WINO_INPUT', True, "forward keeps the Winograd-transformed input for the layer's weight gradient"),
     }
     # negative spellings kept for the recorded A/B command lines of rounds 2-3

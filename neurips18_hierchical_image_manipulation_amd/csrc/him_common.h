@@ -105,4 +105,8 @@ inline int algo_ksplit_max(const HimAlgo& a) { return a.ksplit_max <= 0 ? 8 : a.
 inline int algo_tblock(const HimAlgo& a) { return (a.wino_tblock == 128 || a.wino_tblock == 256) ? a.wino_tblock : 64; }
 inline bool algo_off(const HimAlgo& a, unsigned bit) { return (a.disable & bit) != 0; }
 
+// him_norm.hip: InstanceNorm forward reading the split-K slabs of the convolution in front of it (him_conv2d_in_act_fwd)
+int instnorm_fwd_from_slabs(const float* part, long long slab, int ks, const float* bias, int M, float* xout,
+                            const float* residual, float* y, float* mean, float* rstd, int planes, int hw, float eps,
+                            int act, float slope, hipStream_t st);
 }  // namespace him

@@ -902,10 +902,27 @@ static size_t fprop_panel_floats(const HimConv2d* d) {
   if (wino_fwd_ok(d)) return (size_t)16 * d->Cout * d->Cin;
   return (size_t)d->Cout * d->KH * d->KW * pad16(d->Cin);
 }
+// Conv2d -> InstanceNorm in one call (him_conv2d_in_act_fwd): the descriptors whose forward is a split-K launch of the fast
+// implicit-GEMM kernel -- the few-tile layers (PatchGAN blocks, the last generator down-convolutions) -- hand their slabs to
+// the InstanceNorm kernel.  Same conditions, in the same order, as run_fprop's dispatch.
+static bool in_act_slab_ok(const HimConv2d* d) {
+  if (wino4_fwd_ok(d) || wino_fused_fwd_ok(d) || wino_fwd_ok(d) || small_split_ok(d)) return false;
+  if (!use_fast(d->algo, d->Cout, d->Cin) || d->act != HIM_ACT_NONE) return false;
+  if ((unsigned long long)d->B * d->Cin * d->H * d->W * 4ull >= (1ull << 31)) return false;   // batch-sliced launches
+  // launch_gconv's earlier exits (tiny-M kernel, few-channel tiled kernel) never see a fast split-K descriptor: Cout > 4
+  // and Cin >= 16 are what use_fast asks for
+  return fast_ksplit(d->algo, d->Cout, (long long)d->B * d->OH * d->OW, d->KH * d->KW * (pad16(d->Cin) / 16)) > 1;
+}
 // panel == nullptr: regroup the weights into the workspace on every call; build_only: write the panel to ws and return
+// defer (him_conv2d_in_act_fwd): a split-K launch leaves its raw slabs in the workspace and reports them instead of
+// running the finish pass (bias / activation / y are then the caller's: the InstanceNorm kernel reads the slabs)
+struct FpropDefer {
+  const float* slabs;
+  int ks;
+};
 static int run_fprop(const HimConv2d* d, const float* x, const float* w, const float* bias, float* y, void* ws,
                      size_t ws_bytes, hipStream_t st, const float* panel = nullptr, bool build_only = false,
-                     float* keep = nullptr) {
+                     float* keep = nullptr, FpropDefer* defer = nullptr) {
   if (wino4_fwd_ok(d)) {
     const size_t pf = wino4_panel_floats(d->Cout, d->Cin);
     const size_t need = build_only ? pf * sizeof(float) : fprop_ws_bytes(d);
@@ -987,6 +1004,11 @@ static int run_fprop(const HimConv2d* d, const float* x, const float* w, const f
       const size_t wts = ((size_t)d->Cout * KK * t.C2p * sizeof(float) + 255) / 256 * 256;
       g.ksplit = ks;
       g.kpart = (float*)((char*)ws + wts);
+      if (defer && in_act_slab_ok(d)) {
+        g.kno_finish = 1;
+        defer->slabs = g.kpart;
+        defer->ks = ks;
+      }
     }
   }
   return launch_gconv(d->algo, g, st);
@@ -1295,6 +1317,29 @@ int him_conv2d_fwd(const HimConv2d* d, const float* x, const float* w, const flo
   int rc = check_conv(d);
   if (rc) return rc;
   return run_fprop(d, x, w, bias, y, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int him_conv2d_in_act_fused(const HimConv2d* d) { return (d && !check_conv(d) && in_act_slab_ok(d)) ? 1 : 0; }
+
+int him_conv2d_in_act_fwd(const HimConv2d* d, const float* x, const float* w, const void* panel, const float* bias,
+                          float* y_raw, const float* residual, float* z, float* mean, float* rstd, float eps, int act,
+                          float slope, void* ws, size_t ws_bytes, void* stream) {
+  int rc = check_conv(d);
+  if (rc) return rc;
+  if (d->act != HIM_ACT_NONE) return fail(HIM_E_INVALID, "conv_in_act: the activation follows the norm (descriptor act must be none)");
+  if (!y_raw || !z || !mean || !rstd) return fail(HIM_E_INVALID, "conv_in_act: null output");
+  if (panel && !fprop_panel_floats(d)) return fail(HIM_E_INVALID, "conv_in_act: no panel for this descriptor");
+  hipStream_t st = (hipStream_t)stream;
+  FpropDefer df;
+  df.slabs = nullptr;
+  df.ks = 0;
+  rc = run_fprop(d, x, panel ? nullptr : w, bias, y_raw, ws, ws_bytes, st, (const float*)panel, false, nullptr, &df);
+  if (rc) return rc;
+  const int planes = d->B * d->Cout, hw = d->OH * d->OW;
+  if (df.ks > 1)
+    return instnorm_fwd_from_slabs(df.slabs, (long long)planes * hw, df.ks, bias, d->Cout, y_raw, residual, z, mean, rstd,
+                                   planes, hw, eps, act, slope, st);
+  return him_instnorm_fwd(y_raw, residual, z, mean, rstd, planes, hw, eps, act, slope, stream);
 }
 
 size_t him_conv2d_bwd_data_ws(const HimConv2d* d) { return d ? dgrad_ws_bytes(d) : 0; }

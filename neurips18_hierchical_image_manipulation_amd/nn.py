@@ -189,7 +189,16 @@ def run_layers(layers, x, final_residual=None, relu_gated=None):
                 else:
                     if relu_gated is not None:
                         raise ValueError('relu_gated chains hold conv -> ReLU [-> MaxPool] only')
-                    x = ops.conv2d(x, w, b, l.stride, rpad if pad_mode == 'reflect' else l.padding, pad_mode, epi, slope)
+                    if isinstance(norm, InstanceNorm2d):
+                        # Conv2d -> InstanceNorm -> activation block as one op (ops.conv2d_in_act)
+                        res = final_residual if (final_residual is not None and norm_idx == last_norm) else None
+                        if res is not None and act is not None:
+                            raise ValueError('residual after an activated norm is not a ResnetBlock tail')
+                        x = ops.conv2d_in_act(x, w, b, l.stride, rpad if pad_mode == 'reflect' else l.padding, pad_mode,
+                                              norm.eps, aname, slope, res)
+                        norm = None
+                    else:
+                        x = ops.conv2d(x, w, b, l.stride, rpad if pad_mode == 'reflect' else l.padding, pad_mode, epi, slope)
             if norm is not None:
                 res = final_residual if (final_residual is not None and norm_idx == last_norm) else None
                 if res is not None and act is not None:

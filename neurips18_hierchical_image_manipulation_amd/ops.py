@@ -877,6 +877,63 @@ class _InstNorm(torch.autograd.Function):
         return dx, dres, None, None, None
 
 
+class _Conv2dIN(torch.autograd.Function):
+    """act(InstanceNorm2d(conv2d(pad(x), w) + b)) [+ residual] through him_conv2d_in_act_fwd (include/him.h): taken for
+    the descriptors whose forward is a split-K launch -- the InstanceNorm kernel reads the split-K slabs, the finish pass
+    disappears; outputs bit-identical to conv2d + instance_norm.  Backward = InstanceNorm backward, then _Conv2d's."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, pad_mode, eps, act, slope, residual):
+        ctx.set_materialize_grads(False)
+        x = x.contiguous()
+        if residual is not None:
+            residual = residual.contiguous()
+        _chk(x, w, b, residual)
+        d = _conv_desc(x, w, stride, pad, pad_mode, ACT_NONE, 0.0)
+        y = torch.empty((d.B, d.Cout, d.OH, d.OW), dtype=torch.float32, device=x.device)
+        z = torch.empty_like(y)
+        planes, hw = d.B * d.Cout, d.OH * d.OW
+        mean = torch.empty(planes, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        nb = lib.him_conv2d_fwd_ws(ctypes.byref(d))
+        ws = _ws(nb, x)
+        pan = _panel(w, d, PANEL_FWD, False)
+        lib.him_conv2d_in_act_fwd(ctypes.byref(d), _p(x), 0 if pan else _p(w), pan or 0, _p(b), _p(y), _p(residual), _p(z),
+                                  _p(mean), _p(rstd), eps, act, slope, _p(ws), nb, _stream())
+        # the fields _Conv2d.backward reads
+        ctx.d, ctx.x, ctx.w, ctx.b, ctx.keep = d, x, w, b, None
+        ctx.premasked, ctx.gate_dx = False, False
+        ctx.gslice = getattr(x, '_him_grad_slice', None)
+        ctx.cfg = (planes, hw, act, slope)
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(y, mean, rstd)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        if dz is None:
+            return (None,) * 10
+        dz = dz.contiguous()
+        y, mean, rstd = ctx.saved_tensors
+        planes, hw, act, slope = ctx.cfg
+        dy = torch.empty_like(y)
+        lib.him_instnorm_bwd(_p(y), _p(mean), _p(rstd), _p(dz), _p(dy), planes, hw, act, slope, _stream())
+        dx, dw, db = _Conv2d.backward(ctx, dy)[:3]
+        dres = dz if (ctx.has_res and ctx.needs_input_grad[9]) else None
+        return dx, dw, db, None, None, None, None, None, None, dres
+
+
+def conv2d_in_act(x, w, b=None, stride=1, pad=0, pad_mode='zero', eps=1e-5, act='none', slope=0.2, residual=None):
+    """act(InstanceNorm2d(affine=False)(conv2d(pad(x), w) + b)) [+ residual]: ONE library call
+    (him_conv2d_in_act_fwd) where the convolution is a split-K launch, conv2d + instance_norm otherwise."""
+    pm = PAD_REFLECT if pad_mode == 'reflect' else PAD_ZERO
+    if SCHED.conv_in_fused and getattr(x, '_him_onehot', None) is None and not getattr(w, '_him_frozen', False):
+        d = _conv_desc(x, w, stride, pad, pm, ACT_NONE, 0.0)
+        if lib.him_conv2d_in_act_fused(ctypes.byref(d)):
+            return _Conv2dIN.apply(x, w, b, stride, pad, pm, float(eps), ACTS[act], float(slope), residual)
+    return instance_norm(conv2d(x, w, b, stride, pad, pad_mode, 'none', slope), residual, act, slope, eps)
+
+
 def instance_norm(x, residual=None, act='none', slope=0.2, eps=1e-5):
     """act(InstanceNorm2d(affine=False)(x)) [+ residual]."""
     return _InstNorm.apply(x, residual, ACTS[act], float(slope), float(eps))

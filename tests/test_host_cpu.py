@@ -120,17 +120,19 @@ def test_fusion_plan_groups_pad_conv_norm_act(monkeypatch):
     monkeypatch.setattr(ops, 'conv2d', lambda x, w, b, s, p, pm, act, sl: calls.append(('conv', p, pm, act)) or x)
     monkeypatch.setattr(ops, 'conv_transpose2d', lambda x, w, b, s, p, op, act, sl: calls.append(('deconv', act)) or x)
     monkeypatch.setattr(ops, 'instance_norm', lambda x, r, act, sl, eps: calls.append(('in', act, r is not None)) or x)
+    # Conv2d -> InstanceNorm [-> act] is ONE op (ops.conv2d_in_act -> him_conv2d_in_act_fwd)
+    monkeypatch.setattr(ops, 'conv2d_in_act', lambda x, w, b, s, p, pm, eps, act, sl, r: calls.append(
+        ('conv_in', p, pm, act, r is not None)) or x)
     layers = [hn.ReflectionPad2d(3), hn.Conv2d(4, 4, 7), hn.InstanceNorm2d(4), hn.ReLU(),
               hn.Conv2d(4, 4, 4, 2, 2), hn.LeakyReLU(0.2),
               hn.ConvTranspose2d(4, 4, 3), hn.InstanceNorm2d(4), hn.ReLU(),
               hn.ReflectionPad2d(3), hn.Conv2d(4, 3, 7), hn.Tanh()]
     hn.run_layers(layers, torch.zeros(1))
-    assert calls == [('conv', 3, 'reflect', 'none'), ('in', 'relu', False), ('conv', 2, 'zero', 'lrelu'),
+    assert calls == [('conv_in', 3, 'reflect', 'relu', False), ('conv', 2, 'zero', 'lrelu'),
                      ('deconv', 'none'), ('in', 'relu', False), ('conv', 3, 'reflect', 'tanh')]
     calls.clear()
     hn.ResnetBlock(4)(torch.zeros(1))
-    assert calls == [('conv', 1, 'reflect', 'none'), ('in', 'relu', False), ('conv', 1, 'reflect', 'none'),
-                     ('in', 'none', True)]
+    assert calls == [('conv_in', 1, 'reflect', 'relu', False), ('conv_in', 1, 'reflect', 'none', True)]
 
 
 def test_options_defaults_are_the_reference_defaults():

@@ -778,3 +778,64 @@ def test_multi_pair_l1_is_bit_identical_to_the_single_pair_kernels():
                 assert torch.isnan(d2[i]).all()      # no gradient tensor: untouched
             else:
                 assert torch.equal(d1[i], d2[i]), i
+
+
+CONV_IN_CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad, pad_mode, act, residual     (every one a split-K launch: few output tiles)
+    (8, 64, 129, 257, 128, 4, 2, 2, 'zero', 'lrelu', False),    # PatchGAN scale-0 layer 1 at C2: 65x129 planes (odd: scalar streams)
+    (8, 128, 65, 129, 256, 4, 2, 2, 'zero', 'lrelu', False),    # layer 2: 33x65 planes (register-cached, 256 threads per plane)
+    (8, 256, 33, 65, 512, 4, 1, 2, 'zero', 'lrelu', False),     # layer 3 (stride 1)
+    (8, 512, 32, 64, 1024, 3, 2, 1, 'zero', 'relu', False),     # generator down-conv 4: 16x32 planes (one wave per plane)
+    (1, 256, 128, 256, 128, 3, 2, 1, 'zero', 'relu', False),    # 64x128 planes (float4 streams, 256 threads per plane)
+    (2, 128, 24, 40, 96, 3, 1, 1, 'reflect', 'none', True),     # ResnetBlock tail shape: reflect pad, residual, no activation
+]
+
+
+@pytest.mark.parametrize('case', CONV_IN_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_conv_instancenorm_act_block_is_bit_identical_to_the_two_launch_path(case):
+    """him_conv2d_in_act_fwd (Conv2d -> InstanceNorm -> activation as one call; split-K layers hand their slabs to the
+    InstanceNorm kernel, reference blocks models/Pix2Pix_NET.py:74-92, models/Discriminator_NET.py:64-96) against
+    (1) conv2d + instance_norm of the same library -- forward, input gradient, weight and bias gradient BIT-identical
+    (same sums in the same order) -- and (2) the torch fp32 reference of the block."""
+    import ctypes
+    from neurips18_hierchical_image_manipulation_amd import config
+    from neurips18_hierchical_image_manipulation_amd._cabi import lib
+    ops = _ops()
+    B, Cin, H, W, Cout, k, stride, pad, pad_mode, act, with_res = case
+    x = _rand(B, Cin, H, W, seed=1)
+    w = _rand(Cout, Cin, k, k, seed=2, scale=(Cin * k * k) ** -0.5)
+    b = _rand(Cout, seed=3, scale=0.1)
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = _rand(B, Cout, OH, OW, seed=5) if with_res else None
+    gz = _rand(B, Cout, OH, OW, seed=4)
+    d = ops._conv_desc(x.to(DEV), w.to(DEV), stride, pad, ops.PAD_REFLECT if pad_mode == 'reflect' else ops.PAD_ZERO,
+                       ops.ACT_NONE, 0.0)
+    assert lib.him_conv2d_in_act_fused(ctypes.byref(d)) == 1, 'case is not a split-K launch: nothing fused is tested'
+    got = {}
+    for fused in (True, False):
+        with config.schedule(conv_in_fused=fused):
+            xd = x.to(DEV).requires_grad_(True)
+            wd = torch.nn.Parameter(w.to(DEV))
+            bd = torch.nn.Parameter(b.to(DEV))
+            rd = res.to(DEV).requires_grad_(True) if with_res else None
+            z = ops.conv2d_in_act(xd, wd, bd, stride, pad, pad_mode, 1e-5, act, 0.2, rd)
+            gs = torch.autograd.grad(z, [xd, wd, bd] + ([rd] if with_res else []), gz.to(DEV))
+            got[fused] = [z.detach()] + [g.detach() for g in gs]
+    for name, a, c in zip(['z', 'dx', 'dw', 'db', 'dres'], got[True], got[False]):
+        assert torch.equal(a, c), '%s differs between the fused call and conv2d + instance_norm (max %g)' % (
+            name, float((a - c).abs().max()))
+    # torch reference of the block
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = _ref_conv(xr, wr, br, stride, pad, pad_mode, 'none')
+    zr = torch.nn.functional.instance_norm(y, eps=1e-5)
+    zr = torch.relu(zr) if act == 'relu' else torch.nn.functional.leaky_relu(zr, 0.2) if act == 'lrelu' else zr
+    if with_res:
+        zr = zr + res
+    gxr, gwr, _ = torch.autograd.grad(zr, [xr, wr, br], gz)
+    assert_close('z', got[True][0], zr, rtol=2e-5)
+    # gradients in relative L2: among ~1e6 normalised values a few land within rounding of 0, their ReLU / LeakyReLU
+    # decision differs between two fp32 summation orders and moves the gradient by O(|gz w|) in that neighbourhood (as in
+    # test_winograd_conv3x3_fwd_bwd) -- a handful of elements, invisible in the norm
+    for name, a, r in (('dx', got[True][1], gxr), ('dw', got[True][2], gwr)):
+        rel = float((a.double().cpu() - r.double()).norm() / r.double().norm())
+        assert rel < 2e-3, '%s: relative L2 distance from the torch block %.3e' % (name, rel)
