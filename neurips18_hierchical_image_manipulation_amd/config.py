@@ -41,6 +41,7 @@ class Schedule(object):
         'real_vgg_first': ('HIM_REAL_VGG_FIRST', False, "real-image stream: VGG(real) in front of the wait for D's update and D(real)"),
         'zero_grad_side': ('HIM_ZERO_GRAD_SIDE', False, 'optimize_parameters() zeroes the gradient arenas on the weight-gradient stream before the forward pass (under it) instead of on the main stream in front of the backward pass'),
         'conv_in_fused': ('HIM_CONV_IN_FUSED', True, 'Conv2d -> InstanceNorm [-> act] blocks through him_conv2d_in_act_fwd: split-K layers hand their slabs to the InstanceNorm kernel (no finish pass)'),
+        'adam_chunked': ('HIM_ADAM_CHUNKED', False, "the generator's Adam step + panel rebuild bucket by bucket DURING its backward pass, as each 64 MB gradient bucket becomes final (and, data parallel, has been exchanged), instead of one 5 GB pass behind the last weight gradient"),
         'keep_wino_input': ('HIM_KEEP_WINO_INPUT', True, "forward keeps the Winograd-transformed input for the layer's weight gradient"),
     }
     # negative spellings kept for the recorded A/B command lines of rounds 2-3
@@ -63,7 +64,7 @@ SCHED = Schedule()
 # every stream of the step switched off: the reference's own order on ONE stream
 SERIAL = dict(wgrad_stream=False, d_wgrad_routes=False, real_ahead=False, d_backward_first=False, vgg_stream=False,
               vgg_backward_early=False, d_scale_streams=False, d_update_early=False, inputs_on_real_stream=False,
-              zero_grad_side=False, real_vgg_first=False)
+              zero_grad_side=False, real_vgg_first=False, adam_chunked=False)
 
 
 @contextlib.contextmanager

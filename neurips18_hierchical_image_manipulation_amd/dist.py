@@ -60,18 +60,23 @@ class GradReducer(object):
     ``ranges``  list of (start, end) element ranges, one per parameter, in FORWARD order.
     """
 
-    def __init__(self, flat, ranges, bucket_bytes=64 << 20, group=None, force=False, comm_stream=None, fake=False):
+    def __init__(self, flat, ranges, bucket_bytes=64 << 20, group=None, force=False, comm_stream=None, fake=False,
+                 local=False):
         """``comm_stream``: the stream the collectives are enqueued on (default: a stream of this reducer's own).  The
         trainers pass their optimizer streams -- idle during the backward pass, and the optimizer step that follows the
         exchange runs there anyway -- so that N > 1 ranks run the SAME number of streams / hardware queues as one rank
         (the step sits at the hardware-queue cliff documented in DESIGN.md: one more queue costs 10 ms per step).
         ``fake``: single-GPU stand-in for the exchange (bench.py --fake-comm): every bucket is a device-to-device copy of
         its bytes on the comm stream at the real trigger point -- the scheduling and HBM cost of the exchange without a
-        second GPU; gradients are left untouched."""
+        second GPU; gradients are left untouched.
+        ``local``: no exchange at all (one rank) -- the reducer only tracks which gradient buckets are final and calls
+        ``bucket_hook(b, start, end)`` on the comm stream behind them (the trainers hang the bucket's Adam step there)."""
         self.flat, self.group = flat, group
         self.fake = bool(fake)
+        self.local = bool(local)
+        self.bucket_hook = None      # called inside _launch, on the comm stream, behind the bucket's exchange
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.active = self.fake or self.world > 1 or (force and dist.is_initialized())   # force: exercise the path on 1 rank
+        self.active = self.fake or self.local or self.world > 1 or (force and dist.is_initialized())   # force: exercise the path on 1 rank
         self.ranges = list(ranges)
         self.range_to_bucket = {}
         self.buckets = []            # (start, end, n_params) ; bucket 0 = LAST parameters (first ready in backward)
@@ -154,14 +159,21 @@ class GradReducer(object):
                     for o in range(0, n, self.scratch.numel()):
                         m = min(self.scratch.numel(), n - o)
                         self.scratch[:m].copy_(view[o:o + m])
+                elif self.local or self.world == 1 and not dist.is_initialized():
+                    pass                                         # one rank: the gradients are final as they are
                 elif dist.get_backend(self.group) == 'nccl':     # RCCL: averaging collective
                     dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group)
                 else:                                            # gloo on device tensors (tests): no AVG op
                     dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
                     view.div_(self.world)
+                if self.bucket_hook is not None:
+                    self.bucket_hook(b, s, e)
         else:
-            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
-            view.div_(self.world)
+            if not self.local:
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+                view.div_(self.world)
+            if self.bucket_hook is not None:
+                self.bucket_hook(b, s, e)
 
     def finish(self):
         """Launch whatever has not been triggered and make the current stream wait for the exchange."""
@@ -241,5 +253,6 @@ def attach_data_parallel(model, bucket_bytes=64 << 20, force=False, broadcast=Tr
         red = GradReducer(arena.grad, [p._him_arena_range for p in arena.params], bucket_bytes, force=force,
                           comm_stream=comm, fake=fake)
         red.attach(arena.params)
+        red.bucket_hook = getattr(model, '_bucket_update_' + tag, None)    # the bucket's Adam step behind its exchange
         setattr(model, 'reducer_' + tag, red)
     return model

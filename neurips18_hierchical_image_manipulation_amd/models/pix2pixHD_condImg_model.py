@@ -141,6 +141,16 @@ class Pix2PixHDModel_condImg(BaseModel):
             self.optimizer_D = FusedAdam(self.netD.parameters(), lr=opt.lr, betas=(opt.beta1, 0.999))
             self.reducer_G = self.reducer_D = None
             self.comm_timing = None
+            self._g_chunked = False
+            if SCHED.adam_chunked:
+                # one rank: a LOCAL reducer (no exchange) that only tracks which 64 MB gradient buckets are final and
+                # triggers their Adam step (_bucket_update_G); dist.attach_data_parallel replaces it by the real one
+                from ..dist import GradReducer
+                arena = self.optimizer_G.arena
+                self.reducer_G = GradReducer(arena.grad, [p._him_arena_range for p in arena.params], local=True,
+                                             comm_stream=ops._opt_stream(self.device))
+                self.reducer_G.attach(arena.params)
+                self.reducer_G.bucket_hook = self._bucket_update_G
             # autograd creates a parameter's AccumulateGrad node lazily, on the stream that is current at the parameter's
             # first use of a step -- for D the side stream (real-image branch) -- and makes the caller's stream wait for
             # every such "leaf stream" when backward() returns: loss_G.backward() ended with the main stream waiting for
@@ -572,6 +582,9 @@ class Pix2PixHDModel_condImg(BaseModel):
                 self.reducer_D.begin(contributions=2)
             self._run_backward_D(first=True)
             if self.reducer_G is not None:
+                self._g_chunked = SCHED.adam_chunked and self.reducer_G.bucket_hook is not None
+                if self._g_chunked:
+                    self.optimizer_G.begin_step()
                 self.reducer_G.begin()
             if early is not None:
                 main.wait_stream(ops._vgg_stream(self.device))
@@ -592,9 +605,13 @@ class Pix2PixHDModel_condImg(BaseModel):
                 if self.reducer_G is not None:
                     self.reducer_G.finish()
                 self.optimizer_G.step()
+            self._g_chunked = False
             self._g_update_pending = True
         else:
             if self.reducer_G is not None:
+                self._g_chunked = SCHED.adam_chunked and self.reducer_G.bucket_hook is not None
+                if self._g_chunked:
+                    self.optimizer_G.begin_step()
                 self.reducer_G.begin()
             self._run_backward_G()
             # G's exchange + Adam step go to their own stream: they wait for G's data-gradient chain (main) and weight
@@ -604,6 +621,7 @@ class Pix2PixHDModel_condImg(BaseModel):
                 if self.reducer_G is not None:
                     self.reducer_G.finish()
                 self.optimizer_G.step()
+            self._g_chunked = False
             if gan:
                 if self.reducer_D is not None:
                     self.reducer_D.begin(contributions=2)
@@ -628,6 +646,14 @@ class Pix2PixHDModel_condImg(BaseModel):
         self.loss_G = self.loss_D = None
         self._fake_gate = None
         return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in loss_dict.items()}
+
+    def _bucket_update_G(self, b, start, end):
+        """dist.GradReducer.bucket_hook of the generator: gradient bucket [start, end) is final (all its weight gradients
+        queued, exchanged when data parallel) and the reducer has made its stream -- the generator's optimizer stream -- wait
+        for them: the bucket's Adam step + panel rebuild go right behind, under the rest of the backward pass.  Only inside
+        optimize_parameters() (``_g_chunked``): nothing reads a layer's weights after its own backward there."""
+        if self._g_chunked:
+            self.optimizer_G.step_range(start, end)
 
     def _d_update(self):
         """D's gradient exchange (data parallel) + Adam step + panel rebuild on D's optimizer stream, after everything the

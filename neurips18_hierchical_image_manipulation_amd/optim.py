@@ -9,6 +9,8 @@ gradients, and Adam's two moments).  Consequences:
 Parameters stay ordinary ``nn.Parameter`` objects (views into the arena), so ``state_dict()`` keys and
 tensors are exactly the reference's (``models/base_model.py:46-51`` checkpoint format).
 """
+import bisect
+
 import torch
 
 from ._cabi import lib
@@ -100,20 +102,65 @@ class FusedAdam(object):
             i += n
         return runs
 
-    def step(self):
+    # ---- one optimizer step in pieces (bucket by bucket, as the gradients become final during the backward pass) ----
+    def begin_step(self):
+        """Open a step that ``step_range`` will carry out piecewise; ``step()`` closes it (whatever is left)."""
         self.step_count += 1
+        self._done = []
+
+    def _adam(self, lo, hi):
         a = self.arena
-        from .ops import join_side_stream
-        join_side_stream(a.grad.device)        # wait for the side-stream weight gradients
         for (s, e, lr, b1, b2, eps) in self._runs():
-            lib.him_adam_step(a.data.data_ptr() + 4 * s, a.grad.data_ptr() + 4 * s, self.exp_avg.data_ptr() + 4 * s,
-                              self.exp_avg_sq.data_ptr() + 4 * s, e - s, lr, b1, b2, eps, self.step_count, _stream())
+            s, e = max(s, lo), min(e, hi)
+            if s < e:
+                lib.him_adam_step(a.data.data_ptr() + 4 * s, a.grad.data_ptr() + 4 * s, self.exp_avg.data_ptr() + 4 * s,
+                                  self.exp_avg_sq.data_ptr() + 4 * s, e - s, lr, b1, b2, eps, self.step_count, _stream())
+
+    def _params_in(self, lo, hi):
+        a = self.arena
+        i = bisect.bisect_left(a.offsets, lo)
+        out = []
+        while i < len(a.offsets) and a.offsets[i] < hi:
+            out.append(a.params[i])
+            i += 1
+        return out
+
+    def step_range(self, lo, hi):
+        """Adam update + panel rebuild of arena elements [lo, hi) on the current stream.  The caller guarantees that their
+        gradients are final (and exchanged) and that nothing still reads these parameters (their layers' data gradients
+        have run) -- the data-parallel reducer's bucket trigger (dist.GradReducer.bucket_hook)."""
+        if getattr(self, '_done', None) is None:
+            raise RuntimeError('step_range outside begin_step() ... step()')
+        self._adam(lo, hi)
+        self._done.append((lo, hi))
+        from .ops import refresh_panels
+        refresh_panels(self._params_in(lo, hi))
+
+    def step(self):
+        a = self.arena
+        from .ops import join_side_stream, refresh_panels
+        join_side_stream(a.grad.device)        # wait for the side-stream weight gradients
+        done = getattr(self, '_done', None)
+        if done is None:
+            self.step_count += 1
+            todo = [(0, a.total)]
+        else:                                  # close a piecewise step: the complement of what step_range has covered
+            todo, at = [], 0
+            for lo, hi in sorted(done):
+                if lo > at:
+                    todo.append((at, lo))
+                at = max(at, hi)
+            if at < a.total:
+                todo.append((at, a.total))
+            self._done = None
+        for lo, hi in todo:
+            self._adam(lo, hi)
         # everything that reads the RAW parameters may start here; every cached weight panel carries its own event
         # (ops._panel waits for it), so a consumer need not wait for the whole rebuild pass below
         self.updated = torch.cuda.Event()
         self.updated.record(torch.cuda.current_stream(a.data.device))
-        from .ops import refresh_panels
-        refresh_panels(a.params)               # regrouped weight panels of the conv kernels follow the update
+        for lo, hi in todo:                    # regrouped weight panels of the conv kernels follow the update
+            refresh_panels(self._params_in(lo, hi) if done is not None else a.params)
 
     def load_moments(self, exp_avgs, exp_avg_sqs, step):
         """Adopt per-parameter Adam moments (e.g. from a torch.optim.Adam) -- used by checkpoint import and by the

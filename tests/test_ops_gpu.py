@@ -839,3 +839,36 @@ def test_conv_instancenorm_act_block_is_bit_identical_to_the_two_launch_path(cas
     for name, a, r in (('dx', got[True][1], gxr), ('dw', got[True][2], gwr)):
         rel = float((a.double().cpu() - r.double()).norm() / r.double().norm())
         assert rel < 2e-3, '%s: relative L2 distance from the torch block %.3e' % (name, rel)
+
+
+def test_piecewise_adam_step_is_bit_identical_to_the_whole_step():
+    """FusedAdam.begin_step / step_range / step (the generator's optimizer step carried out bucket by bucket during its
+    backward pass, config.SCHED.adam_chunked) against one whole-arena step(): parameters, both moments and the step count
+    bit-identical over three steps, with two hyper-parameter groups and pieces that cut across them."""
+    from neurips18_hierchical_image_manipulation_amd.optim import FusedAdam
+    shapes = [(64, 38, 7, 7), (64,), (128, 64, 3, 3), (128,), (3, 64, 7, 7), (1000,), (17,)]
+
+    def make():
+        ps = [torch.nn.Parameter(_rand(*s, seed=10 + i, scale=0.02).to(DEV)) for i, s in enumerate(shapes)]
+        groups = [dict(params=ps[:3], lr=2e-4), dict(params=ps[3:], lr=5e-5)]
+        return ps, FusedAdam(groups, lr=2e-4, betas=(0.5, 0.999))
+
+    pa, oa = make()
+    pb, ob = make()
+    offs = oa.arena.offsets
+    for step in range(3):
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            g = _rand(*a.shape, seed=100 * step + i).to(DEV)
+            a.grad.copy_(g)
+            b.grad.copy_(g)
+        oa.step()
+        ob.begin_step()
+        ob.step_range(offs[4], oa.arena.total)           # the LAST parameters first, as the backward pass delivers them
+        ob.step_range(offs[2], offs[4])                  # cuts across the two lr groups
+        ob.step()                                        # closes the step: whatever is left ([0, offs[2]))
+        torch.cuda.synchronize()
+        assert oa.step_count == ob.step_count == step + 1
+        assert torch.equal(oa.arena.data, ob.arena.data), 'parameters differ after step %d' % step
+        assert torch.equal(oa.exp_avg, ob.exp_avg) and torch.equal(oa.exp_avg_sq, ob.exp_avg_sq)
+    with pytest.raises(RuntimeError):
+        ob.step_range(0, 10)                             # outside begin_step() ... step()
