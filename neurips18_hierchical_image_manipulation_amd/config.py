@@ -42,6 +42,7 @@ class Schedule(object):
         'zero_grad_side': ('HIM_ZERO_GRAD_SIDE', False, 'optimize_parameters() zeroes the gradient arenas on the weight-gradient stream before the forward pass (under it) instead of on the main stream in front of the backward pass'),
         'conv_in_fused': ('HIM_CONV_IN_FUSED', True, 'Conv2d -> InstanceNorm [-> act] blocks through him_conv2d_in_act_fwd: split-K layers hand their slabs to the InstanceNorm kernel (no finish pass)'),
         'adam_chunked': ('HIM_ADAM_CHUNKED', False, "the generator's Adam step + panel rebuild bucket by bucket DURING its backward pass, as each 64 MB gradient bucket becomes final (and, data parallel, has been exchanged), instead of one 5 GB pass behind the last weight gradient"),
+        'd_prefill_cond': ('HIM_D_PREFILL_COND', True, "the condition channels of the first PatchGAN conv's input buffers copied at the start of the step (ops.cond_pyramid), only the image channels per pass"),
         'keep_wino_input': ('HIM_KEEP_WINO_INPUT', True, "forward keeps the Winograd-transformed input for the layer's weight gradient"),
     }
     # negative spellings kept for the recorded A/B command lines of rounds 2-3

@@ -294,7 +294,7 @@ class Pix2PixHDModel_condImg(BaseModel):
             mask_cond = mask_in if not self.use_soft_mask else self._dev(mask_out)
             if self._d_split():
                 # the pooled condition of the PatchGAN scales: once per step, before the streams fork (every pass reads it)
-                ops.cond_pyramid(netD_cond, opt.num_D)
+                ops.cond_pyramid(netD_cond, opt.num_D, prefill=2 if self.isTrain else 0, image_channels=opt.output_nc)
             inputs_ready = torch.cuda.Event()
             inputs_ready.record(torch.cuda.current_stream(self.device))
         if enc_side is not None:

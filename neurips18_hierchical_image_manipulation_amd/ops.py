@@ -586,14 +586,29 @@ class CondImage(object):
         return cat_channels([self.cond, self.image])
 
 
-def cond_pyramid(cond, levels):
-    """[cond, pool(cond), pool(pool(cond)), ...] (AvgPool2d(3, 2, 1, count_include_pad=False)), cached on the tensor."""
+def cond_pyramid(cond, levels, prefill=0, image_channels=3):
+    """[cond, pool(cond), pool(pool(cond)), ...] (AvgPool2d(3, 2, 1, count_include_pad=False)), cached on the tensor.
+    ``prefill``: per level, that many (B, Cc + image_channels, H, W) input buffers of the first PatchGAN conv with the
+    condition already copied in (``_CondImageConv2d`` takes one per pass and adds only the image channels): the 164 MB
+    condition copy of the fake-image pass sat on the main stream between the generator's last conv and the first
+    discriminator conv; filled here -- at the start of the step, next to the previous step's Adam pass -- it is off the
+    critical path."""
     pyr = getattr(cond, '_him_pyramid', None)
     if pyr is None or len(pyr) < levels:
         with torch.no_grad():
             pyr = [cond.detach()]
             while len(pyr) < levels:
                 pyr.append(avgpool3s2(pyr[-1]))
+            if prefill > 0 and SCHED.d_prefill_cond:
+                st = _stream()
+                for c in pyr:
+                    B, Cc, H, W = c.shape
+                    bufs = []
+                    for _ in range(prefill):
+                        x = torch.empty((B, Cc + image_channels, H, W), dtype=torch.float32, device=c.device)
+                        lib.him_copy_channels(_p(c), Cc, 0, _p(x), Cc + image_channels, 0, Cc, B, H * W, 0, 0, 0, st)
+                        bufs.append(x)
+                    c._him_prefilled = bufs
         cond._him_pyramid = pyr
     return pyr
 
@@ -611,8 +626,13 @@ class _CondImageConv2d(torch.autograd.Function):
         if image.shape[0] != B or tuple(image.shape[2:]) != (H, W):
             raise HimError('cond/image conv: shapes %s and %s do not stack' % (tuple(cond.shape), tuple(image.shape)))
         st = _stream()
-        x = torch.empty((B, Cc + Ci, H, W), dtype=torch.float32, device=cond.device)
-        lib.him_copy_channels(_p(cond), Cc, 0, _p(x), Cc + Ci, 0, Cc, B, H * W, 0, 0, 0, st)
+        pre = getattr(cond, '_him_prefilled', None)
+        if pre and tuple(pre[-1].shape) == (B, Cc + Ci, H, W):
+            x = pre.pop()                  # condition channels filled by cond_pyramid at the start of the step
+            x.record_stream(torch.cuda.current_stream(x.device))
+        else:
+            x = torch.empty((B, Cc + Ci, H, W), dtype=torch.float32, device=cond.device)
+            lib.him_copy_channels(_p(cond), Cc, 0, _p(x), Cc + Ci, 0, Cc, B, H * W, 0, 0, 0, st)
         lib.him_copy_channels(_p(image), Ci, 0, _p(x), Cc + Ci, Cc, Ci, B, H * W, 0, 0, 0, st)
         d = _conv_desc(x, w, stride, pad, PAD_ZERO, act, slope)
         y = torch.empty((d.B, d.Cout, d.OH, d.OW), dtype=torch.float32, device=x.device)
