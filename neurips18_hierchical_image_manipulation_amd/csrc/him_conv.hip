@@ -146,6 +146,7 @@ static bool launch_gconv_small(const HimAlgo& a, const GConvP& p, long long maxN
     if (tj == 7) launch_small_cfg<MMv, 7>(p, maxN, st);      \
     else if (tj == 4) launch_small_cfg<MMv, 4>(p, maxN, st); \
     else if (tj == 3) launch_small_cfg<MMv, 3>(p, maxN, st); \
+    else if (tj == 2) launch_small_cfg<MMv, 2>(p, maxN, st); \
     else launch_small_cfg<MMv, 0>(p, maxN, st);              \
     break;
   switch (p.M) {
