@@ -27,6 +27,79 @@ def test_library_exports_every_declared_symbol():
     assert _cabi.lib.him_arch() == b'gfx950'
 
 
+def _header_structs():
+    """{struct name: [field names]} of every descriptor typedef in include/him.h."""
+    hdr = re.sub(r'/\*.*?\*/', '', open(os.path.join(ROOT, 'include', 'him.h')).read(), flags=re.S)
+    out = {}
+    for body, name in re.findall(r'typedef\s+struct(?:\s+\w+)?\s*\{(.*?)\}\s*(\w+)\s*;', hdr, flags=re.S):
+        fields = []
+        for decl in body.split(';'):
+            decl = decl.strip()
+            if decl:
+                fields += [re.sub(r'\[.*', '', f).strip() for f in decl.split(None, 1)[1].split(',')]
+        out[name] = fields
+    return out
+
+
+def test_ctypes_descriptors_have_the_layout_of_the_header(tmp_path):
+    """Every struct of include/him.h, compiled by gcc, against its ctypes mirror in _cabi.py: size and the offset of every
+    field (a descriptor that is too short on the Python side makes the library read past it)."""
+    from neurips18_hierchical_image_manipulation_amd import _cabi
+    structs = _header_structs()
+    assert {'HimAlgo', 'HimConv2d', 'HimDeconv2d', 'HimResBlock'} <= set(structs), structs.keys()
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "him.h"', 'int main(void) {']
+    for name, fields in structs.items():
+        lines.append('  printf("%s sizeof %%zu\\n", sizeof(%s));' % (name, name))
+        lines += ['  printf("%s %s %%zu\\n", offsetof(%s, %s));' % (name, f, name, f) for f in fields]
+    lines += ['  return 0;', '}']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = str(tmp_path / 'layout')
+    subprocess.check_call(['gcc', '-std=c99', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), str(src), '-o', exe])
+    seen = 0
+    for line in subprocess.check_output([exe], text=True).splitlines():
+        name, field, value = line.split()
+        mirror = getattr(_cabi, name)
+        if field == 'sizeof':
+            assert ctypes.sizeof(mirror) == int(value), (name, ctypes.sizeof(mirror), value)
+        else:
+            assert getattr(mirror, field).offset == int(value), (name, field)
+        seen += 1
+    assert seen > 40
+
+
+def test_integration_md_bindings_match_the_header(tmp_path):
+    """the ctypes stub a maintainer would paste must declare the descriptors exactly as include/him.h
+    does (field for field, HimAlgo included), and the C snippet must compile against the header."""
+    from neurips18_hierchical_image_manipulation_amd import _cabi
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    py = [b for b in re.findall(r'```python\n(.*?)```', doc, flags=re.S) if 'ctypes.Structure' in b]
+    assert len(py) == 1
+    scope = {}
+    cwd = os.getcwd()
+    os.chdir(ROOT)          # the stub loads the library by its repo-relative path
+    try:
+        exec(compile(py[0], 'INTEGRATION.md', 'exec'), scope)
+    finally:
+        os.chdir(cwd)
+    for name in ('HimAlgo', 'HimConv2d'):
+        doc_fields = [(n, ctypes.sizeof(t)) for n, t in scope[name]._fields_]
+        abi_fields = [(n, ctypes.sizeof(t)) for n, t in getattr(_cabi, name)._fields_]
+        assert doc_fields == abi_fields, name
+        assert [f for f, _ in doc_fields] == _header_structs()[name], name
+    assert callable(scope['reflect_conv3x3'])
+    c_blocks = re.findall(r'```c\n(.*?)```', doc, flags=re.S)
+    assert c_blocks
+    for i, block in enumerate(c_blocks):
+        includes = [l for l in block.splitlines() if l.startswith('#include')]
+        body = [l for l in block.splitlines() if not l.startswith('#include')]
+        src = tmp_path / ('snippet%d.c' % i)
+        src.write_text('#include <stdio.h>\n' + '\n'.join(includes) +
+                       '\nvoid snippet(const float* x_dev, const float* w_dev, const float* b_dev, float* y_dev, '
+                       'void* ws_dev, void* stream) {\n' + '\n'.join(body) + '\n}\n')
+        subprocess.check_call(['gcc', '-std=c99', '-Wall', '-Werror', '-Wno-unused-variable', '-fsyntax-only', '-I', ROOT, str(src)])
+
+
 def test_descriptor_validation_without_gpu():
     """Argument checking happens before any launch, so it is testable on the CPU box."""
     from neurips18_hierchical_image_manipulation_amd import _cabi
