@@ -1,6 +1,9 @@
-"""Multi-scale PatchGAN on the HIP layer executor (reference ``models/Discriminator_NET.py:11-118``,
-getIntermFeat=True; keys ``scale<i>_layer<j>.0.{weight,bias}``)."""
+"""Multi-scale PatchGAN on the HIP layer executor (reference ``models/Discriminator_NET.py:11-118``; state-dict keys
+``scale<i>_layer<j>.0.{weight,bias}`` with getIntermFeat, ``layer<i>.<n>.{weight,bias}`` without -- the reference builds
+its discriminator with ``getIntermFeat = not opt.no_ganFeat_loss``, ``pix2pixHD_condImg_model.py:74-75``)."""
 import os
+import re
+from collections import OrderedDict
 
 import torch
 import torch.nn as nn
@@ -8,6 +11,42 @@ import torch.nn as nn
 from .. import ops
 from ..nn import InstanceNorm2d, BatchNorm2d, LeakyReLU, FusedSequential, AvgPool3s2, _pw
 from .layer_util import weights_init
+
+
+def _flat_index(n_layers):
+    """Position of block j's first module inside the reference's flattened ``NLayerDiscriminator.model`` Sequential
+    (Discriminator_NET.py:100-104): [conv, lrelu] + (n_layers - 1) x [conv, norm, lrelu] + [conv, norm, lrelu] + [conv]."""
+    lens = [2] + [3] * n_layers + [1]
+    return [sum(lens[:j]) for j in range(n_layers + 2)]
+
+
+def _keys_to_flat(module, state_dict, prefix, local_metadata):
+    """state_dict hook (getIntermFeat=False): ``scale<i>_layer<j>.<k>.*`` -> ``layer<i>.<first[j] + k>.*``, order kept."""
+    first = _flat_index(module.n_layers)
+    pat = re.compile(re.escape(prefix) + r'scale(\d+)_layer(\d+)\.(\d+)\.(.*)$')
+    items = list(state_dict.items())
+    meta = getattr(state_dict, '_metadata', None)
+    state_dict.clear()
+    for k, v in items:
+        m = pat.match(k)
+        if m:
+            k = '%slayer%s.%d.%s' % (prefix, m.group(1), first[int(m.group(2))] + int(m.group(3)), m.group(4))
+        state_dict[k] = v
+    if meta is not None:
+        state_dict._metadata = meta
+    return state_dict
+
+
+def _keys_from_flat(module, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+    """load_state_dict pre-hook (getIntermFeat=False): the inverse renaming, in place."""
+    first = _flat_index(module.n_layers)
+    pat = re.compile(re.escape(prefix) + r'layer(\d+)\.(\d+)\.(.*)$')
+    for k in list(state_dict.keys()):
+        m = pat.match(k)
+        if m:
+            n = int(m.group(2))
+            j = max(jj for jj, f in enumerate(first) if f <= n)
+            state_dict['%sscale%s_layer%d.%d.%s' % (prefix, m.group(1), j, n - first[j], m.group(3))] = state_dict.pop(k)
 
 
 class MultiscaleDiscriminator(nn.Module):
@@ -29,9 +68,13 @@ class MultiscaleDiscriminator(nn.Module):
             # so GANLoss's nn.BCELoss (losses.py:19-20) is fed raw logits (an error in torch >= 0.4, NaNs before).
             raise NotImplementedError('--no_lsgan: the reference drops the Sigmoid in front of its BCELoss on this path '
                                       '(Discriminator_NET.py:24-27); LSGAN only')
+        self.num_D, self.n_layers, self.getIntermFeat = num_D, n_layers, bool(getIntermFeat)
         if not getIntermFeat:
-            raise NotImplementedError('the mask2image model always asks for intermediate features')
-        self.num_D, self.n_layers = num_D, n_layers
+            # --no_ganFeat_loss: the reference keeps each scale as ONE flattened Sequential ``layer<i>`` (:27-28) -- the same
+            # convolutions on the same inputs, other checkpoint keys.  The blocks stay separate here (one executor for both
+            # forms); only the names a checkpoint sees change.
+            self._register_state_dict_hook(_keys_to_flat)
+            self._register_load_state_dict_pre_hook(_keys_from_flat, with_module=True)
         for i in range(num_D):
             blocks = [[Conv2d(input_nc, ndf, 4, 2, 2), LeakyReLU(0.2)]]
             nf = ndf

@@ -102,7 +102,7 @@ class Pix2PixHDModel_condImg(BaseModel):
                 netD_input_nc = 3
             from .Discriminator_NET import MultiscaleDiscriminator
             self.netD = MultiscaleDiscriminator(netD_input_nc, opt.ndf, opt.n_layers_D, opt.norm, opt.no_lsgan,
-                                                opt.num_D, True, spectral_norm=bool(getattr(opt, 'sn_D', False)))
+                                                opt.num_D, not opt.no_ganFeat_loss, spectral_norm=bool(getattr(opt, 'sn_D', False)))
             self.netD.to(self.device)
 
         if not self.isTrain or opt.continue_train or opt.load_pretrain:

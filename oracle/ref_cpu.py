@@ -180,12 +180,48 @@ class GlobalTwoStreamGenerator(nn.Module):
         return y
 
 
-class MultiscaleDiscriminator(nn.Module):
-    """models/Discriminator_NET.py:11-118 with getIntermFeat=True (keys ``scale<i>_layer<j>.0.*``)."""
+def _d_flat_first(n_layers):
+    """models/Discriminator_NET.py:100-104: where block j starts inside the flattened ``NLayerDiscriminator.model``."""
+    lens = [2] + [3] * n_layers + [1]
+    return [sum(lens[:j]) for j in range(n_layers + 2)]
 
-    def __init__(self, input_nc, ndf=64, n_layers=3, num_D=3, norm='instance', spectral_norm=False):
+
+def _d_keys_out(module, sd, prefix, local_metadata):
+    import re
+    first, pat = _d_flat_first(module.n_layers), re.compile(re.escape(prefix) + r'scale(\d+)_layer(\d+)\.(\d+)\.(.*)$')
+    items, meta = list(sd.items()), getattr(sd, '_metadata', None)
+    sd.clear()
+    for k, v in items:
+        m = pat.match(k)
+        sd['%slayer%s.%d.%s' % (prefix, m.group(1), first[int(m.group(2))] + int(m.group(3)), m.group(4)) if m else k] = v
+    if meta is not None:
+        sd._metadata = meta
+    return sd
+
+
+def _d_keys_in(module, sd, prefix, *unused):
+    import re
+    first, pat = _d_flat_first(module.n_layers), re.compile(re.escape(prefix) + r'layer(\d+)\.(\d+)\.(.*)$')
+    for k in list(sd.keys()):
+        m = pat.match(k)
+        if m:
+            n = int(m.group(2))
+            j = max(jj for jj, f in enumerate(first) if f <= n)
+            sd['%sscale%s_layer%d.%d.%s' % (prefix, m.group(1), j, n - first[j], m.group(3))] = sd.pop(k)
+
+
+class MultiscaleDiscriminator(nn.Module):
+    """models/Discriminator_NET.py:11-118.  getIntermFeat=True: keys ``scale<i>_layer<j>.0.*`` (:24-26); False
+    (``--no_ganFeat_loss``, pix2pixHD_condImg_model.py:74-75): the reference registers each scale as one flattened
+    Sequential ``layer<i>`` (:27-28, keys ``layer<i>.<n>.*``) -- the same modules on the same inputs, so the blocks stay
+    separate here and only the state-dict names follow the reference."""
+
+    def __init__(self, input_nc, ndf=64, n_layers=3, num_D=3, norm='instance', spectral_norm=False, getIntermFeat=True):
         super().__init__()
         self.num_D, self.n_layers = num_D, n_layers
+        if not getIntermFeat:
+            self._register_state_dict_hook(_d_keys_out)
+            self._register_load_state_dict_pre_hook(_d_keys_in, with_module=True)
         _in_layer = globals()['_in_layer'] if norm == 'instance' else nn.BatchNorm2d   # 'batch': box2mask D
         conv = globals()['SNConv2d'] if spectral_norm else nn.Conv2d   # the build's --sn_D wrap (not a reference flag)
         for i in range(num_D):
@@ -392,7 +428,8 @@ class Mask2ImageModel(nn.Module):
         if opt.netG == 'global_twostream' and opt.which_encoder == 'ctx':
             d_in = 3
         self.d_in = d_in
-        self.netD = MultiscaleDiscriminator(d_in, opt.ndf, opt.n_layers_D, opt.num_D, spectral_norm=opt.sn_D)
+        self.netD = MultiscaleDiscriminator(d_in, opt.ndf, opt.n_layers_D, opt.num_D, spectral_norm=opt.sn_D,
+                                            getIntermFeat=not opt.no_ganFeat_loss)
         self.vgg = None if opt.no_vgg_loss else Vgg19()
         self.optimizer_G = torch.optim.Adam(self.netG.parameters(), lr=opt.lr, betas=(opt.beta1, 0.999))
         self.optimizer_D = torch.optim.Adam(self.netD.parameters(), lr=opt.lr, betas=(opt.beta1, 0.999))

@@ -2,7 +2,7 @@
 /root/reference through oracle/ref_shim.py) and, in the same breath, assert that oracle/ref_cpu.py
 reproduces it.  Runs only in the build container.  Usage:
 
-    python tests/golden/make_golden.py [tiny] [c1] [c2]
+    python tests/golden/make_golden.py [tiny] [flags] [c1] [c2]
 
 Fixtures hold arrays + the flag dict only (no reference source).  Weights/batches are NOT stored: they
 are regenerated from neurips18_hierchical_image_manipulation_amd.synth seeds (G=1, D=2, VGG=3; batch
@@ -50,12 +50,15 @@ def load_same(rm, om):
         om.vgg.load_state_dict(sdV)
 
 
-def trajectory(tag, fl, B, H, W, steps, color=False, save_outputs=False):
+def trajectory(tag, fl, B, H, W, steps, color=False, save_outputs=False, save_keys=False):
     t0 = time.time()
     rm, _ = ref_shim.make_model(flags_to_argv(dict(fl, batchSize=B)), color=color)
     om = ref_cpu.Mask2ImageModel(ref_cpu.Opt(**fl))
     load_same(rm, om)
     extra = {}
+    if save_keys:       # the checkpoint ABI of this flag set: the REFERENCE's state-dict key names, in its order
+        extra['g_keys'] = np.array(list(rm.netG.state_dict().keys()))
+        extra['d_keys'] = np.array(list(rm.netD.state_dict().keys()))
     if save_outputs:
         b0 = synth.make_batch(0, 0, B, H, W, fl.get('label_nc', 35), color)
         with torch.no_grad():
@@ -359,6 +362,14 @@ TINY_TWO = dict(model='pix2pixHD_condImg', netG='global_twostream', ngf=8, ndf=8
                 n_blocks_global=2, num_D=2, n_layers_D=3, label_nc=35, no_instance=True, no_imgCond=True,
                 which_encoder='ctx_label', use_skip=True, use_output_gate=True, mask_gan_input=True)
 TINY_COLOR = dict(TINY_TWO, model='pix2pixHD_condImgColor', label_nc=49)
+# loss / input flags of options/mask2image_train_options.py:39-46 on a 2-down toy net (the flag sets of
+# tests/test_model_gpu.py::test_loss_flag_variants_teacher_forced); --no_ganFeat_loss also changes the discriminator's
+# checkpoint keys (getIntermFeat=False: one flattened Sequential per scale, models/Discriminator_NET.py:27-28)
+TINY2 = dict(TINY, n_downsample_global=2)
+FLAG_VARIANTS = {'tiny_flag_lambda_rec': dict(TINY2, lambda_rec=5.0),
+                 'tiny_flag_soft_mask': dict(TINY2, use_soft_mask=True, mask_gan_input=True),
+                 'tiny_flag_rec_no_ganfeat': dict(TINY2, lambda_rec=2.0, no_ganFeat_loss=True),
+                 'tiny_flag_no_vgg_no_imgcond': dict(TINY2, no_vgg_loss=True, no_imgCond=True)}
 C1 = dict(model='pix2pixHD_condImg', netG='global', ngf=64, ndf=64, n_downsample_global=4, n_blocks_global=9,
           num_D=1, n_layers_D=3, label_nc=35, no_instance=True)
 C2 = dict(C1, num_D=3)
@@ -378,6 +389,9 @@ if __name__ == '__main__':
         trajectory('tiny_inst', TINY_INST, 2, 32, 64, 5, save_outputs=True)
         trajectory('tiny_twostream', TINY_TWO, 2, 64, 64, 20, save_outputs=True)
         trajectory('tiny_color', TINY_COLOR, 2, 64, 64, 5, color=True)
+    if 'flags' in what:
+        for tag, fl in FLAG_VARIANTS.items():
+            trajectory(tag, fl, 2, 32, 64, 5, save_keys=True)
     if 'c1' in what:
         trajectory('c1_traj', C1, 1, 128, 256, 20)
     if 'c2' in what:

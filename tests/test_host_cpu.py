@@ -187,6 +187,48 @@ def test_state_dict_keys_match_oracle_for_every_generator():
         assert [tuple(v.shape) for v in sa.values()] == [tuple(v.shape) for v in sb.values()]
 
 
+FLAG_GOLDENS = ('tiny_flag_lambda_rec', 'tiny_flag_soft_mask', 'tiny_flag_rec_no_ganfeat', 'tiny_flag_no_vgg_no_imgcond')
+
+
+@pytest.mark.parametrize('tag', FLAG_GOLDENS)
+def test_checkpoint_keys_follow_the_reference_for_every_flag_set(tag):
+    """The checkpoint ABI per flag set: the key names (and their order) of the REAL reference's netG / netD state dicts,
+    stored by tests/golden/make_golden.py flags.  ``--no_ganFeat_loss`` builds the reference's discriminator with
+    getIntermFeat=False (pix2pixHD_condImg_model.py:74-75): keys ``layer<i>.<n>.*`` (Discriminator_NET.py:27-28) instead
+    of ``scale<i>_layer<j>.0.*``; ``--no_imgCond`` drops 3 input channels."""
+    import json
+    from oracle import ref_cpu
+    from neurips18_hierchical_image_manipulation_amd import options
+    from neurips18_hierchical_image_manipulation_amd.models import Pix2Pix_NET as P
+    from neurips18_hierchical_image_manipulation_amd.models.Discriminator_NET import MultiscaleDiscriminator
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', tag + '.npz'), allow_pickle=False)
+    flags = json.loads(str(g['flags']))
+    g_keys, d_keys = [str(k) for k in g['g_keys']], [str(k) for k in g['d_keys']]
+    flat = bool(flags.get('no_ganFeat_loss'))
+    assert all(k.startswith('layer' if flat else 'scale') for k in d_keys)
+    om = ref_cpu.Mask2ImageModel(ref_cpu.Opt(**flags))
+    assert list(om.netG.state_dict().keys()) == g_keys and list(om.netD.state_dict().keys()) == d_keys
+    nc = flags['label_nc']
+    d_in = nc + 3 + (0 if flags.get('no_imgCond') else 3)
+    netD = MultiscaleDiscriminator(d_in, flags['ndf'], flags['n_layers_D'], 'instance', False, flags['num_D'], not flat)
+    netG = P.GlobalGenerator(nc + (0 if flags.get('no_imgCond') else 3), 3, flags['ngf'], flags['n_downsample_global'],
+                             flags['n_blocks_global'])
+    assert list(netG.state_dict().keys()) == g_keys
+    sd = netD.state_dict()
+    assert list(sd.keys()) == d_keys
+    assert [tuple(v.shape) for v in sd.values()] == [tuple(v.shape) for v in om.netD.state_dict().values()]
+    # a reference-keyed checkpoint loads (strictly) and round-trips; the module names underneath do not change
+    ref_sd = {k: torch.full_like(v, float(i)) for i, (k, v) in enumerate(om.netD.state_dict().items())}
+    netD.load_state_dict(ref_sd, strict=True)
+    back = netD.state_dict()
+    assert all(torch.equal(back[k], ref_sd[k]) for k in d_keys)
+    assert [n for n, _ in netD.named_parameters()] == [n for n, _ in om.netD.named_parameters()]
+    assert all(n.startswith('scale') for n, _ in netD.named_parameters())
+    with pytest.raises(RuntimeError):
+        netD.load_state_dict({k.replace('layer', 'scale') if flat else k.replace('scale', 'layer'): v
+                              for k, v in ref_sd.items()}, strict=True)
+
+
 def test_fusion_plan_groups_pad_conv_norm_act(monkeypatch):
     from neurips18_hierchical_image_manipulation_amd import nn as hn, ops
     calls = []

@@ -71,7 +71,11 @@ def test_tiny_global_forward_tensors_match_reference():
             assert_close('D scale %d logits' % i, sc[-1], torch.from_numpy(g['d_logits%d' % i]), rtol=2e-4)
 
 
-@pytest.mark.parametrize('tag', ['tiny_global', 'tiny_gate3', 'tiny_inst', 'tiny_twostream', 'tiny_color'])
+@pytest.mark.parametrize('tag', ['tiny_global', 'tiny_gate3', 'tiny_inst', 'tiny_twostream', 'tiny_color',
+                                 # loss / input flags (options/mask2image_train_options.py:39-46), goldens from the REAL
+                                 # reference run with those flags (make_golden.py flags)
+                                 'tiny_flag_lambda_rec', 'tiny_flag_soft_mask', 'tiny_flag_rec_no_ganfeat',
+                                 'tiny_flag_no_vgg_no_imgcond'])
 def test_tiny_trajectories_match_reference(tag):
     rel, _, _, _ = run_traj(tag)
     assert rel[0].max() < 1e-4, 'step-0 losses: %s' % rel[0]
@@ -525,6 +529,31 @@ def test_edges_match_reference_golden():
                        no_vgg_loss=True))
     e = model.get_edges(torch.from_numpy(g['edge_inst']))
     assert torch.equal(e.cpu(), torch.from_numpy(g['edge_map']))
+
+
+def test_no_ganFeat_loss_checkpoint_has_the_reference_keys(tmp_path):
+    """--no_ganFeat_loss: the reference's discriminator is built with getIntermFeat=False (one flattened Sequential per
+    scale, keys ``layer<i>.<n>.*``, models/Discriminator_NET.py:27-28); the saved D checkpoint carries the key list of the
+    REAL reference (golden d_keys) and loads back into a fresh trainer bit for bit."""
+    g = load_golden('tiny_flag_rec_no_ganfeat')
+    flags = json.loads(str(g['flags']))
+    model = build(flags, tmp=str(tmp_path))
+    with torch.no_grad():
+        for q in model.netD.parameters():      # not the seeded initial state a fresh build() would hold anyway
+            q.add_(0.25)
+    model.save('latest')
+    sd = torch.load(os.path.join(str(tmp_path), 't', 'latest_net_D.pth'), map_location='cpu')
+    assert list(sd.keys()) == [str(k) for k in g['d_keys']]
+    sg = torch.load(os.path.join(str(tmp_path), 't', 'latest_net_G.pth'), map_location='cpu')
+    assert list(sg.keys()) == [str(k) for k in g['g_keys']]
+    again = build(flags, tmp=str(tmp_path))
+    again.load_network(again.netD, 'D', 'latest')
+    for (ka, va), (kb, vb) in zip(model.netD.state_dict().items(), again.netD.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb), ka
+    # ... and into the oracle's torch.nn discriminator (strict)
+    from oracle import ref_cpu
+    o = ref_cpu.Mask2ImageModel(ref_cpu.Opt(**flags))
+    o.netD.load_state_dict(sd)
 
 
 def test_checkpoint_roundtrip_and_reference_keys(tmp_path):
