@@ -7,14 +7,14 @@ import os
 # name -> (type|'flag', default)
 BASE_FLAGS = [
     ('name', str, 'label2city'), ('gpu_ids', str, '0'), ('checkpoints_dir', str, './checkpoints'),
-    ('model', str, 'pix2pixHD_condImg'), ('norm', str, 'instance'), ('use_dropout', 'flag', False),
+    ('model', str, 'CVAE_imggen'), ('norm', str, 'instance'), ('use_dropout', 'flag', False),
     ('input_layout', 'flag', False), ('load_image', 'flag', False), ('load_instmap', 'flag', False),
     ('use_bbox', int, 0), ('batchSize', int, 1), ('loadSize', int, 1024), ('fineSize', int, 512),
     ('label_nc', int, 35), ('output_nc', int, 3), ('contextMargin', float, 3.0), ('prob_bg', float, 0.3),
     ('min_box_size', int, 32), ('max_box_size', int, 256), ('random_crop', int, 1),
     ('dataroot', str, './datasets/cityscape/'), ('dataloader', str, 'segmentation_dataset'),
     ('resize_or_crop', str, 'scale_width'), ('serial_batches', 'flag', False), ('no_flip', 'flag', False),
-    ('nThreads', int, 2), ('max_dataset_size', float, float('inf')), ('display_winsize', int, 512),
+    ('nThreads', int, 2), ('max_dataset_size', int, float('inf')), ('display_winsize', int, 512),
     ('tf_log', 'flag', False), ('netG', str, 'global'), ('ngf', int, 64), ('n_downsample_global', int, 4),
     ('n_blocks_global', int, 9), ('n_blocks_local', int, 3), ('n_local_enhancers', int, 1),
     ('niter_fix_global', int, 0), ('which_encoder', str, 'ctx'), ('use_output_gate', 'flag', False),
@@ -34,6 +34,12 @@ TRAIN_FLAGS = [
     ('no_ganFeat_loss', 'flag', False), ('no_vgg_loss', 'flag', False), ('no_lsgan', 'flag', False),
     ('pool_size', int, 0), ('no_imgCond', 'flag', False), ('mask_gan_input', 'flag', False),
     ('use_soft_mask', 'flag', False),
+]
+# options/mask2image_test_options.py:8-14 (inference / visualisation runs; --phase and --which_epoch re-declared there)
+TEST_FLAGS = [
+    ('ntest', int, float('inf')), ('results_dir', str, './checkpoints/'), ('aspect_ratio', float, 1.0),
+    ('phase', str, 'test'), ('which_epoch', str, 'latest'), ('how_many', int, 50),
+    ('cluster_path', str, 'features_clustered_010.npy'),
 ]
 # additions of this build (absent in the reference)
 BUILD_FLAGS = [('vgg_weights', str, ''), ('verbose', 'flag', False), ('color_noise', 'flag', False),
@@ -80,10 +86,21 @@ class MaskToImageTrainOptions(MaskToImageOptions):
     tables = [BASE_FLAGS, TRAIN_FLAGS, BUILD_FLAGS]
 
 
+class MaskToImageTestOptions(MaskToImageOptions):
+    """options/mask2image_test_options.py: the base flags + the test flags, ``isTrain = False``."""
+    isTrain = False
+    tables = [BASE_FLAGS, TEST_FLAGS, BUILD_FLAGS]
+
+
 def complete(opt):
     """dict / Namespace -> Namespace with every hot-path flag present (reference defaults)."""
     if isinstance(opt, dict):
         opt = argparse.Namespace(**opt)
+    if not hasattr(opt, 'model'):
+        # the reference PARSER's default is 'CVAE_imggen' (options/mask2image_base_options.py:18), a name its own
+        # create_model rejects (models/models.py:16-17): every shipped script passes --model.  A partial dict / Namespace
+        # handed to this function means the hot-path trainer.
+        opt.model = 'pix2pixHD_condImg'
     for table in (BASE_FLAGS, TRAIN_FLAGS, BUILD_FLAGS):
         for name, typ, default in table:
             if not hasattr(opt, name):
