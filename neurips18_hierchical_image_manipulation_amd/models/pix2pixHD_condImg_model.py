@@ -203,6 +203,10 @@ class Pix2PixHDModel_condImg(BaseModel):
         cond_image = ops.slice_channels(buf, n_label, n_cond)
         return input_label, inst_map, real_image, feat_map, cond_image
 
+    def forward_wrapper(self, data, infer=False):
+        """Batch dict -> ``forward`` (reference :188-196; train_mask2image.py:57 keeps the call commented out)."""
+        return self.forward(data['label'], data['inst'], data['image'], None, data['mask_in'], data['mask_out'], infer)
+
     def _d_split(self):
         """True when the discriminators get (condition, image) as an ``ops.CondImage`` pair instead of their concatenation:
         no mask on the input, no image pool (it stores concatenated tensors), a condition at all."""

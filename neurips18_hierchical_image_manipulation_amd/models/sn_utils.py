@@ -43,15 +43,18 @@ class _SNMixin(object):
 class SNConv2d(_SNMixin, Conv2d):
     """Conv2d whose effective weight is W / sigma(W) (reference :49-72)."""
 
-    def __init__(self, cin, cout, k, stride=1, padding=0, bias=True):
-        super().__init__(cin, cout, k, stride, padding, bias)
-        self._init_u(cout)
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True):
+        # argument order of the reference (:52-53 = nn.Conv2d's); dilated / grouped SN convolutions are nowhere on the path
+        if dilation != 1 or groups != 1:
+            raise NotImplementedError('SNConv2d: dilation / groups other than 1 are not on the HIP path')
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, bias)
+        self._init_u(out_channels)
 
     def effective_weight(self):
         return self.W_bar
 
-    def forward(self, x):
-        return ops.conv2d(x, self.W_bar, self.bias, self.stride, self.padding)
+    def forward(self, input):
+        return ops.conv2d(input, self.W_bar, self.bias, self.stride, self.padding)
 
 
 class SNLinear(_SNMixin, nn.Module):
@@ -66,9 +69,9 @@ class SNLinear(_SNMixin, nn.Module):
         self.bias = nn.Parameter((torch.rand(out_features) * 2 - 1) * bound) if bias else None
         self._init_u(out_features)
 
-    def forward(self, x):
-        lead = x.shape[:-1]
-        x4 = x.reshape(-1, self.in_features, 1, 1)
+    def forward(self, input):
+        lead = input.shape[:-1]
+        x4 = input.reshape(-1, self.in_features, 1, 1)
         wb = self.W_bar
         w4 = wb.view(self.out_features, self.in_features, 1, 1)
         w4._him_wkey = id(self.weight)

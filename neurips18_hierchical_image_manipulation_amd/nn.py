@@ -237,8 +237,19 @@ class ResnetBlock(nn.Module):
     """x + IN(conv3(refpad(ReLU(IN(conv3(refpad(x)))))))  (reference models/layer_util.py:333-378);
     parameters at ``conv_block.1`` and ``conv_block.5``."""
 
-    def __init__(self, dim):
+    def __init__(self, dim, padding_type='reflect', norm_layer=None, activation=None, use_dropout=False):
+        """Constructor arguments of the reference (:334-335); every call site of the hot path passes reflection padding,
+        the instance norm of ``get_norm_layer`` and ``nn.ReLU(True)`` (Pix2Pix_NET.py:80-83,129-131) -- the one block the
+        HIP executor builds.  Anything else fails here, loudly, instead of being computed as that block."""
         super().__init__()
+        if padding_type != 'reflect':
+            raise NotImplementedError('ResnetBlock: padding [%s] is not on the HIP path (reflect only)' % padding_type)
+        if use_dropout:
+            raise NotImplementedError('ResnetBlock: use_dropout is not on the HIP path')
+        if norm_layer is not None and not isinstance(norm_layer(dim), InstanceNorm2d):
+            raise NotImplementedError('ResnetBlock: norm_layer must be get_norm_layer("instance")')
+        if activation is not None and not isinstance(activation, (ReLU, nn.ReLU)):
+            raise NotImplementedError('ResnetBlock: activation must be ReLU')
         self.conv_block = nn.Sequential(ReflectionPad2d(1), Conv2d(dim, dim, 3), InstanceNorm2d(dim), ReLU(),
                                         ReflectionPad2d(1), Conv2d(dim, dim, 3), InstanceNorm2d(dim))
 

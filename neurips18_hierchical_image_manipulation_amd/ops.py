@@ -1468,6 +1468,22 @@ def get_masked_image(image, bbox, cls2fill=0.0):
     return mask, obj, ctx
 
 
+def tile_embedding(embedding, mask_in):
+    """(B,K) embedding, (B,1,H,W) mask -> (B,K,H,W) = embedding[b,k] * mask[b,0,y,x]  (``encode_global_embedding``,
+    models/pix2pixHD_condImgColor_model.py:147-160); him_tile_embed writes three channels per launch (the colour path's K)."""
+    _chk(embedding, mask_in)
+    B, K = embedding.shape
+    H, W = mask_in.shape[2], mask_in.shape[3]
+    if K % 3:
+        raise ValueError('tile_embedding: K = %d (the colour embedding has 3 channels per group)' % K)
+    out = torch.empty((B, K, H, W), dtype=torch.float32, device=embedding.device)
+    mask_in = mask_in.contiguous()
+    for k in range(0, K, 3):
+        emb = embedding[:, k:k + 3].contiguous()
+        lib.him_tile_embed(_p(emb), _p(mask_in), _p(out), B, K, k, H * W, _stream())
+    return out
+
+
 def masked_mean_color(image, obj_mask, noise=None):
     _chk(image, obj_mask, noise)
     B, _, H, W = image.shape

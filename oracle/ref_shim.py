@@ -30,6 +30,7 @@ def install():
     if _installed:
         return
     assert available(), 'reference checkout not present'
+    sys.dont_write_bytecode = True      # importing must not leave __pycache__ directories inside the reference tree
     sys.path[:0] = [REF, os.path.join(REF, 'models'), os.path.join(REF, 'options')]
     cs = types.ModuleType('cStringIO')
     cs.StringIO = io.BytesIO

@@ -298,6 +298,59 @@ def test_every_flag_of_the_reference_parsers_exists_with_its_default(which):
     assert all(getattr(opt, n) is True for n, sp in ref['options'].items() if sp['kind'] == 'flag')
 
 
+# construction helpers of the reference's network classes that no caller outside the class uses; the HIP executor builds
+# the same modules (same state-dict keys, test_state_dict_keys_match_oracle_for_every_generator) without them
+INTERNAL_HELPERS = {
+    'GlobalTwoStreamGenerator': {'forward_decoder', 'forward_embedder', 'forward_encoder', 'get_downsampler', 'get_embedder',
+                                 'get_input', 'get_output', 'get_upsampler'},
+    'MultiscaleDiscriminator': {'singleD_forward'}, 'ResnetBlock': {'build_conv_block'},
+    'GANLoss': {'get_target_tensor'}, 'VGGLoss': {'normalize_input'},
+}
+
+
+def test_python_surface_follows_the_reference_classes():
+    """tests/golden/api_surface.json = method names + positional parameter names of the REAL reference's classes
+    (make_golden_api.py, inspect).  Every method of the three model classes, and __init__ / forward / __call__ of the network
+    and loss classes, exists here with the reference's positional parameters in the reference's order (the build may append
+    optional ones); the only methods absent are the listed construction helpers."""
+    import importlib
+    import inspect
+    import json
+    with open(os.path.join(ROOT, 'tests', 'golden', 'api_surface.json')) as f:
+        ref = json.load(f)
+    assert len(ref) >= 13
+    for cls_name, spec in ref.items():
+        mod = importlib.import_module('neurips18_hierchical_image_manipulation_amd.' + spec['build_module'])
+        cls = getattr(mod, cls_name)
+        missing = set()
+        for meth, params in spec['methods'].items():
+            fn = getattr(cls, meth, None)
+            if fn is None or (meth == '__call__' and fn is torch.nn.Module.__call__):
+                if meth == '__call__' and fn is not None:
+                    continue        # nn.Module.__call__ -> forward
+                missing.add(meth)
+                continue
+            mine = list(inspect.signature(fn).parameters)
+            assert mine[:len(params)] == params, '%s.%s%s: here %s' % (cls_name, meth, params, mine)
+        assert missing == INTERNAL_HELPERS.get(cls_name, set()), (cls_name, missing)
+
+
+def test_reference_constructor_arguments_fail_loudly_when_off_the_path():
+    from neurips18_hierchical_image_manipulation_amd.models.layer_util import ResnetBlock, get_norm_layer
+    from neurips18_hierchical_image_manipulation_amd.models.sn_utils import SNConv2d
+    blk = ResnetBlock(8, 'reflect', get_norm_layer('instance'), torch.nn.ReLU(True), False)    # a reference call site's form
+    assert [k for k in blk.state_dict()] == ['conv_block.1.weight', 'conv_block.1.bias', 'conv_block.5.weight',
+                                             'conv_block.5.bias']
+    for bad in (dict(padding_type='zero'), dict(use_dropout=True), dict(norm_layer=torch.nn.BatchNorm2d),
+                dict(activation=torch.nn.Tanh())):
+        with pytest.raises(NotImplementedError):
+            ResnetBlock(8, **bad)
+    conv = SNConv2d(6, 10, 3, 1, 1, 1, 1, False)          # nn.Conv2d's order: ..., dilation, groups, bias
+    assert conv.bias is None and tuple(conv.weight.shape) == (10, 6, 3, 3) and tuple(conv.u.shape) == (1, 10)
+    with pytest.raises(NotImplementedError):
+        SNConv2d(6, 10, 3, 1, 1, 2)
+
+
 def test_create_model_without_gpu_fails_loudly():
     if torch.cuda.is_available():
         pytest.skip('GPU present')

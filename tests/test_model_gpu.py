@@ -685,6 +685,47 @@ def test_c4_colour_two_stream_full_width_vs_reference():
     _free_running_vs_envelope('c4_traj', 'c4')
 
 
+def test_reference_call_forms_of_the_model_objects():
+    """The positional call forms of the reference's model classes (tests/golden/api_surface.json):
+    ``forward_wrapper(data)`` = ``forward(label, inst, image, None, mask_in, mask_out)`` (:188-196); the colour model's
+    ``forward(..., mask_out, obj_mask, infer)`` (:252), ``inference(label, inst, image, mask_in, color_embed, obj_mask)``
+    (:315) and ``encode_global_embedding(mask_in, embedding)`` (:147-160)."""
+    from neurips18_hierchical_image_manipulation_amd import synth
+    g = load_golden('tiny_global')
+    model = build(json.loads(str(g['flags'])))
+    b = synth.make_batch(0, 0, 2, 32, 64)
+    la, _ = model.forward(b['label'], b['inst'], b['image'], None, b['mask_in'], b['mask_out'])
+    lb, fake = model.forward_wrapper(b, True)
+    assert fake is not None and tuple(fake.shape) == (2, 3, 32, 64)
+    for x, y, ref in zip(la, lb, g['losses'][0]):
+        assert torch.equal(x.detach(), y.detach())
+        assert abs(float(x.detach()) - float(ref)) <= 1e-4 * abs(float(ref))       # = the reference's step-0 losses
+
+    g = load_golden('tiny_color')
+    flags = json.loads(str(g['flags']))
+    model = build(flags)
+    b = synth.make_batch(0, 0, 2, 64, 64, flags['label_nc'], True)
+    la, _ = model.forward(b['label'], b['inst'], b['image'], None, b['mask_in'], b['mask_out'], b['obj_mask'], False)
+    lb, fake = model.forward_wrapper(b, True)
+    assert fake is not None
+    for x, y, ref in zip(la, lb, g['losses'][0]):
+        assert torch.equal(x.detach(), y.detach())
+        assert abs(float(x.detach()) - float(ref)) <= 1e-4 * abs(float(ref))
+    emb = model.get_color_embedding(model._dev(b['obj_mask']), model._dev(b['image']))
+    assert tuple(emb.shape) == (2, 3)
+    mask = model._dev(b['mask_in'])
+    tiled = model.encode_global_embedding(b['mask_in'], emb)
+    assert torch.equal(tiled, emb.view(2, 3, 1, 1) * mask)
+    assert model.encode_instwise_embedding(b['inst'], emb) is None
+    f_own = model.inference(b['label'], b['inst'], b['image'], b['mask_in'], None, b['obj_mask'])
+    f_given = model.inference(b['label'], b['inst'], b['image'], b['mask_in'], emb, b['obj_mask'])
+    assert torch.equal(f_own, f_given)
+    other = model.inference(b['label'], b['inst'], b['image'], b['mask_in'], -emb, b['obj_mask'])
+    assert not torch.equal(f_own, other)          # the given embedding is the one that is used
+    enc = model.encode_input(b['label'], b['inst'], b['image'], None, b['mask_in'], b['obj_mask'], None, True)
+    assert tuple(enc[4].shape) == (2, 6, 64, 64) and torch.equal(enc[4][:, 3:], tiled)
+
+
 def test_bench_launcher_spawns_the_ranks_it_is_asked_for():
     """`python bench.py --gpus 2` from a bare shell (no launcher, no RANK in the environment) must run TWO ranks and say
     so -- round 1's bench silently trained one.  On this one-GPU box the two ranks share the device over gloo
