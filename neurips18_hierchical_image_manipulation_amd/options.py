@@ -41,6 +41,38 @@ TEST_FLAGS = [
     ('phase', str, 'test'), ('which_epoch', str, 'latest'), ('how_many', int, 50),
     ('cluster_path', str, 'features_clustered_010.npy'),
 ]
+# box2mask (second hot path): options/box2mask_base_options.py:12-83, box2mask_train_options.py:8-36, box2mask_test_options.py:8-16
+BOX2MASK_BASE_FLAGS = [
+    ('add_dilated_layers', 'flag', False), ('batchSize', int, 64), ('checkpoints_dir', str, './checkpoints'),
+    ('cond_in', str, 'ctx'), ('contextMargin', float, 2.0), ('conv_dim', int, 64), ('conv_size', int, 4),
+    ('dataloader', str, 'cityscape'), ('dataroot', str, './datasets/cityscape/'), ('display_winsize', int, 512),
+    ('embed_dim', int, 1024), ('fineSize', int, 128), ('first_conv_size', int, 5), ('first_conv_stride', int, 1),
+    ('fusion_type', str, 'add'), ('gan_weight', float, 1.0), ('gpu_ids', str, '0'), ('label_nc', int, 36),
+    ('lambda_feat', float, 1.0), ('loadSize', int, None), ('load_image', int, 0), ('max_box_size', int, 64),
+    ('max_dataset_size', int, float('inf')), ('min_box_size', int, 32), ('model', str, 'AE_maskgen'),
+    ('nThreads', int, 2), ('n_blocks', int, 4), ('n_blocks_decode', int, 4), ('n_blocks_gt', int, 4),
+    ('n_blocks_masked', int, 4), ('name', str, 'box2mask'), ('ndf', int, 64), ('ngf', int, 64),
+    ('no_comb', 'flag', False), ('no_flip', 'flag', False), ('no_instance', 'flag', False),
+    ('norm_layer', str, 'batch'), ('num_layers', int, 6), ('num_layers_D', int, 4), ('num_resnetblocks', int, 1),
+    ('objReconLoss', str, 'bce'), ('output_nc', int, 36), ('prob_bg', float, 0.3), ('random_crop', int, 1),
+    ('rec_weight', float, 1.0), ('resize_or_crop', str, 'select_region'), ('serial_batches', 'flag', False),
+    ('skip_end', int, 3), ('skip_start', int, 1), ('tf_log', 'flag', False), ('use_bbox', int, 1),
+    ('use_dropout', 'flag', False), ('use_gan', 'flag', False), ('use_output_gate', 'flag', False),
+    ('use_resnetblock', int, 1), ('use_simpleRes', 'flag', False), ('which_epoch', str, 'latest'),
+    ('which_gan', str, 'patch'), ('which_stream', str, 'obj_context'), ('z_dim', int, 512),
+]
+BOX2MASK_TRAIN_FLAGS = [
+    ('beta1', float, 0.9), ('beta2', float, 0.999), ('continue_train', 'flag', False), ('debug', 'flag', False),
+    ('display_freq', int, 40), ('enc_lr', float, 1.0), ('load_pretrain', str, ''), ('lr', float, 0.0002),
+    ('lr_control', 'flag', False), ('mask_gan_input', 'flag', False), ('niter', int, 200), ('niter_decay', int, 0),
+    ('no_html', 'flag', False), ('num_checkpoint', int, 2), ('phase', str, 'train'), ('print_freq', int, 40),
+    ('save_epoch_freq', int, 10), ('save_latest_freq', int, 200), ('use_ganFeat_loss', 'flag', False),
+]
+BOX2MASK_TEST_FLAGS = [
+    ('aspect_ratio', float, 1.0), ('gendata_dir', str, 'gen_ae_512p'), ('gtdata_dir', str, 'gt_512p'),
+    ('how_many', int, 50), ('ntest', int, float('inf')), ('num_samples', int, 1), ('phase', str, 'test'),
+    ('results_dir', str, 'results/'),
+]
 # additions of this build (absent in the reference)
 BUILD_FLAGS = [('vgg_weights', str, ''), ('verbose', 'flag', False), ('color_noise', 'flag', False),
                ('compact_labels', 'flag', False),
@@ -90,6 +122,23 @@ class MaskToImageTestOptions(MaskToImageOptions):
     """options/mask2image_test_options.py: the base flags + the test flags, ``isTrain = False``."""
     isTrain = False
     tables = [BASE_FLAGS, TEST_FLAGS, BUILD_FLAGS]
+
+
+class BoxToMaskOptions(MaskToImageOptions):
+    """options/box2mask_base_options.py: the parser of train_box2mask.py / test_box2mask.py (same parse / opt.txt
+    behaviour as the mask2image parser)."""
+    isTrain = False
+    tables = [BOX2MASK_BASE_FLAGS]
+
+
+class BoxToMaskTrainOptions(BoxToMaskOptions):
+    isTrain = True
+    tables = [BOX2MASK_BASE_FLAGS, BOX2MASK_TRAIN_FLAGS]
+
+
+class BoxToMaskTestOptions(BoxToMaskOptions):
+    isTrain = False
+    tables = [BOX2MASK_BASE_FLAGS, BOX2MASK_TEST_FLAGS]
 
 
 def complete(opt):

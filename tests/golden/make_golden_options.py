@@ -43,8 +43,11 @@ if __name__ == '__main__':
     ref_shim.install()
     from options.mask2image_train_options import MaskToImageTrainOptions
     from options.mask2image_test_options import MaskToImageTestOptions
+    from options.box2mask_train_options import BoxToMaskTrainOptions
+    from options.box2mask_test_options import BoxToMaskTestOptions
     res = dict(note='flag names, kinds and defaults of the reference parsers (tests/golden/make_golden_options.py)',
-               train=table(MaskToImageTrainOptions), test=table(MaskToImageTestOptions))
+               train=table(MaskToImageTrainOptions), test=table(MaskToImageTestOptions),
+               box2mask_train=table(BoxToMaskTrainOptions), box2mask_test=table(BoxToMaskTestOptions))
     with open(os.path.join(HERE, 'option_defaults.json'), 'w') as f:
         json.dump(res, f, indent=1, sort_keys=True)
-    print('train: %d options, test: %d options' % (len(res['train']['options']), len(res['test']['options'])))
+    print({k: len(v['options']) for k, v in res.items() if k != 'note'})

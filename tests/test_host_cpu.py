@@ -261,16 +261,17 @@ def test_options_defaults_are_the_reference_defaults():
     assert c.n_blocks_global == 9 and c.isTrain
 
 
-@pytest.mark.parametrize('which', ['train', 'test'])
+@pytest.mark.parametrize('which', ['train', 'test', 'box2mask_train', 'box2mask_test'])
 def test_every_flag_of_the_reference_parsers_exists_with_its_default(which):
     """tests/golden/option_defaults.json = the live argparse tables of the REAL reference's MaskToImageTrainOptions /
-    MaskToImageTestOptions (make_golden_options.py): every flag must parse here under the same name, with the same kind
+    MaskToImageTestOptions / BoxToMaskTrainOptions / BoxToMaskTestOptions (make_golden_options.py): every flag must parse here under the same name, with the same kind
     (value type / store_true) and default; the only extra names are the build's documented additions."""
     import json
     from neurips18_hierchical_image_manipulation_amd import options
     with open(os.path.join(ROOT, 'tests', 'golden', 'option_defaults.json')) as f:
         ref = json.load(f)[which]
-    cls = options.MaskToImageTrainOptions if which == 'train' else options.MaskToImageTestOptions
+    cls = dict(train=options.MaskToImageTrainOptions, test=options.MaskToImageTestOptions,
+               box2mask_train=options.BoxToMaskTrainOptions, box2mask_test=options.BoxToMaskTestOptions)[which]
     o = cls()
     o.initialize()
     assert bool(o.isTrain) == ref['isTrain']
@@ -279,7 +280,7 @@ def test_every_flag_of_the_reference_parsers_exists_with_its_default(which):
         for name, typ, default in table:
             mine[name] = ('flag' if typ == 'flag' else typ.__name__, default)
     extra = set(mine) - set(ref['options'])
-    assert extra == {n for n, _, _ in options.BUILD_FLAGS}, extra
+    assert extra == ({n for n, _, _ in options.BUILD_FLAGS} if which in ('train', 'test') else set()), extra
     for name, spec in ref['options'].items():
         assert name in mine, 'reference flag --%s is missing' % name
         kind, default = mine[name]
@@ -291,7 +292,7 @@ def test_every_flag_of_the_reference_parsers_exists_with_its_default(which):
             assert kind == spec['kind'] or (kind, spec['kind']) == ('float', 'int'), (name, kind, spec['kind'])
     argv = []
     for name, spec in ref['options'].items():      # every reference flag parses on the command line
-        if spec['default'] != 'inf':               # (int('inf') fails in the reference's parser as well)
+        if spec['default'] not in ('inf', None):   # (int('inf') fails in the reference's parser as well)
             argv += ['--' + name] if spec['kind'] == 'flag' else ['--' + name, str(spec['default'])]
     opt = cls().parse(save=False, default_args=argv)
     assert opt.isTrain == ref['isTrain']
