@@ -180,6 +180,19 @@ def get_raw_transform_fn(normalize=True):
     return _device.ImageTransform(None, None, BICUBIC, normalize, True, False)
 
 
+class _Normalize(object):
+    """transforms.Normalize((0.5,)*3, (0.5,)*3) on a (3,H,W) tensor (host or device): (t - 0.5) / 0.5 per channel."""
+    mean = std = (0.5, 0.5, 0.5)
+
+    def __call__(self, tensor):
+        return (tensor - 0.5) / 0.5
+
+
+def normalize():
+    """Reference :323-324 (unused by its own loaders)."""
+    return _Normalize()
+
+
 def get_masked_image(image_tensor, bbox_tensor, cls2fill=0):
     """(mask, mask*image, (1-mask)*image + mask*cls2fill) for one (C,H,W) map and a (wmin,hmin,wmax,hmax) box
     (reference :342-357), on the device (ops.get_masked_image -> him_masked_image)."""

@@ -1,5 +1,7 @@
-"""File listing of a dataset split (reference data/image_folder.py:11-31)."""
+"""File listing of a dataset split (reference data/image_folder.py:11-31) and its generic folder dataset (:33-64)."""
 import os
+
+import torch.utils.data as data
 
 TGK_EXTENSIONS = ('.jpg', '.JPG', '.jpeg', '.JPEG', '.png', '.PNG', '.ppm', '.PPM', '.bmp', '.BMP', '.tiff', 'json')
 
@@ -16,3 +18,31 @@ def make_dataset(dir):
     for root, _, names in sorted(os.walk(dir)):
         found.extend(os.path.join(root, n) for n in names if is_target_file(n))
     return found
+
+
+def default_loader(path):
+    from PIL import Image
+    return Image.open(path).convert('RGB')
+
+
+class ImageFolder(data.Dataset):
+    """Every target file below ``root`` as one sample: ``transform(loader(path))`` [, path] (reference :37-64; none of the
+    reference's own loaders use it -- kept for user code that does).  ``transform`` may be the device stage returned by
+    ``base_dataset.get_raw_transform_fn``."""
+
+    def __init__(self, root, transform=None, return_paths=False, loader=default_loader):
+        imgs = make_dataset(root)
+        if len(imgs) == 0:
+            raise RuntimeError('Found 0 images in: ' + root + '\nSupported image extensions are: ' +
+                               ','.join(TGK_EXTENSIONS))
+        self.root, self.imgs, self.transform, self.return_paths, self.loader = root, imgs, transform, return_paths, loader
+
+    def __getitem__(self, index):
+        path = self.imgs[index]
+        img = self.loader(path)
+        if self.transform is not None:
+            img = self.transform(img)
+        return (img, path) if self.return_paths else img
+
+    def __len__(self):
+        return len(self.imgs)

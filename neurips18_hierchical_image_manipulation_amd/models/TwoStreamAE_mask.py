@@ -107,6 +107,7 @@ class TwoStreamAE_mask(BaseModel):
             return self._labels(comb_prob, obj_prob, label_map, gate)
         label = self._dev(label_map)
         loss_comb = ops.masked_nll(comb_prob, label, gate)
+        obj_recon_label = obj_prob.detach()          # reconstruct()'s 'obj_recon_label': the UNGATED probability (:280-283)
         if self.use_output_gate:
             obj_prob = ops.mul_mask(obj_prob, gate)
         obj_gt = self._dev(mask_obj_inst)
@@ -149,24 +150,132 @@ class TwoStreamAE_mask(BaseModel):
             if self.reducer_D is not None:
                 self.reducer_D.finish()
             self.optimizer_D.step()
+        # [comb_recon_label, obj_recon_label] as train_box2mask.py:70-71 reads them (the label map is an int64 arg-max map)
         return [loss_comb.detach(), loss_obj.detach(), 0, loss_G_GAN.detach(), loss_D.detach(), loss_feat.detach()], \
-               [None, obj_prob.detach()]
+               [self._comb_label(comb_prob.detach(), label, gate), obj_recon_label]
+
+    @staticmethod
+    def _comb_label(comb_prob, label, gate):
+        """arg-max over channels of postprocess_output(log-prob, mask, one-hot(gt)) for a BINARY mask, as an int64
+        (B,1,H,W) map like torch.max's indices (:276-277): the arg-max log-probability inside the box, the ground-truth
+        label outside (there the blended map IS the one-hot) -- without materialising the (B,label_nc,H,W) blend."""
+        with torch.no_grad():
+            return torch.where(gate >= 0.5, comb_prob.argmax(1, keepdim=True), label.long())
 
     def _labels(self, comb_prob, obj_prob, label_map, gate):
-        """reconstruct()'s outputs in eval mode (:270-296): arg-max label map inside the box, ground truth outside."""
-        with torch.no_grad():
-            nc = self.opt.label_nc
-            label = self._dev(label_map)
-            inside = comb_prob.argmax(1, keepdim=True).float()
-            # postprocess_output: prob*mask + (1-mask)*one_hot(gt); its arg-max is the gt label outside the box
-            comb = torch.where(gate >= 0.5, inside, label)
-            del nc
-        return {'comb_pred_label': comb, 'obj_pred_label': obj_prob.detach()}
+        """generate()'s outputs (:298-301): reconstruct() in eval mode."""
+        return {'comb_pred_label': self._comb_label(comb_prob, self._dev(label_map), gate),
+                'obj_pred_label': obj_prob.detach()}
 
     def generate(self, input_dict):
-        return self.forward(input_dict['label_map'], input_dict.get('mask_obj_in'), input_dict['mask_ctx_in'],
-                            input_dict.get('mask_obj_out'), input_dict['mask_out'], input_dict.get('mask_obj_inst'),
-                            input_dict['cls'], input_dict['mask_in'], eval_mode=True)
+        """Reference :298-301: reconstruct() in eval mode (running BatchNorm statistics; the generator's training /
+        eval mode is what it was afterwards)."""
+        out = self.reconstruct(input_dict, eval_mode=True)
+        return {'comb_pred_label': out['comb_recon_label'], 'obj_pred_label': out['obj_recon_label']}
+
+    # -- the reference's remaining public methods (evaluation / visualisation scripts and user code call them) ----------
+    def get_model(self, model_factory):
+        print(self.name())
+        return model_factory
+
+    def encode_input(self, label_map, mask_ctx_in, mask_out, mask_in, cls, infer=False):
+        """-> (one-hot label map, one-hot context map, mask_out, one-hot class (B,label_nc), the box mask in the object's
+        class channel), reference :127-152, each written by one kernel (him_onehot / him_class_mask write every channel:
+        no zero fill; the reference leaves its class one-hot uninitialised outside the hot entry, :139-140)."""
+        from .._cabi import lib
+        nc = self.opt.label_nc
+        label, ctx = self._dev(label_map), self._dev(mask_ctx_in)
+        B, _, H, W = label.shape
+        st = torch.cuda.current_stream().cuda_stream
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=self.device)  # noqa: E731
+        onehot_label, onehot_ctx, cls_onehot = new(B, nc, H, W), new(B, nc, H, W), new(B, nc)
+        cls_dev = cls.reshape(-1).to(self.device, torch.float32).contiguous()
+        lib.him_onehot(label.data_ptr(), onehot_label.data_ptr(), B, nc, nc, 0, H * W, st)
+        lib.him_onehot(ctx.data_ptr(), onehot_ctx.data_ptr(), B, nc, nc, 0, H * W, st)
+        lib.him_onehot(cls_dev.data_ptr(), cls_onehot.data_ptr(), B, nc, nc, 0, 1, st)
+        if mask_in is None:
+            obj_cond = torch.zeros((B, nc, H, W), dtype=torch.float32, device=self.device)
+        else:
+            obj_cond = new(B, nc, H, W)
+            lib.him_class_mask(self._dev(mask_in).data_ptr(), cls_dev.data_ptr(), obj_cond.data_ptr(), B, nc, nc, 0, H * W, st)
+        return onehot_label, onehot_ctx, self._dev(mask_out), cls_onehot, obj_cond
+
+    def construct_input_cond(self, obj_cond, ctx_cond):
+        """Reference :353-360."""
+        if self.opt.cond_in == 'obj':
+            return obj_cond
+        if self.opt.cond_in == 'ctx':
+            return ctx_cond
+        return ops.cat_channels([obj_cond, ctx_cond])
+
+    def discriminate(self, input, cond):
+        """Reference :154-159 ('patch_multiscale': the condition is concatenated behind the mask)."""
+        return self.netD(ops.cat_channels([input, cond]))
+
+    def mask_variable(self, input, mask):
+        """input * mask.repeat(1, C, 1, 1) (reference :161-165)."""
+        if input.dim() != mask.dim():
+            mask = mask.unsqueeze(1)
+        return ops.mul_mask(input, mask.contiguous())
+
+    def postprocess_output(self, prob_map, gt_mask, gt_one_hot, use_blending=False):
+        """prob_map * gt_mask + (1 - gt_mask) * gt_one_hot (reference :363-371), one kernel."""
+        return ops.blend(gt_one_hot, prob_map, self._dev(gt_mask))
+
+    def reconstruct(self, input_dict, eval_mode=False):
+        """Reference :257-296: one generator pass WITHOUT a training step; ``eval_mode`` runs it on the running BatchNorm
+        statistics (and without a tape), otherwise in training mode with the tape -- the generator's mode is restored."""
+        label_map, cls = input_dict['label_map'], input_dict['cls']
+        was_training = self.netG.training
+        self.netG.train(not eval_mode)
+        try:
+            gt_one_hot, input_ctx, gt_mask, _, input_obj_cond = self.encode_input(
+                label_map, input_dict['mask_ctx_in'], input_dict['mask_out'], input_dict['mask_in'], cls)
+            cond = self.construct_input_cond(input_obj_cond, input_ctx)
+            with torch.set_grad_enabled(not eval_mode and torch.is_grad_enabled()):
+                _, comb_prob, _, obj_prob = self.netG(cond)
+                comb_onehot = self.postprocess_output(comb_prob, gt_mask, gt_one_hot)
+            comb_label = comb_onehot.detach().argmax(1, keepdim=True)
+        finally:
+            self.netG.train(was_training)
+        out = {'comb_recon_label': comb_label, 'obj_recon_label': obj_prob}
+        if not eval_mode:
+            out.update({'label_map': self._dev(label_map), 'input_mask': input_ctx, 'comb_gt_mask': gt_mask,
+                        'obj_gt_mask': self._dev(input_dict['mask_obj_inst']), 'comb_recon_prob': comb_prob,
+                        'obj_recon_prob': obj_prob, 'input_obj_cond': input_obj_cond})
+        return out
+
+    def evaluate(self, input_dict, target_size=None):
+        """Reference :303-348 for the first sample of the batch: the label map with the predicted object pasted in (or, for
+        the background class ``label_nc - 1``, the arg-max context map inside the box).  ``target_size`` (bilinear resize
+        of the probabilities to the original resolution) is the visualisation scripts' path and not built."""
+        if target_size is not None:
+            raise NotImplementedError('TwoStreamAE_mask.evaluate(target_size=...): arbitrary-size bilinear resampling is '
+                                      'not on the HIP path')
+        first = lambda k: input_dict[k][0].unsqueeze(0)  # noqa: E731
+        label_map, cls = first('label_map'), first('cls')
+        was_training = self.netG.training
+        self.netG.train(False)
+        try:
+            with torch.no_grad():
+                gt_one_hot, input_ctx, gt_mask, _, input_obj_cond = self.encode_input(
+                    label_map, first('mask_ctx_in'), first('mask_out'), first('mask_in'), cls)
+                _, comb_prob, _, obj_prob = self.netG(self.construct_input_cond(input_obj_cond, input_ctx))
+                if self.use_output_gate:
+                    obj_prob = self.mask_variable(obj_prob, gt_mask)
+                cls_id = int(cls.reshape(-1)[0])
+                if cls_id == self.opt.label_nc - 1:
+                    return self.postprocess_output(comb_prob, gt_mask, gt_one_hot).argmax(1, keepdim=True)
+                obj_mask = (obj_prob > 0.5).float()
+                return (1 - obj_mask) * self._dev(label_map) + obj_mask * float(cls_id)
+        finally:
+            self.netG.train(was_training)
+
+    def delete_model(self, which_epoch):
+        """Reference :366-369 (train_box2mask.py:142 rotates checkpoints with it)."""
+        self.delete_network('G', which_epoch, self.gpu_ids)
+        if self.use_gan:
+            self.delete_network('D', which_epoch, self.gpu_ids)
 
     # -- checkpoints: the reference's per-module dict (base_model.py:52-66) ------------------------------------------
     @property

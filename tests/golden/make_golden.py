@@ -244,6 +244,59 @@ def golden_box2mask_traj(steps=6):
                         losses=rl.astype(np.float32), loss_names=np.array(ref_mask_cpu.LOSS_NAMES))
 
 
+def golden_box2mask_eval():
+    """The evaluation-side methods of the REAL reference's TwoStreamAE_mask on the box2mask_traj configuration (64x64,
+    batch 2, ndf 16, seeded weights 21 / 22, batch 0), in this order: generate() (eval mode, fresh running statistics),
+    reconstruct(eval_mode=False) (training mode: batch statistics, running statistics move), evaluate() (first sample,
+    eval mode on the moved statistics), then ONE training forward() for the [comb_recon_label, obj_recon_label] it returns.
+    Per label map: the int64 map, the top-1 value of the blended map and its margin over the runner-up (a comparison may
+    skip pixels whose margin is inside fp32 noise)."""
+    fl = dict(ndf=16, label_nc=35, num_layers_D=3, gan_weight=0.1, lr=0.0002, beta1=0.5, beta2=0.999)
+    ref = ref_shim.box2mask_trainer(**fl)
+    ref.netG.load_state_dict(synth.init_state_dict(ref.netG.state_dict(), 21))
+    ref.netD.load_state_dict(synth.init_state_dict(ref.netD.state_dict(), 22))
+    b = synth.make_box2mask_batch(0, 0, 2, 64, 64, 35)
+    d = {'label_map': b['label'], 'mask_obj_in': None, 'mask_ctx_in': b['mask_ctx_in'], 'mask_obj_out': None,
+         'mask_out': b['mask_out'], 'mask_obj_inst': b['mask_obj_inst'], 'cls': b['cls'], 'mask_in': b['mask_in']}
+    out = {}
+
+    def margins(tag, prob_map, gt_mask, gt_one_hot):
+        blended = ref.postprocess_output(prob_map.detach(), gt_mask, gt_one_hot)
+        top = blended.topk(2, dim=1).values
+        out[tag + '_top1'] = top[:, :1].numpy()
+        out[tag + '_margin'] = (top[:, :1] - top[:, 1:2]).numpy()
+
+    with torch.no_grad():
+        gt_one_hot, input_ctx, gt_mask, cls_onehot, obj_cond = ref.encode_input(b['label'], b['mask_ctx_in'], b['mask_out'],
+                                                                            b['mask_in'], b['cls'])
+        out.update(enc_onehot_label_sum=gt_one_hot.sum((2, 3)).numpy(), enc_ctx_sum=input_ctx.sum((2, 3)).numpy(),
+                   enc_obj_cond_sum=obj_cond.sum((2, 3)).numpy(), enc_cls_argmax=cls_onehot.argmax(1).numpy())
+        cond = ref.construct_input_cond(obj_cond, input_ctx)
+        ref.netG.set_mode(eval_mode=True)
+        _, p_eval, _, _ = ref.netG.forward(cond, cls_onehot)
+        ref.netG.set_mode(eval_mode=False)
+        margins('generate', p_eval, gt_mask, gt_one_hot)
+        g = ref.generate(d)
+        assert g['comb_pred_label'].dtype == torch.int64
+        out.update(generate_comb=g['comb_pred_label'].numpy(), generate_obj=g['obj_pred_label'].numpy())
+        r = ref.reconstruct(d, eval_mode=False)
+        margins('reconstruct', r['comb_recon_prob'], gt_mask, gt_one_hot)
+        out.update(reconstruct_comb=r['comb_recon_label'].numpy(), reconstruct_obj=r['obj_recon_label'].numpy(),
+                   reconstruct_keys=np.array(sorted(r.keys())),
+                   running_mean_after=ref.netG.state_dict()['conv_encoder_modules.1.running_mean'].clone().numpy())   # (a copy:
+                   # .numpy() aliases the live buffer, which the training step below moves again)
+        e = ref.evaluate(d)
+        out.update(evaluate_label=e.numpy(), evaluate_cls=b['cls'].numpy())
+    with torch.autograd.graph.allow_mutation_on_saved_tensors():
+        losses, recon = ref.forward(b['label'], None, b['mask_ctx_in'], None, b['mask_out'], b['mask_obj_inst'], b['cls'],
+                                    b['mask_in'], eval_mode=False)
+    out.update(forward_comb=recon[0].detach().numpy(), forward_obj=recon[1].detach().numpy(),
+               forward_losses=np.array([float(x.detach().reshape(-1)[0]) if torch.is_tensor(x) else float(x) for x in losses]))
+    np.savez_compressed(os.path.join(HERE, 'box2mask_eval.npz'), flags=json.dumps(fl), **out)
+    print('box2mask_eval: generate / reconstruct / evaluate / forward outputs of the reference stored; min margins %s' % (
+        {k: float(v.min()) for k, v in out.items() if k.endswith('_margin')}))
+
+
 def golden_data_ops():
     """get_masked_image of the REAL reference (data/base_dataset.py:342-357), sample by sample, for boxes that are
     interior, clipped by the border, empty (hmax == hmin) and full-image; cls2fill 0 and 34."""
@@ -399,6 +452,8 @@ if __name__ == '__main__':
     if 'box2mask' in what:
         golden_box2mask_net()
         golden_box2mask_traj()
+    if 'box2mask_eval' in what:
+        golden_box2mask_eval()
     if 'data_ops' in what:
         golden_data_ops()
     if 'box2mask_ade' in what:

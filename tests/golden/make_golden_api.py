@@ -50,6 +50,9 @@ if __name__ == '__main__':
     for ref, mine in CLASSES.items():
         mod, cls = ref.split(':')
         res[cls] = dict(build_module=mine, methods=surface(getattr(importlib.import_module(mod), cls)))
+    # box2mask trainer: Python-2 source, imported through the shim's in-memory substitutions
+    trainer = type(ref_shim.box2mask_trainer())
+    res[trainer.__name__] = dict(build_module='models.TwoStreamAE_mask', methods=surface(trainer))
     with open(os.path.join(HERE, 'api_surface.json'), 'w') as f:
         json.dump(res, f, indent=1, sort_keys=True)
     print({k: len(v['methods']) for k, v in res.items()})
