@@ -386,3 +386,12 @@ def test_box2mask_evaluation_methods_match_reference_golden():
     np.testing.assert_allclose(got, g['forward_losses'], rtol=2e-5)
     d_out = model.discriminate(torch.from_numpy(g['forward_obj']).cuda(), cond)
     assert len(d_out) == 2 and len(d_out[0]) == fl['num_layers_D'] + 2
+    # checkpoint rotation of train_box2mask.py:138-142: save(epoch) ... delete_model(epoch - num_checkpoint * save_epoch_freq)
+    import os
+    model.save(7)
+    files = [os.path.join('/tmp/him_b2m', 't', '7_net_%s.pth' % k) for k in 'GD']
+    assert all(os.path.isfile(f) for f in files), files
+    model.delete_model(7)
+    assert not any(os.path.isfile(f) for f in files)
+    model.update_learning_rate(epoch=1, data_size=100)          # inside --niter: the rate stays
+    assert model.optimizer.param_groups[0]['lr'] == fl['lr']

@@ -590,6 +590,47 @@ def test_backward_G_backward_D_equal_optimize_parameters():
         assert torch.equal(p, q)
 
 
+def test_reference_training_loop_verbatim():
+    """The drop-in of INTEGRATION.md A: the body of train_mask2image.py:58-86 with nothing but the model object swapped --
+    ``model(label=..., ...)`` through ``__call__``, ``torch.mean`` over the returned losses, the two loss sums, and the
+    caller's OWN ``zero_grad / backward / step`` on ``model.module.optimizer_G / optimizer_D`` (plain autograd, not
+    backward_G / backward_D).  Three steps: losses against the REAL reference's trajectory, and the parameters against a
+    second model driven by optimize_parameters()."""
+    from neurips18_hierchical_image_manipulation_amd import synth
+    g = load_golden('tiny_global')
+    flags = json.loads(str(g['flags']))
+    model, other = build(flags), build(flags)
+    assert model.module is model
+    ref = g['losses'].astype(np.float64)
+    for step in range(3):
+        data = synth.make_batch(step, 0, int(g['B']), int(g['H']), int(g['W']))
+        losses, generated = model(label=data['label'], inst=data['inst'], image=data['image'], feat=None,
+                                  mask_in=data['mask_in'], mask_out=data['mask_out'], infer=(step == 0))
+        assert (generated is not None) == (step == 0)
+        losses = [torch.mean(x) if not isinstance(x, int) else x for x in losses]
+        loss_dict = dict(zip(model.module.loss_names, losses))
+        loss_D = (loss_dict['D_fake'] + loss_dict['D_real']) * 0.5
+        loss_G = loss_dict['G_GAN'] + loss_dict['G_GAN_Feat'] + loss_dict['G_VGG']
+        model.module.optimizer_G.zero_grad()
+        loss_G.backward()
+        model.module.optimizer_G.step()
+        model.module.optimizer_D.zero_grad()
+        loss_D.backward()
+        model.module.optimizer_D.step()
+        got = np.array([float(loss_dict[k].detach()) for k in NAMES])
+        rel = np.abs(got - ref[step]) / np.maximum(np.abs(ref[step]), 1e-12)
+        assert rel.max() < (1e-4 if step == 0 else 5e-3), (step, rel)
+        lo = other.optimize_parameters(data)
+        for k in NAMES:
+            assert abs(float(lo[k]) - float(loss_dict[k].detach())) <= 1e-5 * abs(float(lo[k])), (step, k)
+    model.sync()
+    other.sync()
+    for (n, p), q in zip(model.netG.named_parameters(), other.netG.parameters()):
+        assert_close('G/' + n, p, q, rtol=1e-4)
+    for (n, p), q in zip(model.netD.named_parameters(), other.netD.parameters()):
+        assert_close('D/' + n, p, q, rtol=1e-4)
+
+
 def _run_steps(flags, B, H, W, steps, **sched):
     from neurips18_hierchical_image_manipulation_amd import synth, config
     with config.schedule(**sched):
