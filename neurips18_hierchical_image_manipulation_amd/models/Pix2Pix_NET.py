@@ -99,6 +99,10 @@ class GlobalTwoStreamGenerator(nn.Module):
         if feat_fusion != 'early_add':
             raise NotImplementedError('feat_fusion [%s]: only early_add (the shipped recipe) is on the HIP path'
                                       % feat_fusion)
+        if use_skip and 'ctx' not in which_stream:
+            # the skips are the CONTEXT encoder's features (reference :232-241); with --which_encoder label the reference
+            # builds a decoder with doubled inputs and fails inside it at the first forward (:225)
+            raise NotImplementedError('--use_skip needs the context stream (--which_encoder ctx | ctx_label)')
         self.nd, self.use_skip, self.which_stream = n_downsampling, use_skip, which_stream
         self.use_output_gate, self.output_nc = use_output_gate, output_nc
         self.feat_dim = ngf * 2 ** n_downsampling

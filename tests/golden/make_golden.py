@@ -423,6 +423,17 @@ FLAG_VARIANTS = {'tiny_flag_lambda_rec': dict(TINY2, lambda_rec=5.0),
                  'tiny_flag_soft_mask': dict(TINY2, use_soft_mask=True, mask_gan_input=True),
                  'tiny_flag_rec_no_ganfeat': dict(TINY2, lambda_rec=2.0, no_ganFeat_loss=True),
                  'tiny_flag_no_vgg_no_imgcond': dict(TINY2, no_vgg_loss=True, no_imgCond=True)}
+# encoder choices of the two-stream generator (--which_encoder ctx | label | ctx_label, models/Pix2Pix_NET.py:126-136;
+# 'ctx' is the parser's default and feeds the discriminator the IMAGE ONLY, pix2pixHD_condImg_model.py:70-71,179-180),
+# with and without --use_skip / --use_output_gate; 'label' + --use_skip fails inside the reference's own decoder
+TINY_TWO3 = dict(model='pix2pixHD_condImg', netG='global_twostream', ngf=8, ndf=8, n_downsample_global=3, n_blocks_global=2,
+                 num_D=2, n_layers_D=3, label_nc=35, no_instance=True)
+FLAG_VARIANTS.update({
+    'tiny_two_ctx': dict(TINY_TWO3, which_encoder='ctx'),
+    'tiny_two_ctx_gate_skip': dict(TINY_TWO3, which_encoder='ctx', use_skip=True, use_output_gate=True, no_imgCond=True),
+    'tiny_two_ctxlabel_plain': dict(TINY_TWO3, which_encoder='ctx_label'),
+    'tiny_two_label': dict(TINY_TWO3, which_encoder='label'),
+    'tiny_two_label_gate': dict(TINY_TWO3, which_encoder='label', use_output_gate=True, mask_gan_input=True)})
 C1 = dict(model='pix2pixHD_condImg', netG='global', ngf=64, ndf=64, n_downsample_global=4, n_blocks_global=9,
           num_D=1, n_layers_D=3, label_nc=35, no_instance=True)
 C2 = dict(C1, num_D=3)
@@ -444,7 +455,7 @@ if __name__ == '__main__':
         trajectory('tiny_color', TINY_COLOR, 2, 64, 64, 5, color=True)
     if 'flags' in what:
         for tag, fl in FLAG_VARIANTS.items():
-            trajectory(tag, fl, 2, 32, 64, 5, save_keys=True)
+            trajectory(tag, fl, 2, 64 if fl['netG'] == 'global_twostream' else 32, 64, 5, save_keys=True)
     if 'c1' in what:
         trajectory('c1_traj', C1, 1, 128, 256, 20)
     if 'c2' in what:

@@ -187,7 +187,8 @@ def test_state_dict_keys_match_oracle_for_every_generator():
         assert [tuple(v.shape) for v in sa.values()] == [tuple(v.shape) for v in sb.values()]
 
 
-FLAG_GOLDENS = ('tiny_flag_lambda_rec', 'tiny_flag_soft_mask', 'tiny_flag_rec_no_ganfeat', 'tiny_flag_no_vgg_no_imgcond')
+FLAG_GOLDENS = ('tiny_flag_lambda_rec', 'tiny_flag_soft_mask', 'tiny_flag_rec_no_ganfeat', 'tiny_flag_no_vgg_no_imgcond',
+                'tiny_two_ctx', 'tiny_two_ctx_gate_skip', 'tiny_two_ctxlabel_plain', 'tiny_two_label', 'tiny_two_label_gate')
 
 
 @pytest.mark.parametrize('tag', FLAG_GOLDENS)
@@ -210,9 +211,16 @@ def test_checkpoint_keys_follow_the_reference_for_every_flag_set(tag):
     assert list(om.netG.state_dict().keys()) == g_keys and list(om.netD.state_dict().keys()) == d_keys
     nc = flags['label_nc']
     d_in = nc + 3 + (0 if flags.get('no_imgCond') else 3)
+    if flags['netG'] == 'global_twostream':
+        if flags['which_encoder'] == 'ctx':
+            d_in = 3        # the discriminator sees the image only (pix2pixHD_condImg_model.py:70-71)
+        netG = P.GlobalTwoStreamGenerator(nc, 3, flags['ngf'], flags['n_downsample_global'], flags['n_blocks_global'],
+                                          use_skip=bool(flags.get('use_skip')), which_stream=flags['which_encoder'],
+                                          use_output_gate=bool(flags.get('use_output_gate')))
+    else:
+        netG = P.GlobalGenerator(nc + (0 if flags.get('no_imgCond') else 3), 3, flags['ngf'], flags['n_downsample_global'],
+                                 flags['n_blocks_global'])
     netD = MultiscaleDiscriminator(d_in, flags['ndf'], flags['n_layers_D'], 'instance', False, flags['num_D'], not flat)
-    netG = P.GlobalGenerator(nc + (0 if flags.get('no_imgCond') else 3), 3, flags['ngf'], flags['n_downsample_global'],
-                             flags['n_blocks_global'])
     assert list(netG.state_dict().keys()) == g_keys
     sd = netD.state_dict()
     assert list(sd.keys()) == d_keys
@@ -350,6 +358,9 @@ def test_reference_constructor_arguments_fail_loudly_when_off_the_path():
     assert conv.bias is None and tuple(conv.weight.shape) == (10, 6, 3, 3) and tuple(conv.u.shape) == (1, 10)
     with pytest.raises(NotImplementedError):
         SNConv2d(6, 10, 3, 1, 1, 2)
+    from neurips18_hierchical_image_manipulation_amd.models.Pix2Pix_NET import GlobalTwoStreamGenerator
+    with pytest.raises(NotImplementedError, match='use_skip'):     # the reference fails inside its decoder here (:225)
+        GlobalTwoStreamGenerator(35, 3, 8, 3, 2, use_skip=True, which_stream='label')
 
 
 def test_create_model_without_gpu_fails_loudly():

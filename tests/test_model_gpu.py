@@ -75,12 +75,18 @@ def test_tiny_global_forward_tensors_match_reference():
                                  # loss / input flags (options/mask2image_train_options.py:39-46), goldens from the REAL
                                  # reference run with those flags (make_golden.py flags)
                                  'tiny_flag_lambda_rec', 'tiny_flag_soft_mask', 'tiny_flag_rec_no_ganfeat',
-                                 'tiny_flag_no_vgg_no_imgcond'])
+                                 'tiny_flag_no_vgg_no_imgcond',
+                                 # --which_encoder ctx (image-only discriminator input) | label | ctx_label, +- skip / gate
+                                 'tiny_two_ctx', 'tiny_two_ctx_gate_skip', 'tiny_two_ctxlabel_plain', 'tiny_two_label',
+                                 'tiny_two_label_gate'])
 def test_tiny_trajectories_match_reference(tag):
     rel, _, _, _ = run_traj(tag)
     assert rel[0].max() < 1e-4, 'step-0 losses: %s' % rel[0]
-    # the 32x64 toy nets normalise 2x3-pixel maps, which amplifies rounding; the 1e-3 bar is for the real sizes
-    assert rel[:5].max() < 5e-3, 'first steps: %s' % rel[:5].max(axis=1)
+    # the 32x64 toy nets normalise 2x3-pixel maps, which amplifies rounding; the 1e-3 bar is for the real sizes.  The
+    # two-stream variants WITHOUT the output gate repaint the whole image from 8x8 latent planes and leave the rounding
+    # regime two steps earlier (recorded: 3.9e-4 at step 1, 5.5e-3 at step 3); their per-step bar is
+    # test_two_stream_encoder_variants_teacher_forced
+    assert rel[:5].max() < (2e-2 if tag.startswith('tiny_two_') else 5e-3), 'first steps: %s' % rel[:5].max(axis=1)
     assert np.isfinite(rel).all()
 
 
@@ -957,6 +963,15 @@ def test_loss_flag_variants_teacher_forced(extra):
     # these runs pin the flag plumbing (which terms enter which loss), not kernel numerics: a mis-routed term is an O(1)
     # error; one LeakyReLU / L1-sign decision flipping moves the toy nets' gradients by up to ~1e-3
     _teacher_forced(tag, 3, golden=dict(flags=dict(TINY, **extra), B=2, H=32, W=64), plumbing_tol=5e-3)
+
+
+@pytest.mark.parametrize('tag', ['tiny_two_ctx', 'tiny_two_ctx_gate_skip', 'tiny_two_ctxlabel_plain', 'tiny_two_label',
+                                 'tiny_two_label_gate'])
+def test_two_stream_encoder_variants_teacher_forced(tag):
+    """--which_encoder ctx (the parser default: the discriminator sees the image only) | label | ctx_label, with and without
+    --use_skip / --use_output_gate, flag sets whose goldens come from the REAL reference: 3 steps, each from the oracle's
+    state -- losses at 5e-6, every gradient tensor against the fp32 oracle's, the Adam arithmetic."""
+    _teacher_forced(tag, 3, plumbing_tol=5e-3)
 
 
 def test_update_learning_rate_changes_the_next_adam_step():
