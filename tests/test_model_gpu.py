@@ -970,8 +970,11 @@ def test_loss_flag_variants_teacher_forced(extra):
 def test_two_stream_encoder_variants_teacher_forced(tag):
     """--which_encoder ctx (the parser default: the discriminator sees the image only) | label | ctx_label, with and without
     --use_skip / --use_output_gate, flag sets whose goldens come from the REAL reference: 3 steps, each from the oracle's
-    state -- losses at 5e-6, every gradient tensor against the fp32 oracle's, the Adam arithmetic."""
-    _teacher_forced(tag, 3, plumbing_tol=5e-3)
+    state -- losses at 5e-6 (recorded: <= 6e-7), every gradient tensor against the fp32 oracle's, the Adam arithmetic.
+    Gradient bound: the gated variants sit at 4e-6 / 4e-4; WITHOUT the output gate the whole image (not the box) enters the
+    L1 / VGG terms of an 8x8-latent toy net and sign / ReLU-gate flips reach 1.4e-3 (ctx), 1.8e-3 (ctx_label), 7.2e-3
+    (label) of a tensor's norm in one of the three steps -- a mis-routed stream or loss term is an O(1) error."""
+    _teacher_forced(tag, 3, plumbing_tol=5e-3 if 'gate' in tag else 2e-2)
 
 
 def test_update_learning_rate_changes_the_next_adam_step():
