@@ -182,7 +182,10 @@ def test_loader_batch_drives_the_trainer(tmp_path):
     fx.write_dataset(root, 'city')
     opt = _opt(root, 'city', 64, ['--contextMargin', '3.0', '--min_box_size', '16', '--max_box_size', '96',
                                   '--ngf', '8', '--ndf', '8', '--n_downsample_global', '2', '--n_blocks_global', '2',
-                                  '--num_D', '2', '--no_vgg_loss', '--checkpoints_dir', str(tmp_path / 'ck')])
+                                  '--num_D', '2', '--no_vgg_loss', '--checkpoints_dir', str(tmp_path / 'ck'),
+                                  # as every shipped script does: the parser's own default ('CVAE_imggen') is a name
+                                  # create_model rejects, here as upstream
+                                  '--model', 'pix2pixHD_condImg'])
     model = create_model(opt)
     steps = 0
     for epoch in range(2):
