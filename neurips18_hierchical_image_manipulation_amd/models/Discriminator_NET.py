@@ -3,7 +3,6 @@
 its discriminator with ``getIntermFeat = not opt.no_ganFeat_loss``, ``pix2pixHD_condImg_model.py:74-75``)."""
 import os
 import re
-from collections import OrderedDict
 
 import torch
 import torch.nn as nn
