@@ -28,21 +28,18 @@ def default_loader(path):
 class ImageFolder(data.Dataset):
     """Every target file below ``root`` as one sample: ``transform(loader(path))`` [, path] (reference :37-64; none of the
     reference's own loaders use it -- kept for user code that does).  ``transform`` may be the device stage returned by
-    ``base_dataset.get_raw_transform_fn``."""
+    ``base_dataset.get_raw_transform_fn``.  Public attributes as upstream: root, imgs, transform, return_paths, loader."""
 
     def __init__(self, root, transform=None, return_paths=False, loader=default_loader):
-        imgs = make_dataset(root)
-        if len(imgs) == 0:
-            raise RuntimeError('Found 0 images in: ' + root + '\nSupported image extensions are: ' +
-                               ','.join(TGK_EXTENSIONS))
-        self.root, self.imgs, self.transform, self.return_paths, self.loader = root, imgs, transform, return_paths, loader
-
-    def __getitem__(self, index):
-        path = self.imgs[index]
-        img = self.loader(path)
-        if self.transform is not None:
-            img = self.transform(img)
-        return (img, path) if self.return_paths else img
+        self.root, self.transform, self.return_paths, self.loader = root, transform, return_paths, loader
+        self.imgs = make_dataset(root)
+        if not self.imgs:
+            raise RuntimeError('Found 0 images in: %s\nSupported image extensions are: %s' % (root, ','.join(TGK_EXTENSIONS)))
 
     def __len__(self):
         return len(self.imgs)
+
+    def __getitem__(self, index):
+        sample = self.loader(self.imgs[index])
+        sample = sample if self.transform is None else self.transform(sample)
+        return (sample, self.imgs[index]) if self.return_paths else sample
