@@ -48,6 +48,20 @@ def _keys_from_flat(module, state_dict, prefix, local_metadata, strict, missing_
             state_dict['%sscale%s_layer%d.%d.%s' % (prefix, m.group(1), j, n - first[j], m.group(3))] = state_dict.pop(k)
 
 
+def lr_control(loss_G, loss_D_real, loss_D_fake, gan_margin=0.3):
+    """The reference's host-side gate (:190-211): -> (g_lr, d_lr) in {0.0, 1.0}.  D rests while either of its losses is below
+    the margin, G rests while either is above 1 - margin, never both.  Reads the three scalars back (one sync); the box2mask
+    trainer evaluates the same predicate on the device instead (``ops.lr_control`` / ``him_lr_control``)."""
+    real, fake = float(loss_D_real.detach().reshape(-1)[0]), float(loss_D_fake.detach().reshape(-1)[0])
+    update_d = not (real < gan_margin or fake < gan_margin)
+    update_g = not (real > 1 - gan_margin or fake > 1 - gan_margin)
+    if not (update_d or update_g):
+        update_d = update_g = True
+    what = 'Update Both' if update_g and update_d else ('Froze Discriminator' if update_g else 'Froze Generator')
+    print('%s\t[G=%.3f],[DR=%.3f],[DF=%.3f]' % (what, float(loss_G.detach().reshape(-1)[0]), real, fake))
+    return float(update_g), float(update_d)
+
+
 class MultiscaleDiscriminator(nn.Module):
     def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer='instance', use_sigmoid=False, num_D=3,
                  getIntermFeat=True, spectral_norm=False):

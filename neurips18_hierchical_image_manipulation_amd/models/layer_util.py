@@ -34,6 +34,14 @@ def torch_default_init(net):
     return net
 
 
+def print_network(net):
+    """Module + its parameter count on stdout (reference :28-35)."""
+    if isinstance(net, list):
+        net = net[0]
+    print(net)
+    print('Total number of parameters: %d' % sum(p.numel() for p in net.parameters()))
+
+
 def get_norm_layer(norm_type='instance'):
     if norm_type == 'instance':
         return InstanceNorm2d

@@ -53,6 +53,22 @@ if __name__ == '__main__':
     # box2mask trainer: Python-2 source, imported through the shim's in-memory substitutions
     trainer = type(ref_shim.box2mask_trainer())
     res[trainer.__name__] = dict(build_module='models.TwoStreamAE_mask', methods=surface(trainer))
+    # truth table of the host-side lr_control gate (models/Discriminator_NET.py:190-211) from the reference's own function
+    import io
+    import torch
+    D = importlib.import_module('Discriminator_NET')
+    grid = [0.0, 0.1, 0.29, 0.3, 0.31, 0.5, 0.69, 0.7, 0.71, 0.9, 1.2]
+    table = []
+    stdout, sys.stdout = sys.stdout, io.StringIO()
+    try:
+        for r in grid:
+            for fk in grid:
+                g_lr, d_lr = D.lr_control(torch.tensor([0.5]), torch.tensor([r]), torch.tensor([fk]))
+                table.append([r, fk, g_lr, d_lr])
+    finally:
+        sys.stdout = stdout
+    with open(os.path.join(HERE, 'lr_control_table.json'), 'w') as f:
+        json.dump(dict(note='[loss_D_real, loss_D_fake, g_lr, d_lr] of the reference lr_control, gan_margin 0.3', rows=table), f)
     with open(os.path.join(HERE, 'api_surface.json'), 'w') as f:
         json.dump(res, f, indent=1, sort_keys=True)
     print({k: len(v['methods']) for k, v in res.items()})

@@ -379,6 +379,28 @@ def test_test_time_options_carry_every_field_the_models_read():
     assert [u for u in used if not hasattr(opt, u)] == []
 
 
+def test_host_lr_control_and_print_network_follow_the_reference(capsys):
+    """models/Discriminator_NET.py:190-211 as a host function (the box2mask trainer uses the device form of the same
+    predicate): the REAL reference's truth table over an 11 x 11 grid of (loss_D_real, loss_D_fake) around both margins
+    (tests/golden/lr_control_table.json), for this build's function and for the oracle's restatement; print_network (:28-35)."""
+    import json
+    from oracle import ref_mask_cpu
+    from neurips18_hierchical_image_manipulation_amd.models.Discriminator_NET import lr_control
+    from neurips18_hierchical_image_manipulation_amd.models.layer_util import print_network
+    with open(os.path.join(ROOT, 'tests', 'golden', 'lr_control_table.json')) as f:
+        rows = json.load(f)['rows']
+    assert len(rows) == 121 and {(r[2], r[3]) for r in rows} == {(1.0, 1.0), (1.0, 0.0), (0.0, 1.0)}
+    for real, fake, g_lr, d_lr in rows:
+        got = lr_control(torch.tensor([0.5]), torch.tensor([real]), torch.tensor(fake))
+        assert got == (g_lr, d_lr), (real, fake, got)
+        assert ref_mask_cpu.lr_control(real, fake) == (g_lr, d_lr), (real, fake)
+    out = capsys.readouterr().out
+    assert 'Froze Generator' in out and 'Froze Discriminator' in out and 'Update Both' in out
+    net = torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.Linear(4, 2))
+    print_network([net])
+    assert 'Total number of parameters: 26' in capsys.readouterr().out
+
+
 def test_create_model_without_gpu_fails_loudly():
     if torch.cuda.is_available():
         pytest.skip('GPU present')
