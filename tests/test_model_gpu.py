@@ -973,8 +973,9 @@ def test_two_stream_encoder_variants_teacher_forced(tag):
     state -- losses at 5e-6 (recorded: <= 6e-7), every gradient tensor against the fp32 oracle's, the Adam arithmetic.
     Gradient bound: the gated variants sit at 4e-6 / 4e-4; WITHOUT the output gate the whole image (not the box) enters the
     L1 / VGG terms of an 8x8-latent toy net and sign / ReLU-gate flips reach 1.4e-3 (ctx), 1.8e-3 (ctx_label), 7.2e-3
-    (label) of a tensor's norm in one of the three steps -- a mis-routed stream or loss term is an O(1) error."""
-    _teacher_forced(tag, 3, plumbing_tol=5e-3 if 'gate' in tag else 2e-2)
+    (label) of a tensor's norm in one of the three steps (which flips happen follows the oracle's thread-dependent
+    rounding, so the bound leaves most of a decade) -- a mis-routed stream or loss term is an O(1) error."""
+    _teacher_forced(tag, 3, plumbing_tol=5e-3 if 'gate' in tag else 5e-2)
 
 
 def test_update_learning_rate_changes_the_next_adam_step():
