@@ -205,7 +205,8 @@ int him_class_mask(const float* mask, const float* cls, float* dst, int B, int N
  * (him_onehot; reference encode_input models/pix2pixHD_condImg_model.py:150-155) and are never read; channels
  * [n_onehot, Cin) are ordinary dense inputs.  Replaces nn.Conv2d(input_nc, ngf, 7) of models/Pix2Pix_NET.py:74-76
  * (GlobalGenerator stem) and :137-140 (two-stream label encoder stem).  stride 1, odd square kernel, pad = K/2
- * (zero or reflect), Cout % 16 == 0; *_ws returns 0 when the descriptor is not eligible (use him_conv2d_*).
+ * (zero or reflect) -- or, round 5, 4x4 stride 2 zero-padded (see below) --, Cout % 16 == 0; *_ws returns 0 when the
+ * descriptor is not eligible (use him_conv2d_*).
  * No data gradient: the stem input is data.
  * -------------------------------------------------------------------------------------------*/
 size_t him_conv2d_onehot_fwd_ws(const HimConv2d* d, int n_onehot);
@@ -215,6 +216,19 @@ size_t him_conv2d_onehot_bwd_weight_ws(const HimConv2d* d, int n_onehot);
 int him_conv2d_onehot_bwd_weight(const HimConv2d* d, const float* label, int n_onehot, const float* x,
                                  const float* dy, float* dw, float* dbias, int accumulate, void* ws, size_t ws_bytes,
                                  void* stream);
+/* Round 5.  (1) The same pair for the first PatchGAN convolution of scale 0 -- nn.Conv2d(input_nc, ndf, 4, stride 2,
+ * padding 2) of models/Discriminator_NET.py:71-74 applied to cat(one-hot | cond image | real-or-fake image)
+ * (pix2pixHD_condImg_model.py:149-152,176-186): 4x4, stride 2, zero padding is eligible too (*_ws != 0); forward = 16
+ * table lookups per output pixel, weight gradient in the run-length form (one difference of two prefix sums of a dy row per
+ * (run of equal class, tap), output columns ceil((x0 - tw) / 2) .. ceil((x1 - tw) / 2)).  (2) *_dense: the dense channels
+ * arrive as their OWN tensor xdense (B, Cin - n_onehot, H, W) (NULL when Cin == n_onehot): the (B, Cin, H, W) concatenation
+ * -- 147 MB of one-hot at 512x256 bs 8, written and re-read by three discriminator passes per step -- never exists.
+ * Workspace sizes are those of the plain pair. */
+int him_conv2d_onehot_fwd_dense(const HimConv2d* d, const float* label, int n_onehot, const float* xdense, const float* w,
+                                const float* bias, float* y, void* ws, size_t ws_bytes, void* stream);
+int him_conv2d_onehot_bwd_weight_dense(const HimConv2d* d, const float* label, int n_onehot, const float* xdense,
+                                       const float* dy, float* dw, float* dbias, int accumulate, void* ws,
+                                       size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Weight panels.  The MFMA kernels read the weights regrouped (forward: [Cout][Cin/16][KH][KW][16]; data
@@ -277,6 +291,12 @@ size_t him_conv2d_panel_bytes(const HimConv2d* d, int kind);
  * HIM_PANEL_FWD serves him_conv2d_bwd_data_panel / him_resblock_bwd_data as well (a HIM_PANEL_BWD_DATA panel built for
  * such a layer has the same content). */
 int him_conv2d_bwd_data_shares_fwd_panel(const HimConv2d* d);
+/* Which regrouping the panel of (d, kind) holds: 0 none (raw weights), 1 implicit-GEMM panel, 2 Winograd F(2x2,3x3) for the
+ * separate-transform pipeline, 3 the fused Winograd kernel's chunked panel, 4 Winograd F(4x4,3x3) (frozen weights).  A pure
+ * function of the descriptor, NOT of the weight alone: one nn.Conv2d weight called with another batch / plane size may need
+ * another layout (e.g. VGG conv5_1 of models/layer_util.py:380-411 on the last, smaller batch of an epoch leaves F(4x4)),
+ * so a cache of built panels keys on (kind, layout, him_conv2d_panel_bytes, HimAlgo). */
+int him_conv2d_panel_layout(const HimConv2d* d, int kind);
 int him_conv2d_panel_build(const HimConv2d* d, int kind, const float* w, void* panel, size_t panel_bytes,
                            void* stream);
 int him_conv2d_fwd_panel(const HimConv2d* d, const float* x, const void* panel, const float* bias, float* y,
@@ -346,6 +366,12 @@ int him_add(const float* a, const float* b, float* out, size_t n, void* stream);
  * [c0, c0+n) of a (B,Ctot,H,W) destination so torch.cat never materialises.
  * ------------------------------------------------------------------------------------------- */
 int him_onehot(const float* label, float* dst, int B, int label_nc, int Ctot, int c0, int hw, void* stream);
+/* nn.AvgPool2d(3, 2, 1, count_include_pad=False) applied to one-hot(label) (models/Discriminator_NET.py:31-32,47-58 on the
+ * label channels of pix2pixHD_condImg_model.py:176-186's discriminator input) evaluated from the ids: class counts of the
+ * 3x3 window / valid pixels, written to channels [c0, c0 + label_nc) of a (B, Ctot, OH, OW) destination.  Bit-identical to
+ * him_avgpool3s2_fwd(him_onehot(label)); the full-resolution one-hot tensor is never written. */
+int him_onehot_pool3s2(const float* label, float* dst, int B, int label_nc, int Ctot, int c0, int H, int W, int OH, int OW,
+                       void* stream);
 /* Compact inputs: label / instance maps travel as uint8 ids (1 byte per pixel over PCIe instead of the
  * float maps of data/segmentation_dataset.py:82) and are widened on the device; get_masked_image of
  * data/base_dataset.py:342-357 for a whole batch: bbox[b] = (wmin, hmin, wmax, hmax) floats on the device;

@@ -72,9 +72,12 @@ _SIGS = {
     'him_conv2d_onehot_fwd': (c_int, [_CONV, P, c_int, P, P, P, P, P, c_size_t, P]),
     'him_conv2d_onehot_bwd_weight_ws': (c_size_t, [_CONV, c_int]),
     'him_conv2d_onehot_bwd_weight': (c_int, [_CONV, P, c_int, P, P, P, P, c_int, P, c_size_t, P]),
+    'him_conv2d_onehot_fwd_dense': (c_int, [_CONV, P, c_int, P, P, P, P, P, c_size_t, P]),
+    'him_conv2d_onehot_bwd_weight_dense': (c_int, [_CONV, P, c_int, P, P, P, P, c_int, P, c_size_t, P]),
     'him_winograd_gemm': (c_int, [P, P, P, c_int, c_int, c_int, _ALGO, P]),
     'him_conv2d_panel_bytes': (c_size_t, [_CONV, c_int]),
     'him_conv2d_bwd_data_shares_fwd_panel': (C.c_uint, [_CONV]),
+    'him_conv2d_panel_layout': (C.c_uint, [_CONV, c_int]),
     'him_conv2d_panel_build': (c_int, [_CONV, c_int, P, P, c_size_t, P]),
     'him_conv2d_fwd_panel': (c_int, [_CONV, P, P, P, P, P, c_size_t, P]),
     'him_conv2d_bwd_data_panel': (c_int, [_CONV, P, P, P, P, c_size_t, P]),
@@ -111,6 +114,7 @@ _SIGS = {
     'him_act_bwd': (c_int, [P, P, P, c_size_t, c_int, c_float, P]),
     'him_add': (c_int, [P, P, P, c_size_t, P]),
     'him_onehot': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'him_onehot_pool3s2': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'him_u8_to_f32': (c_int, [P, P, c_size_t, P]),
     'him_data_nearest': (c_int, [P, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, P]),
     'him_data_bicubic_h': (c_int, [P, P, P, P, P, P, P, c_int, P, c_int, c_int, c_int, P]),

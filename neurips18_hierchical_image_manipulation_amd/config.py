@@ -31,6 +31,8 @@ class Schedule(object):
         'share_fake_pass': ('HIM_SHARE_FAKE_PASS', True, 'the fake-image discriminator pass computed once per step'),
         'vgg_gated': ('HIM_VGG_GATED', True, "VGG's ReLU backward folded into the gradient producers"),
         'onehot_stem': ('HIM_ONEHOT_STEM', True, 'generator stem evaluated from the label ids'),
+        'label_ids': ('HIM_LABEL_IDS', True, 'encode_input keeps [one-hot | dense] as (id map, dense channels) (ops.LabelCond): the one-hot block is materialised only for consumers that cannot read ids'),
+        'd_from_ids': ('HIM_D_FROM_IDS', True, 'first PatchGAN convolution of scale 0 evaluated from the label ids (table lookups + run-length weight gradient); the pooled scales from 3x3 class counts'),
         'panel_cache': ('HIM_PANEL_CACHE', True, 'weight panels cached on the parameter, rebuilt after Adam'),
         'resblock_fused': ('HIM_RESBLOCK_FUSED', False, 'ResnetBlock with the norms inside the Winograd transforms'),
         'dead_bias_skip': ('HIM_DEAD_BIAS_SKIP', True, 'no bias gradient in front of a mean-subtracting norm'),

@@ -1357,6 +1357,21 @@ size_t him_conv2d_panel_bytes(const HimConv2d* d, int kind) {
   return (kind == HIM_PANEL_FWD ? fprop_panel_floats(d) : dgrad_panel_floats(d)) * sizeof(float);
 }
 
+// Which regrouping of the weights the panel of (descriptor, kind) holds: 0 none (the kernel reads the raw weights), 1 the
+// implicit-GEMM panel, 2 Winograd F(2x2,3x3) for the separate-transform pipeline (16 positions), 3 the fused Winograd
+// kernel's chunked panel, 4 Winograd F(4x4,3x3) (36 positions, frozen weights).  A pure function of the descriptor: the
+// SAME weight called with another batch / plane size may land on another layout (F(4x4) needs H, W % 4 == 0 and >= 64 real
+// tiles; the tiny-head forms switch on the output size), so a cache of built panels must key on it.
+int him_conv2d_panel_layout(const HimConv2d* d, int kind) {
+  if (!d || check_conv(d)) return 0;
+  if (kind == HIM_PANEL_FWD) {
+    if (!fprop_panel_floats(d)) return 0;
+    return wino4_fwd_ok(d) ? 4 : wino_fused_fwd_ok(d) ? 3 : wino_fwd_ok(d) ? 2 : 1;
+  }
+  if (kind != HIM_PANEL_BWD_DATA || !dgrad_panel_floats(d)) return 0;
+  return wino4_dgrad_ok(d) ? 4 : wino_fused_dgrad_ok(d) ? 3 : wino_dgrad_ok(d) ? 2 : 1;
+}
+
 int him_conv2d_bwd_data_shares_fwd_panel(const HimConv2d* d) {
   if (!d || check_conv(d)) return 0;
   if (wino4_fwd_ok(d) || wino4_dgrad_ok(d)) return 0;
@@ -1483,11 +1498,13 @@ size_t him_conv2d_onehot_fwd_ws(const HimConv2d* d, int n_onehot) {
   return (d && !check_conv(d) && onehot_ok(d, n_onehot)) ? onehot_fwd_ws_bytes(d, n_onehot) : 0;
 }
 
-int him_conv2d_onehot_fwd(const HimConv2d* d, const float* label, int n_onehot, const float* x, const float* w,
-                          const float* bias, float* y, void* ws, size_t ws_bytes, void* stream) {
+// x_dense: x holds ONLY the dense channels, (B, Cin - n_onehot, H, W) contiguous -- no (B, Cin, H, W) buffer exists
+static int onehot_fwd_impl(const HimConv2d* d, const float* label, int n_onehot, const float* x, bool x_dense, const float* w,
+                           const float* bias, float* y, void* ws, size_t ws_bytes, void* stream) {
   int rc = check_conv(d);
   if (rc) return rc;
-  if (!onehot_ok(d, n_onehot)) return fail(HIM_E_UNSUPPORTED, "onehot conv: needs stride 1, odd square kernel, same padding, Cout %% 16 == 0");
+  if (!onehot_ok(d, n_onehot))
+    return fail(HIM_E_UNSUPPORTED, "onehot conv: needs an odd 'same' stride-1 kernel or 4x4 stride 2 zero-padded, Cout %% 16 == 0");
   if (!ws || ws_bytes < onehot_fwd_ws_bytes(d, n_onehot)) return fail(HIM_E_WORKSPACE, "onehot conv fwd: ws too small");
   hipStream_t st = (hipStream_t)stream;
   const int NC = n_onehot, Cd = d->Cin - NC, KK = d->KH * d->KW, HW = d->H * d->W;
@@ -1498,12 +1515,14 @@ int him_conv2d_onehot_fwd(const HimConv2d* d, const float* label, int n_onehot, 
   if (Cd > 0) {  // dense channels: the ordinary conv on contiguous copies (bias folded in here)
     float* wd = xd + ((size_t)d->B * Cd * HW + 63) / 64 * 64;
     float* cws = wd + ((size_t)d->Cout * Cd * KK + 63) / 64 * 64;
-    rc = him_copy_channels(x, d->Cin, NC, xd, Cd, 0, Cd, d->B, HW, nullptr, 0, 0, stream);
-    if (rc) return rc;
+    if (!x_dense) {
+      rc = him_copy_channels(x, d->Cin, NC, xd, Cd, 0, Cd, d->B, HW, nullptr, 0, 0, stream);
+      if (rc) return rc;
+    }
     hipLaunchKernelGGL(onehot_dense_w_kernel, dim3(cdiv((long long)d->Cout * Cd * KK, 256)), dim3(256), 0, st,
                        (float*)w, wd, d->Cout, d->Cin, NC, KK, 0, 0);
     const HimConv2d dd = onehot_dense_desc(d, NC);
-    rc = run_fprop(&dd, xd, wd, bias, y, cws, fprop_ws_bytes(&dd), st);
+    rc = run_fprop(&dd, x_dense ? x : xd, wd, bias, y, cws, fprop_ws_bytes(&dd), st);
     if (rc) return rc;
   }
   OneHotP p;
@@ -1511,7 +1530,8 @@ int him_conv2d_onehot_fwd(const HimConv2d* d, const float* label, int n_onehot, 
   p.B = d->B; p.H = d->H; p.W = d->W; p.NC = NC; p.KS = d->KH; p.pad = d->pad;
   p.reflect = d->pad_mode == HIM_PAD_REFLECT;
   p.Cout = d->Cout;
-  p.npix = d->B * HW;
+  p.stride = d->stride; p.OH = d->OH; p.OW = d->OW;
+  p.npix = d->B * d->OH * d->OW;
   const size_t lds = (size_t)KK * NC * 16 * sizeof(float);
   const dim3 grid(std::min(cdiv(p.npix, 1024), 64), d->Cout / 16);
 #define HIM_OH_FWD(KSv)                                                                                              \
@@ -1522,17 +1542,29 @@ int him_conv2d_onehot_fwd(const HimConv2d* d, const float* label, int n_onehot, 
   }
   if (d->KH == 7) HIM_OH_FWD(7)
   else if (d->KH == 5) HIM_OH_FWD(5)
+  else if (d->KH == 4) HIM_OH_FWD(4)
   else HIM_OH_FWD(3)
 #undef HIM_OH_FWD
   return check_launch("onehot_conv_fwd");
+}
+
+int him_conv2d_onehot_fwd(const HimConv2d* d, const float* label, int n_onehot, const float* x, const float* w,
+                          const float* bias, float* y, void* ws, size_t ws_bytes, void* stream) {
+  return onehot_fwd_impl(d, label, n_onehot, x, false, w, bias, y, ws, ws_bytes, stream);
+}
+int him_conv2d_onehot_fwd_dense(const HimConv2d* d, const float* label, int n_onehot, const float* xdense, const float* w,
+                                const float* bias, float* y, void* ws, size_t ws_bytes, void* stream) {
+  if (d && d->Cin > n_onehot && !xdense) return fail(HIM_E_INVALID, "onehot conv: %d dense channels but no dense tensor", d->Cin - n_onehot);
+  return onehot_fwd_impl(d, label, n_onehot, xdense, true, w, bias, y, ws, ws_bytes, stream);
 }
 
 size_t him_conv2d_onehot_bwd_weight_ws(const HimConv2d* d, int n_onehot) {
   return (d && !check_conv(d) && onehot_ok(d, n_onehot)) ? onehot_wgrad_ws_bytes(d, n_onehot) + bias_ws_bytes(d->Cout) : 0;
 }
 
-int him_conv2d_onehot_bwd_weight(const HimConv2d* d, const float* label, int n_onehot, const float* x, const float* dy,
-                                 float* dw, float* dbias, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+static int onehot_bwd_weight_impl(const HimConv2d* d, const float* label, int n_onehot, const float* x, bool x_dense,
+                                  const float* dy, float* dw, float* dbias, int accumulate, void* ws, size_t ws_bytes,
+                                  void* stream) {
   int rc = check_conv(d);
   if (rc) return rc;
   if (!onehot_ok(d, n_onehot)) return fail(HIM_E_UNSUPPORTED, "onehot conv: unsupported descriptor");
@@ -1547,27 +1579,30 @@ int him_conv2d_onehot_bwd_weight(const HimConv2d* d, const float* label, int n_o
   p.B = d->B; p.H = d->H; p.W = d->W; p.NC = NC; p.KS = d->KH; p.pad = d->pad;
   p.reflect = d->pad_mode == HIM_PAD_REFLECT;
   p.Cout = d->Cout;
-  p.npix = d->B * HW;
+  p.stride = d->stride; p.OH = d->OH; p.OW = d->OW;
+  p.npix = d->B * d->OH * d->OW;
   if (dw && onehot_rle_ok(d, NC)) {   // run-length form (him_conv_onehot.inc): dy read once, cost per run of equal class
     int nbands, rows_per;
     onehot_rle_geom(d, &nbands, &rows_per);
     const int nblk = d->B * nbands;
     const size_t lds = onehot_rle_lds_bytes(d, NC);
-#define HIM_OH_RLE(KSv)                                                                                              \
+#define HIM_OH_RLE(KSv, Sv)                                                                                          \
   {                                                                                                                  \
-    (void)hipFuncSetAttribute((const void*)onehot_wgrad_rle_kernel<KSv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL((onehot_wgrad_rle_kernel<KSv>), dim3(nblk, d->Cout / 8), dim3(512), lds, st, p, dy, part, nbands, \
+    (void)hipFuncSetAttribute((const void*)onehot_wgrad_rle_kernel<KSv, Sv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((onehot_wgrad_rle_kernel<KSv, Sv>), dim3(nblk, d->Cout / 8), dim3(512), lds, st, p, dy, part, nbands, \
                        rows_per);                                                                                    \
   }
-    if (d->KH == 7) HIM_OH_RLE(7)
-    else if (d->KH == 5) HIM_OH_RLE(5)
-    else HIM_OH_RLE(3)
+    if (d->stride == 2) HIM_OH_RLE(4, 2)
+    else if (d->KH == 7) HIM_OH_RLE(7, 1)
+    else if (d->KH == 5) HIM_OH_RLE(5, 1)
+    else HIM_OH_RLE(3, 1)
 #undef HIM_OH_RLE
     hipLaunchKernelGGL(onehot_wgrad_reduce_kernel, dim3(cdiv((long long)KK * NC * d->Cout, 256)), dim3(256), 0, st,
                        (const float*)part, dw, nblk, d->Cout, d->Cin, NC, KK, accumulate);
     rc = check_launch("onehot_wgrad_rle");
     if (rc) return rc;
   } else if (dw) {
+    if (d->stride != 1) return fail(HIM_E_UNSUPPORTED, "onehot conv: the strided weight gradient exists in run-length form only");
     int nsx, nyc, rows_per;
     onehot_wgrad_geom(d, &nsx, &nyc, &rows_per);
     const int nblk = d->B * nsx * nyc;
@@ -1591,9 +1626,11 @@ int him_conv2d_onehot_bwd_weight(const HimConv2d* d, const float* label, int n_o
     if (Cd > 0) {
       float* dwd = xd + ((size_t)d->B * Cd * HW + 63) / 64 * 64;
       float* wws = dwd + ((size_t)d->Cout * Cd * KK + 63) / 64 * 64;
-      rc = him_copy_channels(x, d->Cin, NC, xd, Cd, 0, Cd, d->B, HW, nullptr, 0, 0, stream);
-      if (rc) return rc;
-      rc = run_wgrad(d->algo, dy, xd, dwd, d->Cout, Cd, d->B, d->H, d->W, d->OH, d->OW, d->KH, d->KW, d->stride, d->pad,
+      if (!x_dense) {
+        rc = him_copy_channels(x, d->Cin, NC, xd, Cd, 0, Cd, d->B, HW, nullptr, 0, 0, stream);
+        if (rc) return rc;
+      }
+      rc = run_wgrad(d->algo, dy, x_dense ? x : xd, dwd, d->Cout, Cd, d->B, d->H, d->W, d->OH, d->OW, d->KH, d->KW, d->stride, d->pad,
                      d->pad_mode, 0, wws, wgrad_slab_bytes(d->algo, d->Cout, Cd, d->KH, d->KW, d->B * d->OH * d->OW), st);
       if (rc) return rc;
       hipLaunchKernelGGL(onehot_dense_w_kernel, dim3(cdiv((long long)d->Cout * Cd * KK, 256)), dim3(256), 0, st, dw, dwd,
@@ -1607,6 +1644,18 @@ int him_conv2d_onehot_bwd_weight(const HimConv2d* d, const float* label, int n_o
     rc = run_bias_grad(dy, dbias, d->B, d->Cout, d->OH * d->OW, accumulate, (char*)ws + off, ws_bytes - off, st);
   }
   return rc;
+}
+
+int him_conv2d_onehot_bwd_weight(const HimConv2d* d, const float* label, int n_onehot, const float* x, const float* dy,
+                                 float* dw, float* dbias, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+  return onehot_bwd_weight_impl(d, label, n_onehot, x, false, dy, dw, dbias, accumulate, ws, ws_bytes, stream);
+}
+int him_conv2d_onehot_bwd_weight_dense(const HimConv2d* d, const float* label, int n_onehot, const float* xdense,
+                                       const float* dy, float* dw, float* dbias, int accumulate, void* ws, size_t ws_bytes,
+                                       void* stream) {
+  if (d && d->Cin > n_onehot && dw && !xdense)
+    return fail(HIM_E_INVALID, "onehot conv: %d dense channels but no dense tensor", d->Cin - n_onehot);
+  return onehot_bwd_weight_impl(d, label, n_onehot, xdense, true, dy, dw, dbias, accumulate, ws, ws_bytes, stream);
 }
 
 size_t him_deconv2d_fwd_ws(const HimDeconv2d* t) {

@@ -48,6 +48,37 @@ __global__ void onehot_kernel(const float* __restrict__ label, float* __restrict
   }
 }
 
+// AvgPool2d(3, stride 2, pad 1, count_include_pad=False) of one-hot(label) WITHOUT the one-hot tensor: the pooled value of
+// class c is (number of window pixels with id c) / (window pixels inside the image) -- sums of 0 / 1 are exact in any
+// order, so this equals avgpool3s2_fwd_kernel applied to onehot_kernel's output bit for bit.  One thread per output pixel
+// (<= 9 id loads), nc coalesced stores.  dst[b][c0 + c][oy][ox]
+__global__ void onehot_pool3s2_kernel(const float* __restrict__ label, float* __restrict__ dst, int B, int nc, int Ctot,
+                                      int c0, int H, int W, int OH, int OW) {
+  const long long total = (long long)B * OH * OW;
+  GS_LOOP(i, total) {
+    const int ox = (int)(i % OW);
+    const long long r = i / OW;
+    const int oy = (int)(r % OH);
+    const int b = (int)(r / OH);
+    const float* __restrict__ lab = label + (size_t)b * H * W;
+    const int y0 = max(oy * 2 - 1, 0), y1 = min(oy * 2 + 2, H), x0 = max(ox * 2 - 1, 0), x1 = min(ox * 2 + 2, W);
+    int ids[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int yy = y0 + k / 3, xx = x0 + k % 3;
+      ids[k] = (yy < y1 && xx < x1) ? (int)lab[yy * W + xx] : -1;
+    }
+    const float cnt = (float)((y1 - y0) * (x1 - x0));
+    float* __restrict__ o = dst + ((size_t)b * Ctot + c0) * OH * OW + (size_t)oy * OW + ox;
+    for (int c = 0; c < nc; ++c) {
+      int s = 0;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) s += ids[k] == c ? 1 : 0;
+      o[(size_t)c * OH * OW] = (float)s / cnt;
+    }
+  }
+}
+
 // compact label maps: uint8 ids (as stored on disk / sent over PCIe) -> the float id map the kernels read
 __global__ void u8_to_f32_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst, size_t n) {
   GS_LOOP(i, n) dst[i] = (float)src[i];
@@ -311,6 +342,14 @@ int him_onehot(const float* label, float* dst, int B, int label_nc, int Ctot, in
   hipLaunchKernelGGL(onehot_kernel, gs_grid((long long)B * label_nc * hw), dim3(256), 0, ST, label, dst, B,
                      label_nc, Ctot, c0, hw);
   return check_launch("onehot");
+}
+int him_onehot_pool3s2(const float* label, float* dst, int B, int label_nc, int Ctot, int c0, int H, int W, int OH, int OW,
+                       void* stream) {
+  if (c0 < 0 || c0 + label_nc > Ctot) return fail(HIM_E_INVALID, "onehot_pool: channel slice out of range");
+  if (OH != (H + 2 - 3) / 2 + 1 || OW != (W + 2 - 3) / 2 + 1) return fail(HIM_E_INVALID, "onehot_pool: bad OH/OW");
+  hipLaunchKernelGGL(onehot_pool3s2_kernel, gs_grid((long long)B * OH * OW), dim3(256), 0, ST, label, dst, B, label_nc,
+                     Ctot, c0, H, W, OH, OW);
+  return check_launch("onehot_pool3s2");
 }
 int him_edges(const float* inst, float* dst, int B, int H, int W, int Ctot, int c0, void* stream) {
   if (c0 < 0 || c0 + 1 > Ctot) return fail(HIM_E_INVALID, "edges: channel slice out of range");

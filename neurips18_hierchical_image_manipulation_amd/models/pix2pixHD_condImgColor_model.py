@@ -22,10 +22,10 @@ class Pix2PixHDModel_condImgColor(Pix2PixHDModel_condImg):
     # The reference's colour model puts obj_mask / color_embed IN FRONT of infer (positional callers such as its
     # vis_mask2image_color-style scripts depend on the order); the parent's methods take them as trailing keywords.
     def encode_input(self, label_map, inst_map=None, real_image=None, feat_map=None, mask_in=None, obj_mask=None,
-                     color_embed=None, infer=False):
-        """Reference :188-228 (argument order of :188)."""
+                     color_embed=None, infer=False, lazy=False):
+        """Reference :188-228 (argument order of :188); ``lazy``: see the parent (the trainer's own calls)."""
         return super().encode_input(label_map, inst_map, real_image, feat_map, mask_in=mask_in, infer=infer,
-                                    obj_mask=obj_mask, color_embed=color_embed)
+                                    obj_mask=obj_mask, color_embed=color_embed, lazy=lazy)
 
     def forward(self, label, inst, image, feat, mask_in, mask_out, obj_mask, infer=False):
         """Reference :252 -- ``obj_mask`` is the seventh positional argument, ``infer`` the eighth."""

@@ -188,16 +188,20 @@ class Pix2PixHDModel_condImg(BaseModel):
         return None
 
     def encode_input(self, label_map, inst_map=None, real_image=None, feat_map=None, mask_in=None, infer=False,
-                     obj_mask=None, color_embed=None):
+                     obj_mask=None, color_embed=None, lazy=False):
         """-> (input_label, inst_map, real_image, feat_map, cond_image), as the reference (:144-174); the
-        concatenated [label | cond] buffer the generator/discriminator read is kept in ``self._enc``."""
+        concatenated [label | cond] buffer the generator/discriminator read is kept in ``self._enc``.
+        ``lazy`` (the trainer's own calls): the one-hot block stays an id map -- ``input_label`` and the buffer are
+        ``ops.LabelCond`` objects, which the stems, the first PatchGAN convolution and the pooled scales read directly; a
+        caller of the public method gets the reference's tensors."""
         assert real_image is not None
         assert mask_in is not None
         label_map, inst_map = self._dev(label_map), self._dev(inst_map)
         real_image, mask_in = self._dev(real_image), self._dev(mask_in)
         emb = self._color_embedding(self._dev(obj_mask), real_image, color_embed, infer)
         buf, n_label, n_cond = ops.encode_channels(label_map, inst_map, real_image, mask_in, self.opt.label_nc,
-                                                   not self.opt.no_instance, color_emb=emb)
+                                                   not self.opt.no_instance, color_emb=emb,
+                                                   lazy=lazy and SCHED.label_ids and self.opt.label_nc > 0)
         self._enc = (buf, n_label, n_cond, mask_in)
         input_label = ops.slice_channels(buf, 0, n_label)
         cond_image = ops.slice_channels(buf, n_label, n_cond)
@@ -292,7 +296,7 @@ class Pix2PixHDModel_condImg(BaseModel):
                 enc_side.wait_stream(main)       # device tensors of unknown origin: whatever the current stream holds
         with torch.cuda.stream(enc_side) if enc_side is not None else contextlib.nullcontext():
             input_mask, inst_map, real_image, _, cond_image = self.encode_input(label, inst, image, feat, mask_in=mask_in,
-                                                                               obj_mask=obj_mask)
+                                                                               obj_mask=obj_mask, lazy=True)
             buf, n_label, n_cond, mask_in = self._enc
             netD_cond = input_mask if self.no_imgCond else buf
             mask_cond = mask_in if not self.use_soft_mask else self._dev(mask_out)
@@ -305,7 +309,7 @@ class Pix2PixHDModel_condImg(BaseModel):
             main.wait_event(inputs_ready)
             for t in (buf, input_mask, inst_map, real_image, cond_image, mask_in, mask_cond) + tuple(
                     getattr(netD_cond, '_him_pyramid', ())):
-                if torch.is_tensor(t):
+                if torch.is_tensor(t) or isinstance(t, ops.LabelCond):
                     t.record_stream(main)        # allocated on the real-image stream, read on the main one
 
         # Everything that depends only on the REAL image (its discriminator pass and its VGG features) is independent
@@ -416,7 +420,7 @@ class Pix2PixHDModel_condImg(BaseModel):
         with torch.no_grad():
             input_mask, _, real_image, _, cond_image = self.encode_input(label, inst, image, mask_in=mask_in,
                                                                         infer=True, obj_mask=obj_mask,
-                                                                        color_embed=color_embed)
+                                                                        color_embed=color_embed, lazy=True)
             buf, _, _, mask_dev = self._enc
             self._wait_g_update()
             fake_image = self._generate(buf, input_mask, cond_image, mask_dev)
@@ -433,6 +437,8 @@ class Pix2PixHDModel_condImg(BaseModel):
 
     def get_current_visuals(self):
         fake, real, label, cond = self._visuals
+        if isinstance(label, ops.LabelCond):
+            label = label.full()
         return OrderedDict([('input_label', label[0].cpu()), ('input_image', cond[0].cpu()),
                             ('real_image', real[0].cpu()), ('synthesized_image', fake[0].cpu())])
 
@@ -509,9 +515,15 @@ class Pix2PixHDModel_condImg(BaseModel):
 
     def optimize_parameters(self, data=None, infer=False):
         """One full training step on a batch dict (keys of SegmentationDataset: label, inst, image, mask_in,
-        mask_out[, obj_mask]).  Same arithmetic as backward_G(); backward_D() but the generator's all-reduce and
-        Adam step are deferred behind loss_D.backward() (legal: loss_D's graph holds no G parameter, the fake is
-        detached) so the 730 MB exchange overlaps D's backward."""
+        mask_out[, obj_mask]).  Same arithmetic as backward_G(); backward_D(), in the shipped order
+        (``SCHED.d_backward_first``): both arenas zeroed, ``loss_D.backward()`` FIRST (its graph holds no generator
+        parameter: the fake is detached / gated) with D's 34 MB exchange going out under it, then ``loss_G.backward()`` --
+        the LAST thing in the step -- with G's 730 MB leaving bucket by bucket under the rest of its own backward; D's Adam
+        waits for the generator's backward (loss_G differentiates through D's current weights); G's last buckets + Adam +
+        panel rebuild are left running on the optimizer stream into the NEXT step's input encoding and real-image branch
+        (``_wait_g_update``).  The exchange budget of this order is written down in DESIGN.md 6.  With
+        ``d_backward_first`` off (``bench.py --g-backward-first``) the reference's order runs: G's exchange + Adam then
+        hide under the whole of D's backward."""
         data = data if data is not None else self.input
         kw = dict(label=data['label'], inst=data['inst'], image=data['image'], feat=None, mask_in=data['mask_in'],
                   mask_out=data['mask_out'], infer=infer)

@@ -343,10 +343,15 @@ def _panel(w, d, kind, is_deconv):
     # every descriptor field the panel LAYOUT can depend on (include/him.h "Weight panels": Winograd eligibility needs
     # pad 1 + planes >= 2x2 + an unchanged plane size for the data gradient; tiny heads switch on the output size)
     # ... and the HimAlgo the panel is built with (Winograd thresholds decide the layout)
+    # The layout is the LIBRARY's choice for this descriptor (him_conv2d_panel_layout: implicit GEMM / Winograd F(2x2) /
+    # fused Winograd / F(4x4)) and depends on batch and plane size, not on the weight alone: the same frozen VGG weight on
+    # the last, smaller batch of an epoch leaves F(4x4) (a 36-position panel read as a 16-position one).
+    nbytes = int((lib.him_deconv2d_panel_bytes if is_deconv else lib.him_conv2d_panel_bytes)(ctypes.byref(d), kind))
     if is_deconv:
-        key = (kind, d.stride, d.pad, d.out_pad, bytes(d.algo))
+        key = (kind, d.stride, d.pad, d.out_pad, nbytes, bytes(d.algo))
     else:
-        key = (kind, d.stride, d.pad, d.pad_mode, d.H >= 2 and d.W >= 2, d.OH == d.H and d.OW == d.W,
+        key = (kind, int(lib.him_conv2d_panel_layout(ctypes.byref(d), kind)), nbytes, d.stride, d.pad, d.pad_mode,
+               d.H >= 2 and d.W >= 2, d.OH == d.H and d.OW == d.W,
                d.B * d.OH * d.OW < 131072, d.B * d.Cin * d.H * d.W < (1 << 29), d.B * d.Cout * d.H * d.W < (1 << 29),
                bytes(d.algo))
     e = cache.get(key)
@@ -354,8 +359,7 @@ def _panel(w, d, kind, is_deconv):
         e = cache[key] = _Panel()
         e.kind, e.is_deconv = kind, is_deconv
         e.desc = type(d).from_buffer_copy(d)
-        fn = lib.him_deconv2d_panel_bytes if is_deconv else lib.him_conv2d_panel_bytes
-        e.nbytes = int(fn(ctypes.byref(d), kind))
+        e.nbytes = nbytes
         e.buf = torch.empty(e.nbytes // 4, dtype=torch.float32, device=w.device) if e.nbytes else None
         e.token = None
     if e.buf is None:
@@ -496,16 +500,24 @@ class _OneHotConv2d(torch.autograd.Function):
     """conv2d over [one-hot(label) | dense channels] evaluated from the label ids (include/him.h "One-hot stems")."""
 
     @staticmethod
-    def forward(ctx, x, label, n_onehot, w, b, pad, pad_mode, act, slope):
+    def forward(ctx, x, label, n_onehot, w, b, pad, pad_mode, act, slope, stride=1, dense_only=False):
+        """``dense_only``: ``x`` holds only the dense channels (B, Cin - n_onehot, H, W) -- or is None when there are none --
+        instead of the (B, Cin, H, W) concatenation with the materialised one-hot block (``LabelCond`` inputs)."""
         ctx.set_materialize_grads(False)
-        x, label = x.contiguous(), label.contiguous()
+        label = label.contiguous()
+        if x is not None:
+            x = x.contiguous()
         _chk(x, label, w, b)
-        d = _conv_desc(x, w, 1, pad, pad_mode, act, slope)
-        y = torch.empty((d.B, d.Cout, d.OH, d.OW), dtype=torch.float32, device=x.device)
+        d = _ids_conv_desc(label, w, stride, pad, pad_mode, act, slope)
+        if dense_only and (0 if x is None else x.shape[1]) != d.Cin - n_onehot:
+            raise HimError('one-hot conv: %d dense channels given, the weight expects %d'
+                           % (0 if x is None else x.shape[1], d.Cin - n_onehot))
+        y = torch.empty((d.B, d.Cout, d.OH, d.OW), dtype=torch.float32, device=label.device)
         nb = lib.him_conv2d_onehot_fwd_ws(ctypes.byref(d), n_onehot)
-        ws = _ws(nb, x)
-        lib.him_conv2d_onehot_fwd(ctypes.byref(d), _p(label), n_onehot, _p(x), _p(w), _p(b), _p(y), _p(ws), nb, _stream())
-        ctx.d, ctx.n_onehot = d, n_onehot
+        ws = _ws(nb, label)
+        fn = lib.him_conv2d_onehot_fwd_dense if dense_only else lib.him_conv2d_onehot_fwd
+        fn(ctypes.byref(d), _p(label), n_onehot, _p(x), _p(w), _p(b), _p(y), _p(ws), nb, _stream())
+        ctx.d, ctx.n_onehot, ctx.dense_only = d, n_onehot, bool(dense_only)
         ctx.x, ctx.label, ctx.w, ctx.b = x, label, w, b
         ctx.save_for_backward(y if act != ACT_NONE else None)
         return y
@@ -513,10 +525,11 @@ class _OneHotConv2d(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         if dy is None:
-            return (None,) * 9
+            return (None,) * 11
         if ctx.needs_input_grad[0]:
             raise HimError('one-hot stem conv has no data gradient (its input is data)')
         d, x, label, w, b = ctx.d, ctx.x, ctx.label, ctx.w, ctx.b
+        bw = lib.him_conv2d_onehot_bwd_weight_dense if ctx.dense_only else lib.him_conv2d_onehot_bwd_weight
         dy = dy.contiguous()
         st = _stream()
         if d.act != ACT_NONE:
@@ -532,19 +545,113 @@ class _OneHotConv2d(torch.autograd.Function):
             nb = lib.him_conv2d_onehot_bwd_weight_ws(ctypes.byref(d), ctx.n_onehot)
             if need_w and _direct(w) and (not need_b or _direct(b)):
                 with _wgrad_stream(x, dz, label):
-                    ws = _ws(nb, x)
-                    lib.him_conv2d_onehot_bwd_weight(ctypes.byref(d), _p(label), ctx.n_onehot, _p(x), _p(dz), _p(w.grad),
-                                                     _p(b.grad) if need_b else 0, 1, _p(ws), nb, _stream())
+                    ws = _ws(nb, label)
+                    bw(ctypes.byref(d), _p(label), ctx.n_onehot, _p(x), _p(dz), _p(w.grad),
+                       _p(b.grad) if need_b else 0, 1, _p(ws), nb, _stream())
                     _notify(w)
                     if need_b:
                         _notify(b)
             else:
-                ws = _ws(nb, x)
+                ws = _ws(nb, label)
                 dw = torch.empty_like(w) if need_w else None
                 db = torch.empty_like(b) if need_b else None
-                lib.him_conv2d_onehot_bwd_weight(ctypes.byref(d), _p(label), ctx.n_onehot, _p(x), _p(dz), _p(dw), _p(db), 0,
-                                                 _p(ws), nb, st)
-        return None, None, None, dw, db, None, None, None, None
+                bw(ctypes.byref(d), _p(label), ctx.n_onehot, _p(x), _p(dz), _p(dw), _p(db), 0, _p(ws), nb, st)
+        return None, None, None, dw, db, None, None, None, None, None, None
+
+
+def _ids_conv_desc(label, w, stride, pad, pad_mode, act, slope):
+    """HimConv2d of a convolution whose input is [one-hot(label) | dense]: the weight names the channel count."""
+    B, _, H, W = label.shape
+    Cout, Cin, KH, KW = w.shape
+    OH = (H + 2 * pad - KH) // stride + 1
+    OW = (W + 2 * pad - KW) // stride + 1
+    return HimConv2d(B, Cin, H, W, Cout, KH, KW, stride, pad, pad_mode, OH, OW, act, slope, current_algo())
+
+
+class LabelCond(object):
+    """The reference's ``encode_input`` result [one-hot(label) | dense channels] (pix2pixHD_condImg_model.py:144-174 + the
+    cat at :204) kept as what it is made from: the (B,1,H,W) id map and the few dense channels (edges, (1-mask)*image, colour
+    embedding).  Consumers that can read ids do -- the generators' stems and (round 5) the first PatchGAN convolution
+    (``_OneHotConv2d``), the pooled discriminator scales (``pooled``: 3x3 class counts) -- so the one-hot block (147 MB at
+    512x256 bs 8) is neither written nor copied into the discriminator inputs; anything else calls ``full()`` (materialised
+    once, cached)."""
+
+    def __init__(self, label, n_onehot, dense=None):
+        if dense is not None and dense.shape[1] == 0:
+            dense = None
+        self.label, self.n_onehot, self.dense = label, int(n_onehot), dense
+        self._full = self._pooled = None
+
+    @property
+    def n_dense(self):
+        return 0 if self.dense is None else self.dense.shape[1]
+
+    @property
+    def shape(self):
+        B, _, H, W = self.label.shape
+        return torch.Size((B, self.n_onehot + self.n_dense, H, W))
+
+    @property
+    def device(self):
+        return self.label.device
+
+    is_cuda, requires_grad = True, False
+
+    def dim(self):
+        return 4
+
+    def detach(self):
+        return self
+
+    def contiguous(self):
+        return self
+
+    def record_stream(self, stream):
+        for t in (self.label, self.dense, self._full, self._pooled):
+            if t is not None:
+                t.record_stream(stream)
+
+    def full(self):
+        """The (B, n_onehot + n_dense, H, W) tensor itself (him_onehot + one channel copy), cached."""
+        if self._full is None:
+            B, C, H, W = self.shape
+            buf = torch.empty((B, C, H, W), dtype=torch.float32, device=self.device)
+            st = _stream()
+            lib.him_onehot(_p(self.label), _p(buf), B, self.n_onehot, C, 0, H * W, st)
+            if self.dense is not None:
+                lib.him_copy_channels(_p(self.dense), self.n_dense, 0, _p(buf), C, self.n_onehot, self.n_dense, B, H * W,
+                                      0, 0, 0, st)
+            self._full = mark_onehot(buf, self.label, self.n_onehot)
+        return self._full
+
+    def slice(self, c0, n):
+        """Channels [c0, c0 + n): a ``LabelCond`` while the slice still starts with the whole one-hot block, a tensor else."""
+        if c0 == 0 and n >= self.n_onehot:
+            k = n - self.n_onehot
+            if k == self.n_dense:
+                return self
+            return LabelCond(self.label, self.n_onehot, slice_channels(self.dense, 0, k) if k else None)
+        if c0 >= self.n_onehot:
+            return slice_channels(self.dense, c0 - self.n_onehot, n)
+        return slice_channels(self.full(), c0, n)
+
+    def pooled(self):
+        """AvgPool2d(3, 2, 1, count_include_pad=False) of the whole thing (reference Discriminator_NET.py:31-32, LocalEnhancer
+        Pix2Pix_NET.py:50-53): the one-hot channels as class counts of the 3x3 windows straight from the ids
+        (him_onehot_pool3s2, bit-identical to pooling the one-hot), the dense channels through the ordinary pool."""
+        if self._pooled is None:
+            with torch.no_grad():
+                B, C, H, W = self.shape
+                OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+                out = torch.empty((B, C, OH, OW), dtype=torch.float32, device=self.device)
+                st = _stream()
+                lib.him_onehot_pool3s2(_p(self.label), _p(out), B, self.n_onehot, C, 0, H, W, OH, OW, st)
+                if self.dense is not None:
+                    pd = avgpool3s2(self.dense)
+                    lib.him_copy_channels(_p(pd), self.n_dense, 0, _p(out), C, self.n_onehot, self.n_dense, B, OH * OW,
+                                          0, 0, 0, st)
+                self._pooled = out
+        return self._pooled
 
 
 def mark_onehot(x, label, n_onehot):
@@ -561,6 +668,12 @@ def conv2d(x, w, b=None, stride=1, pad=0, pad_mode='zero', act='none', slope=0.2
     ``grad_premasked`` the caller guarantees that every consumer of this layer's output multiplies the gradient it
     sends back by (output > 0) -- this layer then skips its own ReLU backward pass; ``gate_dx`` makes this layer such a
     consumer for its input (dx = (x > 0) * dgrad, in the data-gradient kernel's epilogue)."""
+    if isinstance(x, LabelCond):
+        pm = PAD_REFLECT if pad_mode == 'reflect' else PAD_ZERO
+        d = _ids_conv_desc(x.label, w, stride, pad, pm, ACTS[act], float(slope))
+        if SCHED.onehot_stem and w.shape[1] == x.shape[1] and lib.him_conv2d_onehot_fwd_ws(ctypes.byref(d), x.n_onehot):
+            return _OneHotConv2d.apply(x.dense, x.label, x.n_onehot, w, b, pad, pm, ACTS[act], float(slope), int(stride), True)
+        x = x.full()
     oh = getattr(x, '_him_onehot', None) if SCHED.onehot_stem else None
     if oh is not None and stride == 1 and not x.requires_grad:
         label, n_onehot = oh
@@ -583,7 +696,8 @@ class CondImage(object):
         self.cond, self.image = cond, image
 
     def cat(self):
-        return cat_channels([self.cond, self.image])
+        cond = self.cond.full() if isinstance(self.cond, LabelCond) else self.cond
+        return cat_channels([cond, self.image])
 
 
 def cond_pyramid(cond, levels, prefill=0, image_channels=3):
@@ -598,10 +712,23 @@ def cond_pyramid(cond, levels, prefill=0, image_channels=3):
         with torch.no_grad():
             pyr = [cond.detach()]
             while len(pyr) < levels:
-                pyr.append(avgpool3s2(pyr[-1]))
+                # a LabelCond's next level comes from the ids (3x3 class counts); from there on the levels are tensors
+                pyr.append(pyr[-1].pooled() if isinstance(pyr[-1], LabelCond) else avgpool3s2(pyr[-1]))
             if prefill > 0 and SCHED.d_prefill_cond:
                 st = _stream()
                 for c in pyr:
+                    if isinstance(c, LabelCond):
+                        # scale 0 reads the ids: the buffers hold [dense condition channels | image slot] only
+                        B, _, H, W = c.shape
+                        Cd, bufs = c.n_dense, []
+                        for _ in range(prefill):
+                            x = torch.empty((B, Cd + image_channels, H, W), dtype=torch.float32, device=c.device)
+                            if Cd:
+                                lib.him_copy_channels(_p(c.dense), Cd, 0, _p(x), Cd + image_channels, 0, Cd, B, H * W, 0, 0,
+                                                      0, st)
+                            bufs.append(x)
+                        c._him_prefilled = bufs
+                        continue
                     B, Cc, H, W = c.shape
                     bufs = []
                     for _ in range(prefill):
@@ -690,8 +817,94 @@ class _CondImageConv2d(torch.autograd.Function):
         return None, dimg, dw, db, None, None, None, None
 
 
+class _IdsCondImageConv2d(torch.autograd.Function):
+    """act(conv2d([one-hot(label) | dense condition | image], w) + b), zero padding, with the one-hot block read from the
+    ids (reference: the first nn.Conv2d of every NLayerDiscriminator, Discriminator_NET.py:71-74, on the concatenation of
+    pix2pixHD_condImg_model.py:176-186): forward = table lookups + the (dense condition | image) channels as an ordinary
+    few-channel conv; weight gradient = run-length sums over the label rows + the few-channel weight gradient; data gradient
+    to the image channels only (the 3-channel weight slice, as ``_CondImageConv2d``)."""
+
+    @staticmethod
+    def forward(ctx, cond, image, w, b, stride, pad, act, slope):
+        ctx.set_materialize_grads(False)
+        image = image.contiguous()
+        _chk(image, w, b)
+        B, _, H, W = cond.shape
+        Cd, Ci, NC = cond.n_dense, image.shape[1], cond.n_onehot
+        if image.shape[0] != B or tuple(image.shape[2:]) != (H, W):
+            raise HimError('cond/image conv: shapes %s and %s do not stack' % (tuple(cond.shape), tuple(image.shape)))
+        st = _stream()
+        pre = getattr(cond, '_him_prefilled', None)
+        if pre and tuple(pre[-1].shape) == (B, Cd + Ci, H, W):
+            x = pre.pop()                  # dense condition channels filled by cond_pyramid at the start of the step
+            x.record_stream(torch.cuda.current_stream(x.device))
+        else:
+            x = torch.empty((B, Cd + Ci, H, W), dtype=torch.float32, device=image.device)
+            if Cd:
+                lib.him_copy_channels(_p(cond.dense), Cd, 0, _p(x), Cd + Ci, 0, Cd, B, H * W, 0, 0, 0, st)
+        lib.him_copy_channels(_p(image), Ci, 0, _p(x), Cd + Ci, Cd, Ci, B, H * W, 0, 0, 0, st)
+        label = cond.label
+        d = _ids_conv_desc(label, w, stride, pad, PAD_ZERO, act, slope)
+        y = torch.empty((d.B, d.Cout, d.OH, d.OW), dtype=torch.float32, device=x.device)
+        nb = lib.him_conv2d_onehot_fwd_ws(ctypes.byref(d), NC)
+        ws = _ws(nb, x)
+        lib.him_conv2d_onehot_fwd_dense(ctypes.byref(d), _p(label), NC, _p(x), _p(w), _p(b), _p(y), _p(ws), nb, st)
+        ctx.d, ctx.NC, ctx.Cc, ctx.Ci = d, NC, NC + Cd, Ci
+        ctx.x, ctx.label, ctx.w, ctx.b = x, label, w, b
+        ctx.save_for_backward(y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if dy is None:
+            return (None,) * 8
+        d, x, label, w, b, Cc, Ci = ctx.d, ctx.x, ctx.label, ctx.w, ctx.b, ctx.Cc, ctx.Ci
+        dy = dy.contiguous()
+        st = _stream()
+        if d.act != ACT_NONE:
+            dz = torch.empty_like(dy)
+            lib.him_act_bwd(_p(ctx.saved_tensors[0]), _p(dy), _p(dz), dy.numel(), d.act, d.slope, st)
+        else:
+            dz = dy
+        dimg = dw = db = None
+        if ctx.needs_input_grad[1] and _wkey(w) not in SKIP_DGRAD:
+            d2 = HimConv2d.from_buffer_copy(d)
+            d2.Cin = Ci
+            dimg = torch.empty((d.B, Ci, d.H, d.W), dtype=torch.float32, device=x.device)
+            wsl = w.detach()[:, Cc:].contiguous()
+            nb = lib.him_conv2d_bwd_data_ws(ctypes.byref(d2))
+            ws = _ws(nb, x)
+            lib.him_conv2d_bwd_data(ctypes.byref(d2), _p(dz), _p(wsl), _p(dimg), _p(ws), nb, st)
+        skip_w = _wkey(w) in SKIP_WGRAD
+        need_w = ctx.needs_input_grad[2] and not skip_w
+        need_b = b is not None and ctx.needs_input_grad[3] and not skip_w
+        if need_w or need_b:
+            nb = lib.him_conv2d_onehot_bwd_weight_ws(ctypes.byref(d), ctx.NC)
+            if need_w and _direct(w) and (not need_b or _direct(b)):
+                with _wgrad_stream(x, dz, label):
+                    ws = _ws(nb, x)
+                    lib.him_conv2d_onehot_bwd_weight_dense(ctypes.byref(d), _p(label), ctx.NC, _p(x), _p(dz), _p(w.grad),
+                                                           _p(b.grad) if need_b else 0, 1, _p(ws), nb, _stream())
+                    _notify(w)
+                    if need_b:
+                        _notify(b)
+            else:
+                ws = _ws(nb, x)
+                dw = torch.empty_like(w) if need_w else None
+                db = torch.empty_like(b) if need_b else None
+                lib.him_conv2d_onehot_bwd_weight_dense(ctypes.byref(d), _p(label), ctx.NC, _p(x), _p(dz), _p(dw), _p(db), 0,
+                                                       _p(ws), nb, st)
+        return None, dimg, dw, db, None, None, None, None
+
+
 def cond_image_conv2d(cond, image, w, b=None, stride=1, pad=0, act='none', slope=0.2):
     """The first PatchGAN convolution on a ``CondImage`` pair (see there)."""
+    if isinstance(cond, LabelCond):
+        d = _ids_conv_desc(cond.label, w, stride, pad, PAD_ZERO, ACTS[act], float(slope))
+        if (SCHED.d_from_ids and w.shape[1] == cond.shape[1] + image.shape[1]
+                and lib.him_conv2d_onehot_fwd_ws(ctypes.byref(d), cond.n_onehot)):
+            return _IdsCondImageConv2d.apply(cond, image, w, b, stride, pad, ACTS[act], float(slope))
+        cond = cond.full()
     return _CondImageConv2d.apply(cond, image, w, b, stride, pad, ACTS[act], float(slope))
 
 
@@ -947,7 +1160,8 @@ def conv2d_in_act(x, w, b=None, stride=1, pad=0, pad_mode='zero', eps=1e-5, act=
     """act(InstanceNorm2d(affine=False)(conv2d(pad(x), w) + b)) [+ residual]: ONE library call
     (him_conv2d_in_act_fwd) where the convolution is a split-K launch, conv2d + instance_norm otherwise."""
     pm = PAD_REFLECT if pad_mode == 'reflect' else PAD_ZERO
-    if SCHED.conv_in_fused and getattr(x, '_him_onehot', None) is None and not getattr(w, '_him_frozen', False):
+    if (SCHED.conv_in_fused and not isinstance(x, LabelCond) and getattr(x, '_him_onehot', None) is None
+            and not getattr(w, '_him_frozen', False)):
         d = _conv_desc(x, w, stride, pad, pm, ACT_NONE, 0.0)
         if lib.him_conv2d_in_act_fused(ctypes.byref(d)):
             return _Conv2dIN.apply(x, w, b, stride, pad, pm, float(eps), ACTS[act], float(slope), residual)
@@ -1242,6 +1456,8 @@ class _AvgPool3s2(torch.autograd.Function):
 
 def avgpool3s2(x):
     """nn.AvgPool2d(3, stride=2, padding=1, count_include_pad=False)."""
+    if isinstance(x, LabelCond):
+        return x.pooled()
     y = _AvgPool3s2.apply(x)
     gs = getattr(x, '_him_grad_slice', None)
     if gs is not None:
@@ -1321,6 +1537,7 @@ class _CatMask(torch.autograd.Function):
 
 
 def cat_channels(tensors, mask=None, mask_mode=0):
+    tensors = [t.full() if isinstance(t, LabelCond) else t for t in tensors]
     out = _CatMask.apply(mask, int(mask_mode if mask is not None else 0), *tensors)
     need = [bool(t.requires_grad) for t in tensors]
     if torch.is_grad_enabled() and any(need) and not all(need):
@@ -1376,6 +1593,11 @@ class _Blend(torch.autograd.Function):
 
 
 def blend(a, b, m, a0=0):
+    if isinstance(a, LabelCond):
+        if a0 >= a.n_onehot:        # the channels read are dense ones (the output gate reads the image out of the G input)
+            a, a0 = a.dense, a0 - a.n_onehot
+        else:
+            a = a.full()
     return _Blend.apply(a, int(a0), b, m)
 
 
@@ -1401,16 +1623,29 @@ def add(a, b):
 # ------------------------------------------------------------------------------------------------
 # input encoding (no gradients)
 # ------------------------------------------------------------------------------------------------
-def encode_channels(label, inst, image, mask_in, label_nc, use_edges, extra_after=0, color_emb=None):
+def encode_channels(label, inst, image, mask_in, label_nc, use_edges, extra_after=0, color_emb=None, lazy=False):
     """Builds, in ONE (B, Ctot, H, W) buffer and without any torch.cat,
          [ one-hot(label) | edges(inst)? | (1-mask)*image | emb*mask ? ]
-    (reference encode_input + the torch.cat at pix2pixHD_condImg_model.py:204).  Returns (buf, n_label, n_cond)."""
+    (reference encode_input + the torch.cat at pix2pixHD_condImg_model.py:204).  Returns (buf, n_label, n_cond).
+    ``lazy`` (label_nc > 0): ``buf`` is a ``LabelCond`` -- the id map + the dense channels; the one-hot block is written
+    only if a consumer asks for it (``LabelCond.full``)."""
     _chk(label, inst, image, mask_in, color_emb)
     B, _, H, W = image.shape
     hw = H * W
     n_label = (label_nc if label_nc else label.shape[1]) + (1 if use_edges else 0)
     n_cond = 3 + (3 if color_emb is not None else 0)
     Ctot = n_label + n_cond
+    if lazy and label_nc:
+        Cd = Ctot - label_nc
+        dense = torch.empty((B, Cd, H, W), dtype=torch.float32, device=image.device)
+        st, c = _stream(), 0
+        if use_edges:
+            lib.him_edges(_p(inst), _p(dense), B, H, W, Cd, 0, st)
+            c = 1
+        lib.him_copy_channels(_p(image), 3, 0, _p(dense), Cd, c, 3, B, hw, _p(mask_in), 2, 0, st)
+        if color_emb is not None:
+            lib.him_tile_embed(_p(color_emb), _p(mask_in), _p(dense), B, Cd, c + 3, hw, st)
+        return LabelCond(label.contiguous(), label_nc, dense), n_label, n_cond
     buf = torch.empty((B, Ctot, H, W), dtype=torch.float32, device=image.device)
     st = _stream()
     if label_nc:
@@ -1433,6 +1668,8 @@ def encode_channels(label, inst, image, mask_in, label_nc, use_edges, extra_afte
 
 def slice_channels(x, c0, n):
     """contiguous copy of x[:, c0:c0+n] (no gradient)."""
+    if isinstance(x, LabelCond):
+        return x.slice(c0, n)
     _chk(x)
     B, Cn, H, W = x.shape
     out = torch.empty((B, n, H, W), dtype=torch.float32, device=x.device)
@@ -1623,7 +1860,13 @@ def lincomb(terms, weights=None, scale=1.0):
         for w, t in zip(ws, terms):
             acc = acc + (t if w == 1.0 else t * w)
         return acc if scale == 1.0 else acc * scale
-    return _LinComb.apply(tuple(weights) if weights is not None else (1.0,) * len(terms), scale, *terms)
+    ws = tuple(weights) if weights is not None else (1.0,) * len(terms)
+    # him_lincomb_* take at most 8 terms per launch: longer sums (--num_D > 8) fold 8 at a time, left to right -- the
+    # running sum enters the next launch as its first term with weight 1 (x * 1.0 is exact: same rounding as one chain)
+    while len(terms) > 8:
+        head = _LinComb.apply(ws[:8], 1.0, *terms[:8])
+        terms, ws = [head] + terms[8:], (1.0,) + ws[8:]
+    return _LinComb.apply(ws, scale, *terms)
 
 
 class _MSEConst(torch.autograd.Function):

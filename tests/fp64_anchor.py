@@ -40,16 +40,25 @@ def default_dtype(dt):
         torch.set_default_dtype(prev)
 
 
-def make_oracle(flags, dtype=torch.float32):
-    """oracle/ref_cpu.Mask2ImageModel with the build's seeded weights (G 1, D 2, VGG 3), in fp32 or fp64."""
+def make_oracle(flags, dtype=torch.float32, device='cpu'):
+    """oracle/ref_cpu.Mask2ImageModel with the build's seeded weights (G 1, D 2, VGG 3), in fp32 or fp64.
+    ``device='cuda'`` (float64 only): the ANCHOR step runs through torch's own double-precision operators on the GPU --
+    the same oracle code, the same float64 arithmetic, a summation order that differs from the host's at the 1e-15 level
+    (tests/test_model_gpu.py::test_float64_anchor_on_the_gpu_equals_the_host_anchor).  The fp32 oracle -- the thing the
+    HIP path is compared with -- always runs on the host."""
     from oracle import ref_cpu
     from neurips18_hierchical_image_manipulation_amd import synth
+    if device != 'cpu' and dtype != torch.float64:
+        raise ValueError('only the float64 anchor may leave the host: the fp32 oracle is pinned to the reference on the CPU')
     with default_dtype(dtype):
         om = ref_cpu.Mask2ImageModel(ref_cpu.Opt(**flags))
+    om.anchor_device = torch.device(device)
     om.netG.load_state_dict(synth.init_state_dict(om.netG.state_dict(), 1))
     om.netD.load_state_dict(synth.init_state_dict(om.netD.state_dict(), 2))
     if om.vgg is not None:
         om.vgg.load_state_dict(synth.init_state_dict(om.vgg.state_dict(), 3, 'vgg'))
+    if device != 'cpu':
+        om.to(device)       # before the first optimizer step: the Adams hold the same Parameter objects
     return om
 
 
@@ -65,8 +74,10 @@ def adopt64(om64, om):
 
 
 def step64(om64, batch, **kw):
-    with default_dtype(torch.float64):
-        b = type(batch)((k, v.double() if torch.is_floating_point(v) else v) for k, v in batch.items())
+    dev = getattr(om64, 'anchor_device', torch.device('cpu'))
+    # torch.device as a context: the oracle's factory calls (torch.zeros(...) for the one-hot / empty loss terms) land there
+    with default_dtype(torch.float64), dev:
+        b = type(batch)((k, (v.double() if torch.is_floating_point(v) else v).to(dev)) for k, v in batch.items())
         return om64.optimize_parameters(b, **kw)
 
 
@@ -90,7 +101,7 @@ def oracle_quantities(om, before):
         for name, p in net.named_parameters():
             st = opt.state[p]
             out['%s/%s' % (tag, name)] = dict(grad=p.grad, exp_avg=st['exp_avg'], exp_avg_sq=st['exp_avg_sq'],
-                                              delta=p.detach().double() - before[tag][name].double())
+                                              delta=p.detach().double() - before[tag][name].double().to(p.device))
     return out
 
 

@@ -1,6 +1,7 @@
 """-m gpu: every HIP op (through the C ABI) against the fp32 CPU oracle building blocks (torch.nn.functional
 on the CPU -- the exact ops the reference executes), forward and backward, on the layer shapes of the path:
 odd PatchGAN sizes, Cin 38/41, Cout 3/1, reflect pads, stride-2 phases, split-K wgrad."""
+import ctypes
 import pytest
 import torch
 import torch.nn.functional as F
@@ -453,6 +454,37 @@ def test_winograd_f4x4_frozen_conv_fwd_and_gated_dgrad(case):
         assert torch.equal(got[True], got[False]), 'F(4x4) selected for fewer than 64 tiles (him_conv_wino4.inc: wino4_shape_ok)'
 
 
+def test_cached_panel_follows_the_layout_the_library_picks_for_each_shape():
+    """ONE frozen VGG weight called with a shape that takes Winograd F(4x4,3x3) (36-position panel) and then
+    with shapes that leave it -- the last, smaller batch of an epoch (B = 1: fewer than 64 real tiles), a plane with
+    H % 4 != 0 -- and back.  The panel cache on the parameter must hold one panel per LAYOUT (him_conv2d_panel_layout): every
+    call against the fp32 torch reference, forward and gated data gradient, in both orders of first use."""
+    ops = _ops()
+    Cin = Cout = 256
+    w = _rand(Cout, Cin, 3, 3, seed=2, scale=(Cin * 9) ** -0.5)
+    b = _rand(Cout, seed=3, scale=0.1)
+    shapes = [(8, 16, 32), (1, 16, 32), (8, 18, 32), (8, 16, 32), (2, 8, 8)]      # (B, H, W)
+    for order in (shapes, shapes[::-1]):
+        wd = torch.nn.Parameter(w.to(DEV), requires_grad=False)
+        wd._him_frozen = True
+        layouts = set()
+        for (B, H, W) in order:
+            xin = torch.relu(_rand(B, Cin, H, W, seed=B + H)).requires_grad_(True)
+            y_ref = _ref_conv(xin, w, b, 1, 1, 'zero', 'none')
+            gy = _rand(*y_ref.shape, seed=4)
+            (gx_ref,) = torch.autograd.grad(y_ref, xin, gy)
+            gx_ref = gx_ref * (xin.detach() > 0)
+            xd = xin.detach().to(DEV).requires_grad_(True)
+            y = ops.conv2d(xd, wd, b.to(DEV), 1, 1, 'zero', 'none', 0.2, gate_dx=True)
+            (gx,) = torch.autograd.grad(y, xd, gy.to(DEV))
+            assert_close('fwd %s' % ((B, H, W),), y, y_ref, rtol=3e-5)
+            assert_close('gated dgrad %s' % ((B, H, W),), gx, gx_ref, rtol=3e-5)
+            d = ops._conv_desc(xd, wd, 1, 1, 0, 0, 0.2, frozen=True)
+            layouts.add(int(ops.lib.him_conv2d_panel_layout(ctypes.byref(d), 0)))
+        assert 4 in layouts and len(layouts) >= 2, 'the shapes must cross the F(4x4) boundary: %s' % layouts
+        assert len(wd._him_panels) >= 3, 'one cached panel per (kind, layout): %s' % [k[:3] for k in wd._him_panels]
+
+
 def test_conv_source_tensor_above_2_gib_is_sliced_along_the_batch():
     """Buffer-resource addressing caps ONE launch's source tensor at 2 GiB (31-bit byte offsets); C2 at >= 64 images per
     GPU crosses it on the 64-channel full-resolution planes.  The dispatch then slices the batch: forward and
@@ -872,3 +904,112 @@ def test_piecewise_adam_step_is_bit_identical_to_the_whole_step():
         assert torch.equal(oa.exp_avg, ob.exp_avg) and torch.equal(oa.exp_avg_sq, ob.exp_avg_sq)
     with pytest.raises(RuntimeError):
         ob.step_range(0, 10)                             # outside begin_step() ... step()
+
+
+@pytest.mark.parametrize('n', [1, 3, 8, 9, 19])
+def test_scalar_loss_arithmetic_in_one_launch_matches_the_torch_chain(n):
+    """ops.lincomb = the trainer's scalar loss arithmetic (train_mask2image.py:70-71, the per-scale GAN sums of
+    models/losses.py:30-38): scale * (w0 t0 + w1 t1 + ...) left to right in fp32.  him_lincomb_* take 8 terms per launch;
+    longer sums (--num_D > 8) fold 8 at a time.  Value and every term's gradient bit-identical to the chain of
+    one-element fp32 torch ops on the host."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(n)
+    vals = [(torch.randn((), generator=g) * 3).requires_grad_(True) for _ in range(n)]
+    ws = [1.0 if i % 3 == 0 else float(torch.randn((), generator=g)) for i in range(n)]
+    acc = 0
+    for w, t in zip(ws, vals):
+        acc = acc + (t if w == 1.0 else t * w)
+    ref = acc * 0.5
+    ref.backward()
+    dv = [v.detach().to(DEV).requires_grad_(True) for v in vals]
+    out = ops.lincomb(dv, ws, scale=0.5)
+    out.backward()
+    assert float(out) == float(ref), (float(out), float(ref))
+    for i, (a, b) in enumerate(zip(dv, vals)):
+        assert float(a.grad) == float(b.grad), (i, float(a.grad), float(b.grad))
+
+
+def _label_blocks(B, H, W, NC, block, seed):
+    """piecewise-constant id map (blocks of ``block`` pixels, some ids outside [0, NC) -> all-zero one-hot column)."""
+    g = torch.Generator().manual_seed(seed)
+    small = torch.randint(0, NC, (B, 1, (H + block - 1) // block, (W + block - 1) // block), generator=g).float()
+    lab = small.repeat_interleave(block, 2).repeat_interleave(block, 3)[:, :, :H, :W].contiguous()
+    lab[:, :, H // 3, : W // 2] = float(NC + 3)       # ids outside the range select nothing (him_onehot semantics)
+    return lab
+
+
+D_IDS_CASES = [
+    # B, NC, Cd (dense condition channels), H, W, Cout, label block  -- the first PatchGAN conv: 4x4, stride 2, pad 2
+    (8, 35, 3, 256, 512, 64, 16),    # C2 scale 0: 41 -> 64 at 256x512 -> 129x257
+    (2, 35, 4, 64, 96, 64, 5),       # edges + image condition, odd runs
+    (3, 49, 0, 33, 47, 32, 1),       # no dense condition channel (--no_imgCond), odd plane, per-pixel noise labels
+    (1, 8, 3, 16, 1000, 16, 7),      # wide rows (16 dy columns per lane), few classes
+]
+
+
+@pytest.mark.parametrize('case', D_IDS_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_first_patchgan_conv_from_label_ids_matches_the_dense_conv(case):
+    """Round 5 (second half): nn.Conv2d(input_nc, ndf, 4, stride 2, padding 2) + LeakyReLU of
+    Discriminator_NET.py:71-74 on cat(one-hot(label) | dense condition | image) (pix2pixHD_condImg_model.py:176-186) evaluated
+    from the ids -- ops.cond_image_conv2d on an ops.LabelCond -- against F.conv2d on the materialised concatenation (fp32 CPU):
+    forward, weight / bias gradient, the image's data gradient; deterministic run to run; and the materialised HIP path
+    (ops.LabelCond.full -> the MFMA kernels) agrees with both."""
+    ops = _ops()
+    B, NC, Cd, H, W, Cout, block = case
+    lab = _label_blocks(B, H, W, NC, block, seed=5)
+    dense = _rand(B, Cd, H, W, seed=6) if Cd else None
+    img = _rand(B, 3, H, W, seed=7).requires_grad_(True)
+    Cin = NC + Cd + 3
+    w = (_rand(Cout, Cin, 4, 4, seed=8) * 0.05).requires_grad_(True)
+    b = (_rand(Cout, seed=9) * 0.1).requires_grad_(True)
+    onehot = torch.zeros(B, NC, H, W)
+    valid = (lab >= 0) & (lab < NC)
+    onehot.scatter_(1, lab.clamp(0, NC - 1).long(), valid.float())
+    xin = torch.cat([onehot] + ([dense] if Cd else []) + [img], 1)
+    y_ref = F.leaky_relu(F.conv2d(xin, w, b, 2, 2), 0.2)
+    gy = _rand(*y_ref.shape, seed=4)
+    gw_ref, gb_ref, gi_ref = torch.autograd.grad(y_ref, (w, b, img), gy)
+
+    def run(from_ids):
+        from neurips18_hierchical_image_manipulation_amd import config
+        with config.schedule(d_from_ids=from_ids):
+            cond = ops.LabelCond(lab.to(DEV), NC, dense.to(DEV) if Cd else None)
+            wd, bd, imd = (t.detach().to(DEV).requires_grad_(True) for t in (w, b, img))
+            y = ops.cond_image_conv2d(cond, imd, wd, bd, 2, 2, 'lrelu', 0.2)
+            assert y.grad_fn.__class__.__name__.startswith('_IdsCondImageConv2d' if from_ids else '_CondImageConv2d')
+            return (y,) + torch.autograd.grad(y, (wd, bd, imd), gy.to(DEV))
+
+    got = run(True)
+    for name, a, r in zip(('fwd', 'wgrad', 'bgrad', 'image dgrad'), got, (y_ref, gw_ref, gb_ref, gi_ref)):
+        assert_close('D layer 0 from ids: ' + name, a, r, rtol=2e-5)
+    again = run(True)
+    assert all(torch.equal(a, c) for a, c in zip(got, again)), 'the ids path must be run-to-run deterministic'
+    mat = run(False)
+    for name, a, c in zip(('fwd', 'wgrad', 'bgrad', 'image dgrad'), got, mat):
+        assert_close('ids vs materialised HIP path: ' + name, a, c.cpu(), rtol=2e-5)
+
+
+@pytest.mark.parametrize('shape', [(8, 35, 3, 256, 512), (2, 49, 6, 33, 47), (1, 5, 0, 2, 3)], ids=str)
+def test_label_cond_full_and_pooled_equal_the_materialised_tensors(shape):
+    """ops.LabelCond: full() == [him_onehot | dense] and pooled() -- the one-hot channels as 3x3 class counts straight from
+    the ids (him_onehot_pool3s2) -- is BIT-identical to AvgPool2d(3, 2, 1, count_include_pad=False) of the materialised
+    tensor (sums of 0 / 1 are exact), on the HIP pool and on torch's; slices follow the reference's channel order."""
+    ops = _ops()
+    B, NC, Cd, H, W = shape
+    lab = _label_blocks(B, H, W, NC, 3, seed=1)
+    dense = _rand(B, Cd, H, W, seed=2) if Cd else None
+    cond = ops.LabelCond(lab.to(DEV), NC, dense.to(DEV) if Cd else None)
+    onehot = torch.zeros(B, NC, H, W)
+    onehot.scatter_(1, lab.clamp(0, NC - 1).long(), ((lab >= 0) & (lab < NC)).float())
+    full_ref = torch.cat([onehot] + ([dense] if Cd else []), 1)
+    assert tuple(cond.shape) == tuple(full_ref.shape)
+    assert torch.equal(cond.full().cpu(), full_ref)
+    pooled = cond.pooled()
+    assert torch.equal(pooled, ops.avgpool3s2(cond.full()))
+    assert_close('pooled vs torch', pooled, F.avg_pool2d(full_ref, 3, 2, 1, count_include_pad=False), rtol=1e-6)
+    assert torch.equal(ops.cond_pyramid(cond, 3)[2], ops.avgpool3s2(ops.avgpool3s2(cond.full())))
+    if Cd:
+        assert torch.equal(ops.slice_channels(cond, NC, Cd).cpu(), dense)
+        head = ops.slice_channels(cond, 0, NC + 1)
+        assert isinstance(head, ops.LabelCond) and torch.equal(head.full().cpu(), full_ref[:, :NC + 1])
+    assert torch.equal(ops.slice_channels(cond, 1, NC - 1).cpu(), full_ref[:, 1:NC])

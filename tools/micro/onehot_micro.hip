@@ -25,13 +25,13 @@ int main(int argc, char** argv) {
   hipMalloc(&dl, lab.size() * 4); hipMalloc(&dy, hy.size() * 4); hipMalloc(&part, (size_t)nblk * KS * KS * NC * Cout * 4);
   hipMemcpy(dl, lab.data(), lab.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(dy, hy.data(), hy.size() * 4, hipMemcpyHostToDevice);
-  OneHotP p; p.label = dl; p.B = B; p.H = H; p.W = W; p.NC = NC; p.KS = KS; p.pad = pad; p.reflect = 1; p.Cout = Cout; p.npix = B * H * W;
+  OneHotP p; p.label = dl; p.B = B; p.H = H; p.W = W; p.NC = NC; p.KS = KS; p.pad = pad; p.reflect = 1; p.Cout = Cout; p.npix = B * H * W; p.stride = 1; p.OH = H; p.OW = W;
   const size_t lds = (size_t)8 * (W + 1) * 8 + (size_t)KS * KS * NC * 8 * 4 + (size_t)(KS + 1) * (W + 2 * pad + 2) * 4 + 64;
-  hipFuncSetAttribute((const void*)onehot_wgrad_rle_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipFuncSetAttribute((const void*)onehot_wgrad_rle_kernel<7, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((onehot_wgrad_rle_kernel<7>), dim3(nblk, Cout / 8), dim3(512), lds, 0, p, dy, part, nbands, rows_per);
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((onehot_wgrad_rle_kernel<7, 1>), dim3(nblk, Cout / 8), dim3(512), lds, 0, p, dy, part, nbands, rows_per);
   hipEventRecord(e0, 0);
-  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((onehot_wgrad_rle_kernel<7>), dim3(nblk, Cout / 8), dim3(512), lds, 0, p, dy, part, nbands, rows_per);
+  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((onehot_wgrad_rle_kernel<7, 1>), dim3(nblk, Cout / 8), dim3(512), lds, 0, p, dy, part, nbands, rows_per);
   hipEventRecord(e1, 0); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   printf("onehot_wgrad_rle (skip mask %d, %dx%d label blocks, %d bands): %.4f ms  (%s)\n", HIM_OH_SKIP, blockpx, blockpx, nbands, ms / 10, hipGetErrorString(hipGetLastError()));
