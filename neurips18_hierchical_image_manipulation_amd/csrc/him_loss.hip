@@ -156,9 +156,17 @@ struct LinComb {
   float scale;
 };
 __global__ void lincomb_fwd_kernel(const LinComb p, float* __restrict__ out) {
+  // every product and every sum rounded on its own, as the reference's chain of one-element torch ops: hipcc's default
+  // -ffp-contract=fast fused __fadd_rn(acc, __fmul_rn(w, t)) into v_fma_f32 all the same (round 5: a 9-term sum came out one
+  // ulp off the fp32 chain, tests/test_ops_gpu.py::test_scalar_loss_arithmetic_...; `#pragma clang fp contract(off)` is
+  // ignored under that mode) -- the product passes through an empty asm, which the optimizer cannot look through
   if (threadIdx.x) return;
   float acc = 0.f;
-  for (int i = 0; i < p.n; ++i) acc = __fadd_rn(acc, __fmul_rn(p.w[i], p.t[i][0]));
+  for (int i = 0; i < p.n; ++i) {
+    float prod = __fmul_rn(p.w[i], p.t[i][0]);
+    asm volatile("" : "+v"(prod));
+    acc = __fadd_rn(acc, prod);
+  }
   out[0] = __fmul_rn(acc, p.scale);
 }
 __global__ void lincomb_bwd_kernel(const LinComb p, const float* __restrict__ g) {

@@ -61,7 +61,7 @@ class GradReducer(object):
     """
 
     def __init__(self, flat, ranges, bucket_bytes=64 << 20, group=None, force=False, comm_stream=None, fake=False,
-                 local=False):
+                 local=False, tail_bytes=8 << 20):
         """``comm_stream``: the stream the collectives are enqueued on (default: a stream of this reducer's own).  The
         trainers pass their optimizer streams -- idle during the backward pass, and the optimizer step that follows the
         exchange runs there anyway -- so that N > 1 ranks run the SAME number of streams / hardware queues as one rank
@@ -70,7 +70,13 @@ class GradReducer(object):
         its bytes on the comm stream at the real trigger point -- the scheduling and HBM cost of the exchange without a
         second GPU; gradients are left untouched.
         ``local``: no exchange at all (one rank) -- the reducer only tracks which gradient buckets are final and calls
-        ``bucket_hook(b, start, end)`` on the comm stream behind them (the trainers hang the bucket's Adam step there)."""
+        ``bucket_hook(b, start, end)`` on the comm stream behind them (the trainers hang the bucket's Adam step there).
+        ``tail_bytes`` (round 5): the LAST bucket to become final -- the first parameters of the network, whose weight
+        gradients close the backward pass -- is the one collective nothing can hide (the optimizer step waits for it, the
+        next generator forward for the optimizer step).  Cut in reverse order, that bucket is whatever is left over, up to
+        ``bucket_bytes`` (58 MB of the generator's 730 MB at C2: 0.66 ms on one 153 GB/s ring link).  It is split on a
+        parameter boundary so that the final piece holds at most ``tail_bytes`` (C2: stem + the first three down-convolutions,
+        6.3 MB = 0.07 ms); the rest of it becomes final ~3 ms earlier."""
         self.flat, self.group = flat, group
         self.fake = bool(fake)
         self.local = bool(local)
@@ -94,6 +100,16 @@ class GradReducer(object):
                 start = None
         if start is not None:
             self.buckets.append((start, end, n))
+        if tail_bytes and self.buckets and (self.buckets[-1][1] - self.buckets[-1][0]) * 4 > tail_bytes:
+            s0, e0, _ = self.buckets[-1]
+            inside = [r for r in self.ranges if s0 <= r[0] and r[1] <= e0]          # forward order
+            cut = next((i for i, r in enumerate(inside) if (r[1] - s0) * 4 > tail_bytes), len(inside))
+            if 0 < cut < len(inside):
+                mid = inside[cut][0]
+                self.buckets[-1] = (mid, e0, len(inside) - cut)
+                self.buckets.append((s0, mid, cut))
+                for r in inside[:cut]:
+                    self.range_to_bucket[r] = len(self.buckets) - 1
         self.on_gpu = flat.is_cuda
         self.comm_stream = (comm_stream or torch.cuda.Stream(device=flat.device)) if self.on_gpu else None
         self.scratch = torch.empty(min(cap, flat.numel()) + 64, dtype=flat.dtype, device=flat.device) if self.fake else None

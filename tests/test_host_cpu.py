@@ -444,22 +444,30 @@ flat = torch.zeros(off)
 params = []
 for r in ranges:
     p = P(); p._him_arena_range = r; params.append(p)
-red = GradReducer(flat, ranges, bucket_bytes=4 * 128)
-red.attach(params)
-assert len(red.buckets) >= 3 and red.buckets[0][1] == ranges[-1][1]
-for step in range(3):
-    flat.zero_()
-    red.begin(contributions=2)
-    for rep in range(2):
-        for p in reversed(params):                       # backward order, two contributions each
-            s, e = p._him_arena_range
-            flat[s:e] += (rank + 1) * (step + 1) * torch.arange(e - s, dtype=torch.float32)
-            red.on_param(p)
-    red.finish()
-    for (s, e) in ranges:                                # avg over ranks of 2*(rank+1)*(step+1)*i
-        exp = 2 * 1.5 * (step + 1) * torch.arange(e - s, dtype=torch.float32)
-        assert torch.allclose(flat[s:e], exp), (rank, step, s, e)
-assert all(red.launched)
+# second configuration: the left-over bucket (the FIRST parameters, final last) is split so that its tail piece is small
+for bucket_bytes, tail_bytes in ((4 * 128, 8 << 20), (4 * 200, 4 * 100)):
+    red = GradReducer(flat, ranges, bucket_bytes=bucket_bytes, tail_bytes=tail_bytes)
+    red.attach(params)
+    assert len(red.buckets) >= 3 and red.buckets[0][1] == ranges[-1][1]
+    if tail_bytes < 1000:
+        assert red.buckets[-2:] == [(64, 195, 2), (0, 64, 1)], red.buckets
+    covered = sorted((s, e) for s, e, _ in red.buckets)
+    assert covered[0][0] == 0 and all(a[1] <= b[0] for a, b in zip(covered, covered[1:])) and covered[-1][1] == ranges[-1][1]
+    assert all(any(s <= r[0] and r[1] <= e for s, e, _ in red.buckets) for r in ranges)
+    assert sum(n for _, _, n in red.buckets) == len(ranges)
+    for step in range(3):
+        flat.zero_()
+        red.begin(contributions=2)
+        for rep in range(2):
+            for p in reversed(params):                       # backward order, two contributions each
+                s, e = p._him_arena_range
+                flat[s:e] += (rank + 1) * (step + 1) * torch.arange(e - s, dtype=torch.float32)
+                red.on_param(p)
+        red.finish()
+        for (s, e) in ranges:                                # avg over ranks of 2*(rank+1)*(step+1)*i
+            exp = 2 * 1.5 * (step + 1) * torch.arange(e - s, dtype=torch.float32)
+            assert torch.allclose(flat[s:e], exp), (rank, step, s, e)
+    assert all(red.launched)
 print('RANK%%d OK' %% rank)
 '''
 

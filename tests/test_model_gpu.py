@@ -287,8 +287,18 @@ def _post_step_state_errors(model, om, before):
 # D/scale0_layer0) -> K_EVENT stays one decade, but the C1 run is repeated on a SECOND, independent batch sequence so that
 # one draw of the event lottery cannot decide.  Losses 9e-7 -> 5e-6; Adam moments 1.7e-7 -> 1e-6, update 1.25e-4 -> 2.5e-4.
 # In addition to the lower quartile, the MEDIAN over the steps is bounded (2x the quartile's K against the oracle's median)
-# for every tensor whose oracle distances are unimodal: a defect present in half of the steps cannot pass (see the comment
-# at the assertion for the bimodal discriminator tensors).
+# for every tensor whose oracle distances are unimodal: a defect present in half of the steps cannot pass.
+# Round 5.  (1) The float64 step runs on the GPU (tests/fp64_anchor.py make_oracle(device='cuda'): the oracle's own code
+# through torch's double-precision operators, 1.1 s instead of 57 s per C2 step, 7e-14 from the host's float64 step,
+# test_float64_anchor_on_the_gpu_equals_the_host_anchor); every BASELINE configuration now runs >= 6 anchored steps (C1: all
+# 20, C2 6, C4 at bs 16: 6, LocalEnhancer at 512x256 bs 8: 6) and the whole GPU suite takes ~13 min instead of 15.5.
+# (2) BIMODAL tensors -- the discriminator's: the oracle's own distances span more than 30x, baseline 1e-6 or an event of
+# 1e-4..1e-3 -- are bounded by their MINIMUM over the samples instead of the lower quartile: at full size an event strikes
+# most steps on either side (C4 bs 16, first 6 steps: HIP 5 of 6, oracle 3-4 of 6; LocalEnhancer D/scale1_layer1: 6 of 6 / 5
+# of 6), so a quantile of a handful of steps is a lottery between the modes while a kernel defect raises the baseline of
+# EVERY step; when the regular steps hold no baseline-level HIP sample of some bimodal tensor, extra (HIP step, float64 step)
+# samples are drawn from the oracle's current state on fresh batches (~1.5 s each, no fp32 host step) until one appears --
+# at most 40, after which the bound fails.  Unimodal tensors (every generator tensor) keep quartile + median.
 PARITY_K_TYPICAL, PARITY_K_TYPICAL_WINOGRAD, PARITY_K_EVENT, PARITY_FLOOR = 4.0, 6.0, 10.0, 1e-5
 PARITY_LOSS_TOL = 5e-6
 ADAM_TOL = dict(exp_avg=1e-6, exp_avg_sq=1e-6, delta=2.5e-4)    # measured worst over 20 C1 steps: 1.7e-7 / 8.3e-8 / 1.25e-4
@@ -296,6 +306,14 @@ ADAM_TOL = dict(exp_avg=1e-6, exp_avg_sq=1e-6, delta=2.5e-4)    # measured worst
 # layers take a Winograd form) and recorded in every report -- not whatever a process environment would select.
 PINNED_ALGO = dict(wino_min_c=256, wino_fused_min_c=64, wino_fused_max_c=255, ksplit_max=8, tile_wb=4, tile_nb=4,
                    wino_tblock=64, wgrad_splits=0, disable=0)
+
+
+def _unimodal(oracle_sorted):
+    """The oracle's own distances from float64 show ONE level for this tensor: every sample above the floor and within 30x
+    of the smallest (every full-size generator tensor: 1e8 activations put an fp32 event into every step).  Anything else --
+    a baseline below the floor, with or without events among the samples (the discriminator's tensors: 1e-6 or 1e-4..1e-3)
+    -- is bounded through its baseline (minimum over the samples), not through a quantile."""
+    return oracle_sorted[0] >= PARITY_FLOOR and oracle_sorted[-1] <= 30.0 * oracle_sorted[0]
 
 
 def _quartile(vals):
@@ -407,6 +425,39 @@ def _teacher_forced_run(tag, steps, loss_tol, anchor, golden, batch_fn, plumbing
                                     'delta': fa.rel_l2(q_hip[n]['delta'], q64[n]['delta'])} for n in live})
             e_32_steps.append({n: {'grad': fa.rel_l2(q32[n]['grad'], q64[n]['grad']),
                                    'delta': fa.rel_l2(q32[n]['delta'], q64[n]['delta'])} for n in live})
+    # ---- extra float64 samples for the BIMODAL tensors (round 5) ---------------------------------------------------------
+    # A discriminator tensor's distance from float64 is either at its rounding baseline (1e-6) or at an event (1e-4..1e-3),
+    # and at full size an event strikes most steps on EITHER side (C4 bs 16: HIP 5 of 6, oracle 3-4 of 6; LocalEnhancer
+    # D/scale1_layer1: HIP 6 of 6, oracle 5 of 6): no quantile of 6 steps separates "same baseline, unlucky draw" from "raised
+    # baseline".  What a kernel defect raises is the BASELINE -- it is there in every step -- so for these tensors the bound is
+    # on the MINIMUM over the samples, and samples are cheap now: a HIP step + the float64 step on the GPU from the oracle's
+    # current state on a fresh batch cost ~1.5 s (no fp32 host step: the oracle's yard-stick comes from the steps above and
+    # the committed anchor).  Drawn only while some bimodal tensor has no baseline-level HIP sample yet, at most 40.
+    extra, extra_min, extra_base = 0, {}, {}
+    if om64 is not None and len(e_hip_steps) >= 6:
+        names_ = list(e_hip_steps[0].keys())
+        o_all = list(e_32_steps) + ([st['tensors'] for st in fa.load_anchor()[anchor]['steps']] if anchor is not None else [])
+        o_min = {n_: min(st[n_]['grad'] for st in o_all) for n_ in names_}
+        bimodal = [n_ for n_ in names_ if not _unimodal(sorted(st[n_]['grad'] for st in o_all))]
+        extra_min = {n_: min(st[n_]['grad'] for st in e_hip_steps) for n_ in bimodal}
+        extra_base = {n_: sum(1 for st in e_hip_steps if st[n_]['grad'] <= k_typical * max(o_min[n_], PARITY_FLOOR))
+                      for n_ in bimodal}
+        while extra < 40 and any(extra_min[n_] > k_typical * max(o_min[n_], PARITY_FLOOR) for n_ in bimodal):
+            _adopt(model, om)
+            fa.adopt64(om64, om)
+            b = batch_fn(5000 + extra) if batch_fn else synth.make_batch(5000 + extra + batch_seed, 0, B, H, W,
+                                                                        flags.get('label_nc', 35), color)
+            model.optimize_parameters(b)
+            model.sync()
+            fa.step64(om64, b)
+            g_hip, g64 = ({'%s/%s' % (tg, k): p.grad for tg, net in (('G', m_.netG), ('D', m_.netD))
+                           for k, p in net.named_parameters()} for m_ in (model, om64))
+            for n_ in bimodal:          # the bimodal tensors only (the discriminator's 8 M parameters: cheap)
+                e = fa.rel_l2(g_hip[n_], g64[n_])
+                extra_min[n_] = min(extra_min[n_], e)
+                extra_base[n_] += 1 if e <= k_typical * max(o_min[n_], PARITY_FLOOR) else 0
+            extra += 1
+    n_regular = len(e_hip_steps)
     adam_worst = {k: max(a[k] for a in adam_log) for k in ADAM_TOL}
     os.makedirs(OUT, exist_ok=True)
     report = dict(tag=tag, loss_rel_per_step=log, loss_tol=loss_tol, adam_arithmetic_worst=adam_worst, adam_tol=ADAM_TOL,
@@ -423,30 +474,41 @@ def _teacher_forced_run(tag, steps, loss_tol, anchor, golden, batch_fn, plumbing
             rec = fa.load_anchor()[anchor]['steps']
             assert set(rec[0]['tensors'].keys()) == set(names), 'anchor fixture lists other tensors than the model'
             oracle_steps += [st['tensors'] for st in rec]
-        typical, typical_med, events = [], [], []
-        if len(e_hip_steps) >= 6:
+        typical, typical_med, events, baseline = [], [], [], []
+        regular = e_hip_steps[:n_regular]
+        if len(regular) >= 6:
             for n in names:
-                th = _quartile([st[n]['grad'] for st in e_hip_steps])
-                to = max(_quartile([st[n]['grad'] for st in oracle_steps]), PARITY_FLOOR)
-                typical.append((th / to, n, th, to))
-                if not th <= k_typical * to:
-                    bad.append(('typical', n, th, k_typical * to))
-                # MEDIAN bound: asserted where the oracle's own distances are unimodal (largest within 30x of the
-                # smallest: every generator tensor).  The discriminator's tensors are bimodal on BOTH sides -- baseline
-                # 3e-6 or an event of 1e-4..5e-3 in about every second step (round 4, C1: HIP 5 of 8 steps, oracle 4 of 8)
-                # -- so their median is a coin toss between the two modes; it is recorded, and stream races are caught by
-                # test_multi_stream_schedule_is_bit_identical_to_the_serial_one instead.
                 os_ = sorted(st[n]['grad'] for st in oracle_steps)
-                unimodal = os_[-1] <= 30.0 * max(os_[0], PARITY_FLOOR)     # no baseline / event split among its samples
-                mh = _median([st[n]['grad'] for st in e_hip_steps])
+                unimodal = _unimodal(os_)
+                th = _quartile([st[n]['grad'] for st in regular])
+                to = max(_quartile(os_), PARITY_FLOOR)
+                typical.append((th / to, n, th, to, unimodal))
+                # UNIMODAL tensors (the oracle's largest distance within 30x of its smallest: every generator tensor): lower
+                # quartile AND median over the steps.  BIMODAL tensors (the discriminator's: baseline 1e-6 or an event of
+                # 1e-4..5e-3, in most full-size steps on both sides): the quartile / median of a handful of steps is a
+                # coin toss between the modes (recorded only) -- the bound is on the MINIMUM over all samples, regular steps
+                # + the extra float64 samples drawn above: a kernel defect raises the baseline of EVERY step; stream races
+                # are caught by test_multi_stream_schedule_is_bit_identical_to_the_serial_one.
+                mh = _median([st[n]['grad'] for st in regular])
                 mo = max(_median(os_), PARITY_FLOOR)
                 typical_med.append((mh / mo, n, mh, mo, unimodal))
-                if unimodal and not mh <= 2.0 * k_typical * mo:
-                    bad.append(('typical (median)', n, mh, 2.0 * k_typical * mo))
+                if unimodal:
+                    if not th <= k_typical * to:
+                        bad.append(('typical', n, th, k_typical * to))
+                    if not mh <= 2.0 * k_typical * mo:
+                        bad.append(('typical (median)', n, mh, 2.0 * k_typical * mo))
+                else:
+                    bh = extra_min.get(n, min(st[n]['grad'] for st in regular))
+                    bo = max(os_[0], PARITY_FLOOR)
+                    baseline.append((bh / bo, n, bh, bo, extra_base.get(n), len(regular) + extra))
+                    if not bh <= k_typical * bo:
+                        bad.append(('baseline (bimodal tensor, min over %d samples)' % (len(regular) + extra), n, bh,
+                                    k_typical * bo))
             typical.sort(reverse=True)
             typical_med.sort(reverse=True)
-        for net in 'GD':
-            mh = max((st[n]['grad'], s, n) for s, st in enumerate(e_hip_steps) for n in names if n.startswith(net))
+            baseline.sort(reverse=True)
+        for net in 'GD':       # EVENTS: over the regular steps (the oracle's events are known for those only)
+            mh = max((st[n]['grad'], s, n) for s, st in enumerate(regular) for n in names if n.startswith(net))
             mo = max(max(st[n]['grad'] for st in oracle_steps for n in names if n.startswith(net)), PARITY_FLOOR)
             events.append((mh[0] / mo, net, mh[0], mh[1], mh[2], mo))
             if not mh[0] <= PARITY_K_EVENT * mo:
@@ -456,11 +518,14 @@ def _teacher_forced_run(tag, steps, loss_tol, anchor, golden, batch_fn, plumbing
                          **{'%s_%s_%s' % (net, q, who): med([st[n][q] for n in names if n.startswith(net)])
                             for net in 'GD' for q in ('grad', 'delta')
                             for who, st in (('hip', e_hip_steps[s]), ('oracle', e_32_steps[s]))})
-                    for s in range(len(e_hip_steps))]
+                    for s in range(len(regular))]
         report.update(mode='fp64 anchor', K_typical=k_typical, K_event=PARITY_K_EVENT, floor=PARITY_FLOOR,
                       anchor=anchor or 'live only', oracle_step_samples=len(oracle_steps),
-                      typical_columns=['ratio', 'tensor', 'hip_lower_quartile', 'oracle_lower_quartile_or_floor'],
-                      typical_worst=typical[:25], typical_median_worst=typical_med[:25], fp64_steps=len(e_hip_steps),
+                      typical_columns=['ratio', 'tensor', 'hip_lower_quartile', 'oracle_lower_quartile_or_floor', 'asserted (unimodal)'],
+                      typical_worst=typical[:25], typical_median_worst=typical_med[:25], fp64_steps=len(regular),
+                      extra_fp64_samples=extra,
+                      baseline_columns=['ratio', 'tensor', 'hip_min', 'oracle_min_or_floor', 'hip_samples_at_baseline', 'hip_samples'],
+                      baseline_bimodal_worst=baseline[:25],
                       grad_distance_from_fp64=dict(tensors=names,
                                                    hip=[[st[n]['grad'] for n in names] for st in e_hip_steps],
                                                    oracle_live=[[st[n]['grad'] for n in names] for st in e_32_steps]),
@@ -846,7 +911,9 @@ def test_bench_launcher_spawns_the_ranks_it_is_asked_for():
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['config']['global_batch'] == 16 and out['config']['parallelism'] == 'dp2'
-    assert out['ranks'] == {'world_size': 2, 'backend': 'gloo', 'replicas_identical': True}
+    assert out['ranks'] == {'world_size': 2, 'backend': 'gloo', 'replicas_identical': True,
+                            'rccl_max_nchannels': 'library default'}
+    assert out['schedule']['d_backward_first'] is True      # --g-backward-first flips it (the 8-GPU A/B)
     # per-rank event-timed waits for the exchange (what shows overlap on a real multi-GPU run)
     ex = out['exposed_comm_ms']
     assert len(ex['per_rank']) == 2 and set(ex['per_rank'][0]) == {'g_update_tail', 'd_update_wait', 'g_exchange_wait',

@@ -966,7 +966,13 @@ def test_first_patchgan_conv_from_label_ids_matches_the_dense_conv(case):
     valid = (lab >= 0) & (lab < NC)
     onehot.scatter_(1, lab.clamp(0, NC - 1).long(), valid.float())
     xin = torch.cat([onehot] + ([dense] if Cd else []) + [img], 1)
-    y_ref = F.leaky_relu(F.conv2d(xin, w, b, 2, 2), 0.2)
+    # full-size case without the LeakyReLU: among 17 M outputs a handful land within rounding of 0, their gate flips between
+    # two fp32 summation orders and moves a weight gradient by 0.8 |gy| there (seen: 0.5 on an entry of 40; without the
+    # activation every piece sits at 2..6e-7 of the float64 result) -- as in test_winograd_conv3x3_fwd_bwd
+    act = 'lrelu' if B * H * W < 100000 else 'none'
+    y_ref = F.conv2d(xin, w, b, 2, 2)
+    if act == 'lrelu':
+        y_ref = F.leaky_relu(y_ref, 0.2)
     gy = _rand(*y_ref.shape, seed=4)
     gw_ref, gb_ref, gi_ref = torch.autograd.grad(y_ref, (w, b, img), gy)
 
@@ -975,7 +981,7 @@ def test_first_patchgan_conv_from_label_ids_matches_the_dense_conv(case):
         with config.schedule(d_from_ids=from_ids):
             cond = ops.LabelCond(lab.to(DEV), NC, dense.to(DEV) if Cd else None)
             wd, bd, imd = (t.detach().to(DEV).requires_grad_(True) for t in (w, b, img))
-            y = ops.cond_image_conv2d(cond, imd, wd, bd, 2, 2, 'lrelu', 0.2)
+            y = ops.cond_image_conv2d(cond, imd, wd, bd, 2, 2, act, 0.2)
             assert y.grad_fn.__class__.__name__.startswith('_IdsCondImageConv2d' if from_ids else '_CondImageConv2d')
             return (y,) + torch.autograd.grad(y, (wd, bd, imd), gy.to(DEV))
 
