@@ -81,6 +81,8 @@ const char* him_last_error(void);
 #define HIM_ALGO_NO_RESBLOCK_FUSED (1u << 8)/* him_resblock_supported() answers 0 */
 #define HIM_ALGO_NO_BGEMM (1u << 10)        /* batched Winograd GEMMs on the conv kernel instead of the LDS-DMA GEMM kernel */
 #define HIM_ALGO_NO_ONEHOT_RLE (1u << 11)   /* one-hot stem weight gradient per pixel (round-1 kernel) instead of per run of equal class */
+#define HIM_ALGO_NO_FEWIN_FOLD (1u << 12)    /* reflection-padded few-channel data gradient (generator head) through the padded
+                                               gradient + reflect_fold pass instead of the fold inside the tiled kernel */
 #define HIM_ALGO_FROZEN_WEIGHTS (1u << 9)   /* the layer's weights never change (VGG19 of the perceptual loss,
                                                models/layer_util.py:380-411): forward / data gradient may use Winograd
                                                F(4x4,3x3), whose 36-position panel is built once per run */

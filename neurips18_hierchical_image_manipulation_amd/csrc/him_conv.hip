@@ -1207,6 +1207,25 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
     rc = check_launch("reflect_extend");
     if (rc) return rc;
   }
+  // Reflection-padded few-channel data gradient (the generator's 7x7 head, 3 -> 64 at full resolution: the FIRST kernel of
+  // the generator's backward pass): fold inside the tiled kernel (round 5, him_conv_direct.inc FOLD) instead of writing the
+  // padded gradient and folding it in a second pass.  Same sums in the same order: bit-identical.
+  if (refl && g.ksplit <= 1 && !algo_off(d->algo, HIM_ALGO_NO_FEWIN_FOLD) && fewin_tiled_ok(d->algo, g)) {
+    int sy, sx;
+    if (fewin_fold_shift(IH, d->pad, 16, &sy) && fewin_fold_shift(IW, d->pad, 64, &sx)) {
+      g.fold_p = d->pad;
+      g.fold_sy = sy;
+      g.fold_sx = sx;
+      g.dst = out;
+      g.DH = d->H;
+      g.DW = d->W;
+      if (fewin_tiled_ok(d->algo, g)) return launch_gconv(d->algo, g, st);
+      g.fold_p = g.fold_sy = g.fold_sx = 0;
+      g.dst = dpad;
+      g.DH = IH;
+      g.DW = IW;
+    }
+  }
   rc = launch_gconv(d->algo, g, st);
   if (rc) return rc;
   if (refl) {
@@ -1296,7 +1315,7 @@ void him_algo_from_env(HimAlgo* a) {
       {"HIM_NO_FEWOUT_TILED", HIM_ALGO_NO_FEWOUT_TILED}, {"HIM_NO_FEWIN_TILED", HIM_ALGO_NO_FEWIN_TILED},
       {"HIM_NO_FEWCH_MFMA", HIM_ALGO_NO_FEWCH_MFMA},   {"HIM_GENERIC_CONV", HIM_ALGO_GENERIC_CONV},
       {"HIM_NO_RESBLOCK_FUSED", HIM_ALGO_NO_RESBLOCK_FUSED}, {"HIM_NO_BGEMM", HIM_ALGO_NO_BGEMM},
-      {"HIM_NO_ONEHOT_RLE", HIM_ALGO_NO_ONEHOT_RLE}};
+      {"HIM_NO_ONEHOT_RLE", HIM_ALGO_NO_ONEHOT_RLE},   {"HIM_NO_FEWIN_FOLD", HIM_ALGO_NO_FEWIN_FOLD}};
   for (const auto& f : flags)
     if (getenv(f.k)) a->disable |= f.bit;
 }

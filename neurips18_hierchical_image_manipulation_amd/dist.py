@@ -76,7 +76,7 @@ class GradReducer(object):
         next generator forward for the optimizer step).  Cut in reverse order, that bucket is whatever is left over, up to
         ``bucket_bytes`` (58 MB of the generator's 730 MB at C2: 0.66 ms on one 153 GB/s ring link).  It is split on a
         parameter boundary so that the final piece holds at most ``tail_bytes`` (C2: stem + the first three down-convolutions,
-        6.3 MB = 0.07 ms); the rest of it becomes final ~3 ms earlier."""
+        6.7 MB = 0.08 ms); the rest of it becomes final ~3 ms earlier."""
         self.flat, self.group = flat, group
         self.fake = bool(fake)
         self.local = bool(local)

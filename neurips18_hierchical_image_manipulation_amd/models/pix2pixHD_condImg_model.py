@@ -610,9 +610,30 @@ class Pix2PixHDModel_condImg(BaseModel):
             # longer queues behind the generator's whole backward.  Without a shared fake pass: after the backward, as before.
             if SCHED.d_update_early and self._fake_gate is not None:
                 self._fake_gate['on_open_backward'] = self._d_update
+            ops.take_stem_pre(self.device)      # a stale record of an earlier backward (backward_G(), another model)
             self._run_backward_G(last=True, extra_root=early)
             if self._fake_gate is None or self._fake_gate.pop('on_open_backward', None) is not None or not SCHED.d_update_early:
                 self._d_update()
+            # GlobalGenerator is a chain: its stem's backward is the last node, and the stem's run-length weight gradient
+            # (0.5 ms, LDS-bound, one workgroup per CU) the last kernel of the pass.  Everything ELSE is final one kernel
+            # earlier: that part of Adam (5 GB of HBM traffic, no LDS) + the panel rebuild start next to it, behind the two
+            # events ops recorded in front of the stem's weight gradient; step() below closes with the stem's slice.
+            pre = ops.take_stem_pre(self.device)
+            if (pre is not None and SCHED.adam_split_stem and self.netG_type == 'global' and self.reducer_G is None
+                    and pre[3] == id(self.netG.model[1].weight)):
+                ev_main, ev_side, (lo, hi), _ = pre
+                with torch.cuda.stream(opt_stream):
+                    opt_stream.wait_event(ev_main)
+                    opt_stream.wait_event(ev_side)
+                    self.optimizer_G.begin_step()
+                    try:
+                        if lo > 0:
+                            self.optimizer_G.step_range(0, lo)
+                        if hi < self.optimizer_G.arena.total:
+                            self.optimizer_G.step_range(hi, self.optimizer_G.arena.total)
+                    except Exception:
+                        self.optimizer_G.abort_step()
+                        raise
             # G's exchange + Adam + panel rebuild (5 GB of HBM traffic, no matrix work) on their own stream, NOT waited for
             # here: the next step's input encoding and real-image branch do not touch G and run next to them; the next
             # generator forward waits (forward()); anything else that reads parameters calls sync() first.

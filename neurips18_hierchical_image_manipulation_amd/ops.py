@@ -544,6 +544,18 @@ class _OneHotConv2d(torch.autograd.Function):
         if need_w or need_b:
             nb = lib.him_conv2d_onehot_bwd_weight_ws(ctypes.byref(d), ctx.n_onehot)
             if need_w and _direct(w) and (not need_b or _direct(b)):
+                if SCHED.adam_split_stem and SCHED.wgrad_stream and hasattr(w, '_him_arena_range'):
+                    # A generator stem is the LAST node of a chain-shaped generator's backward pass: what the streams hold
+                    # at this moment is every data gradient (current stream) and every OTHER weight gradient (weight-gradient
+                    # stream) of the network.  A trainer may start the optimizer step of everything else behind these two
+                    # events, next to this layer's own weight gradient (Pix2PixHDModel_condImg.optimize_parameters).
+                    dev = label.device
+                    cur = torch.cuda.current_stream(dev)
+                    side = _WGRAD_ROUTE.get(cur.cuda_stream) or _side_stream(dev)
+                    ev_main, ev_side = torch.cuda.Event(), torch.cuda.Event()
+                    ev_main.record(cur)
+                    ev_side.record(side)
+                    _STEM_PRE[dev] = (ev_main, ev_side, tuple(w._him_arena_range), id(w))
                 with _wgrad_stream(x, dz, label):
                     ws = _ws(nb, label)
                     bw(ctypes.byref(d), _p(label), ctx.n_onehot, _p(x), _p(dz), _p(w.grad),
@@ -557,6 +569,14 @@ class _OneHotConv2d(torch.autograd.Function):
                 db = torch.empty_like(b) if need_b else None
                 bw(ctypes.byref(d), _p(label), ctx.n_onehot, _p(x), _p(dz), _p(dw), _p(db), 0, _p(ws), nb, st)
         return None, None, None, dw, db, None, None, None, None, None, None
+
+
+_STEM_PRE = {}      # device -> (event on the data-gradient stream, event on the weight-gradient stream, arena range, id(weight))
+
+
+def take_stem_pre(device):
+    """The events recorded in front of the LAST one-hot stem weight gradient on ``device`` (see _OneHotConv2d.backward), once."""
+    return _STEM_PRE.pop(device, None)
 
 
 def _ids_conv_desc(label, w, stride, pad, pad_mode, act, slope):

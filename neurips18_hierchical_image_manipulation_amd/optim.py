@@ -108,6 +108,16 @@ class FusedAdam(object):
         self.step_count += 1
         self._done = []
 
+    def abort_step(self):
+        """Forget an open piecewise step (an exception between ``begin_step`` and ``step``): the next ``step()`` is a whole
+        step again instead of 'the complement of what step_range covered' (ADVICE r4).  Ranges already updated stay updated --
+        the caller is unwinding an error -- but the step count only stays advanced if something was applied."""
+        done = getattr(self, '_done', None)
+        if done is not None:
+            if not done:
+                self.step_count -= 1
+            self._done = None
+
     def _adam(self, lo, hi):
         a = self.arena
         for (s, e, lr, b1, b2, eps) in self._runs():

@@ -222,7 +222,7 @@ def _hip_quantities(model, before):
             n = p.numel()
             out['%s/%s' % (tag, name)] = dict(grad=p.grad, exp_avg=opt.exp_avg[o:o + n].view(p.shape),
                                               exp_avg_sq=opt.exp_avg_sq[o:o + n].view(p.shape),
-                                              delta=p.detach().double().cpu() - before[tag][name].double())
+                                              delta=p.detach().double() - before[tag][name].to(p.device).double())
     return out
 
 
@@ -242,7 +242,7 @@ def _post_step_state_errors(model, om, before):
                 continue
             worst_m = max(worst_m, _rel_l2(qh[n]['exp_avg'], qo[n]['exp_avg']))
             worst_v = max(worst_v, _rel_l2(qh[n]['exp_avg_sq'], qo[n]['exp_avg_sq']))
-            num += float((qh[n]['delta'] - qo[n]['delta']).pow(2).sum())
+            num += float((qh[n]['delta'] - qo[n]['delta'].to(qh[n]['delta'].device)).pow(2).sum())
             den += float(qo[n]['delta'].pow(2).sum())
         worst_d = max(worst_d, (num / max(den, 1e-300)) ** 0.5)
     return worst_m, worst_v, worst_d

@@ -1019,3 +1019,29 @@ def test_label_cond_full_and_pooled_equal_the_materialised_tensors(shape):
         head = ops.slice_channels(cond, 0, NC + 1)
         assert isinstance(head, ops.LabelCond) and torch.equal(head.full().cpu(), full_ref[:, :NC + 1])
     assert torch.equal(ops.slice_channels(cond, 1, NC - 1).cpu(), full_ref[:, 1:NC])
+
+
+@pytest.mark.parametrize('shape', [(8, 64, 256, 512, 3, 7), (2, 32, 67, 130, 3, 7), (3, 16, 40, 200, 2, 3), (1, 64, 33, 64, 4, 7),
+                                   (16, 16, 20, 70, 3, 7)], ids=str)
+def test_reflect_fold_inside_the_few_channel_data_gradient_is_bit_identical(shape):
+    """Round 5: the data gradient of a reflection-padded layer with <= 4 output channels (the generator's head,
+    ReflectionPad2d(3) + Conv2d(64, 3, 7) of models/Pix2Pix_NET.py:91 -- the FIRST kernel of the generator's backward) folds the
+    mirrored border strips inside the LDS-tiled kernel instead of writing the padded gradient and running reflect_fold_kernel
+    over it.  Same terms, same order: torch.equal to the two-kernel form (HIM_ALGO_NO_FEWIN_FOLD), and both against the fp32
+    torch reference; odd planes, a plane too small for the tiled kernel (falls back), 2..4 channels, 3x3 and 7x7."""
+    ops = _ops()
+    from neurips18_hierchical_image_manipulation_amd._cabi import ALGO_NO_FEWIN_FOLD
+    B, Cin, H, W, Cout, k = shape
+    x = _rand(B, Cin, H, W, seed=1).requires_grad_(True)
+    w = _rand(Cout, Cin, k, k, seed=2, scale=(Cin * k * k) ** -0.5)
+    y_ref = _ref_conv(x, w, None, 1, k // 2, 'reflect', 'none')
+    gy = _rand(*y_ref.shape, seed=3)
+    (gx_ref,) = torch.autograd.grad(y_ref, x, gy)
+    got = {}
+    for off in (0, ALGO_NO_FEWIN_FOLD):
+        with ops.algo_scope(disable=off):
+            xd = x.detach().to(DEV).requires_grad_(True)
+            y = ops.conv2d(xd, w.to(DEV), None, 1, k // 2, 'reflect', 'none')
+            (got[off],) = torch.autograd.grad(y, xd, gy.to(DEV))
+        assert_close('dgrad (disable=%d)' % off, got[off], gx_ref, rtol=2e-5)
+    assert torch.equal(got[0], got[ALGO_NO_FEWIN_FOLD]), 'the in-kernel fold must reproduce the fold pass bit for bit'

@@ -64,11 +64,11 @@ def main():
             gf = executed_gflop(kern, spec)
             iso = st['avg']
             ins = step.get((kern, grid))
-            isf = gf / iso / 1e3
+            isf = gf / iso * 1e3
             line = '%-9s %-36s %-42s %-14s %8.2f %9.1f %7.1f %6.3f' % (name, spec[-1][:36], kern[:42], str(grid).replace(' ', ''),
                                                                      gf, iso, isf, isf / PEAK)
             if ins:
-                inf = gf / ins['avg'] / 1e3
+                inf = gf / ins["avg"] * 1e3
                 line += ' %9.1f %7.1f %6.3f %6.1f' % (ins['avg'], inf, inf / PEAK, ins['calls'] / steps)
                 tot[(kern, grid)] = ins['total'] / steps
             else:
