@@ -99,7 +99,10 @@ typedef struct HimAlgo {
   int wino_tblock;      /* threads per workgroup of the Winograd transform kernels: 64 (default), 128, 256 */
   int wgrad_splits;     /* fast weight-gradient kernel: split count; 0 = automatic */
   unsigned disable;     /* HIM_ALGO_* bits */
-  int reserved[2];
+  int wino_fused_chunk; /* reduction channels per K-chunk of the fused Winograd kernel: 0 = default, 8 = the whole 160 KB of a CU's
+                           LDS per workgroup (fastest alone: 0.54 ms at VGG conv1_2), 4 = 80 KB (0.69 ms alone, but the
+                           workgroup shares its CU with the other streams' kernels inside the training step) */
+  int reserved[1];
 } HimAlgo;
 /* out = in with every 0 replaced by the default it selects (in == NULL: all defaults). */
 void him_algo_resolve(const HimAlgo* in, HimAlgo* out);

@@ -17,7 +17,7 @@ class HimAlgo(C.Structure):
     """Kernel-selection overrides carried by every descriptor (include/him.h "Algorithm selection"); zero = defaults."""
     _fields_ = [(n, c_int) for n in ('wino_min_c', 'wino_fused_min_c', 'wino_fused_max_c', 'wino4_min_c', 'ksplit_max',
                                      'tile_wb', 'tile_nb', 'wino_tblock', 'wgrad_splits')] + \
-               [('disable', C.c_uint), ('reserved', c_int * 2)]
+               [('disable', C.c_uint), ('wino_fused_chunk', c_int), ('reserved', c_int * 1)]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != 'reserved'}

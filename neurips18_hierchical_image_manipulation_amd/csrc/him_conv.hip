@@ -946,7 +946,8 @@ static int run_fprop(const HimConv2d* d, const float* x, const float* w, const f
       if (rc || build_only) return rc;
     }
     return run_wino_fused(d->B, d->Cin, d->H, d->W, d->Cout, d->pad_mode == HIM_PAD_REFLECT, x,
-                          panel ? panel : (const float*)ws, bias, d->act, d->slope, y, st);
+                          panel ? panel : (const float*)ws, bias, d->act, d->slope, y, st, nullptr,
+                          algo_wino_fused_chunk(d->algo) == 4);
   }
   if (wino_fwd_ok(d)) {
     const size_t need = build_only ? fprop_panel_floats(d) * sizeof(float) : fprop_ws_bytes(d);
@@ -1087,7 +1088,7 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
     }
     if (mask_done) *mask_done = relu_mask != nullptr;   // the gate rides in this kernel's epilogue
     return run_wino_fused(d->B, d->Cout, d->OH, d->OW, d->Cin, false, gy, panel ? panel : (const float*)ws, bias, act, slope,
-                          out, st, relu_mask);
+                          out, st, relu_mask, algo_wino_fused_chunk(d->algo) == 4);
   }
   if (wino_dgrad_ok(d) && panel && (bias || act != HIM_ACT_NONE))
     return fail(HIM_E_UNSUPPORTED, "dgrad: Winograd panel with a fused bias/activation epilogue");
@@ -1291,6 +1292,7 @@ void him_algo_resolve(const HimAlgo* in, HimAlgo* out) {
   r.tile_wb = a.tile_wb == HIM_TILE_DEFAULT ? HIM_TILE_64x128 : a.tile_wb;
   r.tile_nb = a.tile_nb == HIM_TILE_DEFAULT ? HIM_TILE_64x128 : a.tile_nb;
   r.wino_tblock = algo_tblock(a);
+  r.wino_fused_chunk = algo_wino_fused_chunk(a);
   *out = r;
 }
 
@@ -1309,6 +1311,7 @@ void him_algo_from_env(HimAlgo* a) {
   a->tile_nb = geti("HIM_GCONV_TILE_NB", tile_all);
   a->wino_tblock = geti("HIM_WINO_TBLOCK", 0);
   a->wgrad_splits = geti("HIM_WGRAD_SPLITS", 0);
+  a->wino_fused_chunk = geti("HIM_WINO_FUSED_CHUNK", 0);
   const struct { const char* k; unsigned bit; } flags[] = {
       {"HIM_NO_SPLITK", HIM_ALGO_NO_SPLITK},           {"HIM_NO_DFOLD", HIM_ALGO_NO_DFOLD},
       {"HIM_WINO_PADDED_DGRAD", HIM_ALGO_WINO_PADDED_DGRAD}, {"HIM_NO_SMALL_WIN", HIM_ALGO_NO_SMALL_WIN},

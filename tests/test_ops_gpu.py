@@ -1045,3 +1045,29 @@ def test_reflect_fold_inside_the_few_channel_data_gradient_is_bit_identical(shap
             (got[off],) = torch.autograd.grad(y, xd, gy.to(DEV))
         assert_close('dgrad (disable=%d)' % off, got[off], gx_ref, rtol=2e-5)
     assert torch.equal(got[0], got[ALGO_NO_FEWIN_FOLD]), 'the in-kernel fold must reproduce the fold pass bit for bit'
+
+
+@pytest.mark.parametrize('case', [(8, 64, 64, 128, 64, 'zero'), (2, 128, 37, 53, 128, 'zero'), (3, 72, 16, 24, 64, 'reflect')],
+                         ids=str)
+def test_fused_winograd_kernel_at_80_kb_of_lds(case):
+    """HimAlgo.wino_fused_chunk = 4 (round 5: 4-channel K-chunks, 80 KB of LDS, two lanes per input patch, four epilogue
+    rounds -- measured slower inside the step, kept as a switch: profiles/r05_ab_log.txt): forward and zero-pad data gradient
+    against the fp32 torch reference, and within 2e-6 of the shipped 8-channel-chunk kernel."""
+    ops = _ops()
+    B, Cin, H, W, Cout, mode = case
+    x = _rand(B, Cin, H, W, seed=1).requires_grad_(True)
+    w = _rand(Cout, Cin, 3, 3, seed=2, scale=(Cin * 9) ** -0.5)
+    b = _rand(Cout, seed=3, scale=0.1)
+    y_ref = _ref_conv(x, w, b, 1, 1, mode, 'none')
+    gy = _rand(*y_ref.shape, seed=4)
+    (gx_ref,) = torch.autograd.grad(y_ref, x, gy)
+    got = {}
+    for ck in (8, 4):
+        with ops.algo_scope(wino_fused_chunk=ck, wino_fused_min_c=64, wino_fused_max_c=255, wino_min_c=256):
+            xd = x.detach().to(DEV).requires_grad_(True)
+            y = ops.conv2d(xd, w.to(DEV), b.to(DEV), 1, 1, mode, 'none')
+            (gx,) = torch.autograd.grad(y, xd, gy.to(DEV))
+        assert_close('fwd chunk %d' % ck, y, y_ref, rtol=2e-5)
+        assert_close('dgrad chunk %d' % ck, gx, gx_ref, rtol=2e-5)
+        got[ck] = y.detach()
+    assert_close('chunk 4 vs chunk 8', got[4], got[8].cpu(), rtol=2e-6)

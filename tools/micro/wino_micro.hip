@@ -25,6 +25,7 @@ int main(int argc, char** argv) {
   const int B = argc > 1 ? atoi(argv[1]) : 8, Ci = argc > 2 ? atoi(argv[2]) : 256, H = argc > 3 ? atoi(argv[3]) : 64;
   const int W = argc > 4 ? atoi(argv[4]) : 128, Co = argc > 5 ? atoi(argv[5]) : 256, refl = argc > 6 ? atoi(argv[6]) : 0;
   const int iters = argc > 7 ? atoi(argv[7]) : 20;
+  const bool chunk4 = argc > 8 && atoi(argv[8]) == 4;      // 4-channel chunks (80 KB of LDS)
   if (!wino_fused_shape_ok(Co, Ci, 3, 3, 1, 1, B, H, W)) { printf("shape not supported\n"); return 2; }
   const size_t nx = (size_t)B * Ci * H * W, nw = (size_t)Co * Ci * 9, ny = (size_t)B * Co * H * W;
   std::vector<float> hx(nx), hw(nw), hb(Co), hy(ny);
@@ -43,11 +44,11 @@ int main(int argc, char** argv) {
   hipStream_t st;
   hipStreamCreate(&st);
   hipLaunchKernelGGL((wino_fused_weight_kernel<0>), dim3((Ci + 255) / 256, Co), dim3(256), 0, st, w, Uf, Co, Ci);
-  for (int i = 0; i < 3; ++i) run_wino_fused(B, Ci, H, W, Co, refl != 0, x, Uf, bias, HIM_ACT_RELU, 0.f, y, st);
+  for (int i = 0; i < 3; ++i) run_wino_fused(B, Ci, H, W, Co, refl != 0, x, Uf, bias, HIM_ACT_RELU, 0.f, y, st, nullptr, chunk4);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0, st);
-  for (int i = 0; i < iters; ++i) run_wino_fused(B, Ci, H, W, Co, refl != 0, x, Uf, bias, HIM_ACT_RELU, 0.f, y, st);
+  for (int i = 0; i < iters; ++i) run_wino_fused(B, Ci, H, W, Co, refl != 0, x, Uf, bias, HIM_ACT_RELU, 0.f, y, st, nullptr, chunk4);
   hipEventRecord(e1, st);
   hipEventSynchronize(e1);
   float ms = 0;
