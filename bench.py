@@ -382,6 +382,8 @@ def main():
     ap.add_argument('--rccl-channels', type=int, default=0,
                     help='N > 1: cap RCCL at this many channels (NCCL_MAX_NCHANNELS; each channel is a workgroup = CUs taken '
                          'from the compute streams); 0 = the library default.  Printed under "ranks"')
+    ap.add_argument('--tail-mb', type=float, default=8.0,
+                    help='gradient reducer: size cap of the LAST bucket to become final (dist.GradReducer tail_bytes); 0 = no split')
     ap.add_argument('--g-backward-first', action='store_true',
                     help="A/B of the step order (DESIGN.md 6): loss_G.backward() BEFORE loss_D.backward() (the reference's own "
                          "order, train_mask2image.py:78-86) -- G's 730 MB exchange then has D's whole backward to hide under; "
@@ -414,7 +416,7 @@ def main():
     # every rank draws the same Philox weights (and attach_data_parallel broadcasts rank 0's state anyway)
     model.netG.load_state_dict(synth.init_state_dict(model.netG.state_dict(), 1))
     model.netD.load_state_dict(synth.init_state_dict(model.netD.state_dict(), 2))
-    attach_data_parallel(model)
+    attach_data_parallel(model, tail_bytes=int(args.tail_mb * (1 << 20)))
 
     # synthetic batches, resident in HBM before the timed region (4 distinct batches per rank, cycled; seeded by rank)
     if args.workload == 'box2mask':
@@ -462,7 +464,7 @@ def main():
     if args.fake_comm and world == 1 and args.workload != 'box2mask':
         # the exchange stand-in (dist.GradReducer(fake=True)): same step, same batches, reducers attached
         dt0 = dt
-        attach_data_parallel(model, fake=True)
+        attach_data_parallel(model, fake=True, tail_bytes=int(args.tail_mb * (1 << 20)))
         for i in range(max(args.warmup, 2)):
             step(i)
         torch.cuda.synchronize()

@@ -41,7 +41,7 @@ class Schedule(object):
         'd_update_early': ('HIM_D_UPDATE_EARLY', False, "D's exchange + Adam step start inside loss_G.backward(), as soon as the gradient has passed back through the discriminator (its last reader of the step), instead of after the generator's whole backward"),
         'inputs_on_real_stream': ('HIM_INPUTS_ON_REAL_STREAM', False, "input encoding on the real-image stream: with D updated early, the NEXT step's encoding + D(real) + VGG(real) run under this step's generator backward / Adam instead of behind them"),
         'real_vgg_first': ('HIM_REAL_VGG_FIRST', False, "real-image stream: VGG(real) in front of the wait for D's update and D(real)"),
-        'zero_grad_side': ('HIM_ZERO_GRAD_SIDE', True, 'optimize_parameters() zeroes the gradient arenas on the weight-gradient stream before the forward pass (under it) instead of on the main stream in front of the backward pass'),
+        'zero_grad_side': ('HIM_ZERO_GRAD_SIDE', True, 'one rank: optimize_parameters() zeroes the gradient arenas on the weight-gradient stream before the forward pass (under it) instead of on the main stream in front of the backward pass; with a gradient exchange attached the fill stays on the main stream'),
         'conv_in_fused': ('HIM_CONV_IN_FUSED', True, 'Conv2d -> InstanceNorm [-> act] blocks through him_conv2d_in_act_fwd: split-K layers hand their slabs to the InstanceNorm kernel (no finish pass)'),
         'adam_chunked': ('HIM_ADAM_CHUNKED', False, "the generator's Adam step + panel rebuild bucket by bucket DURING its backward pass, as each 64 MB gradient bucket becomes final (and, data parallel, has been exchanged), instead of one 5 GB pass behind the last weight gradient"),
         'adam_split_stem': ('HIM_ADAM_SPLIT_STEM', True, "GlobalGenerator: the generator's Adam step + panel rebuild for everything but the stem starts behind the LAST data gradient, next to the stem's run-length weight gradient (0.5 ms, LDS-bound, the last kernel of the backward pass) instead of behind it; the stem's slice follows (FusedAdam.begin_step / step_range / step: bit-identical)"),

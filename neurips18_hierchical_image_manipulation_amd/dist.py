@@ -249,7 +249,7 @@ def replica_checksum_equal(model):
     return bool(torch.equal(lo, hi))
 
 
-def attach_data_parallel(model, bucket_bytes=64 << 20, force=False, broadcast=True, fake=False):
+def attach_data_parallel(model, bucket_bytes=64 << 20, force=False, broadcast=True, fake=False, tail_bytes=8 << 20):
     """Give a mask2image / box2mask model per-network reducers (no-op for world size 1 unless ``force``).
     Rank 0's parameters / Adam state / buffers are broadcast first (see ``broadcast_replica_state``).
     BatchNorm layers keep per-rank batch statistics (the reference's DataParallel behaviour); only gradients are averaged."""
@@ -267,7 +267,7 @@ def attach_data_parallel(model, bucket_bytes=64 << 20, force=False, broadcast=Tr
         dev = arena.grad.device
         comm = (ops._opt_stream(dev) if tag == 'G' else ops._d_opt_stream(dev)) if arena.grad.is_cuda else None
         red = GradReducer(arena.grad, [p._him_arena_range for p in arena.params], bucket_bytes, force=force,
-                          comm_stream=comm, fake=fake)
+                          comm_stream=comm, fake=fake, tail_bytes=tail_bytes)
         red.attach(arena.params)
         red.bucket_hook = getattr(model, '_bucket_update_' + tag, None)    # the bucket's Adam step behind its exchange
         setattr(model, 'reducer_' + tag, red)

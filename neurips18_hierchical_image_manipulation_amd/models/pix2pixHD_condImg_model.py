@@ -535,14 +535,17 @@ class Pix2PixHDModel_condImg(BaseModel):
         self._inputs_ready_event = data.get('ready_event') if hasattr(data, 'get') else None
         gan = not self.opt.no_gan
         zero_ev = None
-        if SCHED.zero_grad_side and SCHED.wgrad_stream:
+        if SCHED.zero_grad_side and SCHED.wgrad_stream and self.reducer_G is None and self.reducer_D is None:
             # both arenas zeroed on the weight-gradient stream NOW, under the forward pass (nothing reads the gradients until
             # the backward pass; the weight-gradient kernels follow on the same stream) -- the fill used to sit on the main
-            # stream between the losses and the first backward kernel
+            # stream between the losses and the first backward kernel (one rank: -0.37 ms per step).  NOT with a gradient
+            # exchange attached: the fill makes the weight-gradient stream a FIFTH busy hardware queue at the step boundary,
+            # next to the exchange + Adam on the optimizer streams -- measured with the exchange stand-in: +2.2 ms per step
+            # (profiles/r05_ab_log.txt; the queue cliff of DESIGN.md 3); on the optimizer streams behind Adam it gains nothing
             main0 = torch.cuda.current_stream(self.device)
             ws = ops._side_stream(self.device)
             ws.wait_stream(main0)             # the caller may have read / written .grad on the current stream
-            ws.wait_stream(ops._opt_stream(self.device))      # the previous step's Adam kernels (and exchanges) read them
+            ws.wait_stream(ops._opt_stream(self.device))      # the previous step's Adam kernels read them
             ws.wait_stream(ops._d_opt_stream(self.device))
             with torch.cuda.stream(ws):
                 self.optimizer_G.zero_grad()
@@ -642,6 +645,9 @@ class Pix2PixHDModel_condImg(BaseModel):
                 if self.reducer_G is not None:
                     self.reducer_G.finish()
                 self.optimizer_G.step()
+                # what the next generator forward waits for (NOT the whole stream: the next step's arena fill follows here)
+                self._g_update_done = torch.cuda.Event(enable_timing=False)
+                self._g_update_done.record(opt_stream)
             self._g_chunked = False
             self._g_update_pending = True
         else:
@@ -709,6 +715,8 @@ class Pix2PixHDModel_condImg(BaseModel):
             from ..dist import timed_wait
             cur = torch.cuda.current_stream(self.device)
             ev = getattr(self.optimizer_G, 'updated', None) if SCHED.panel_pipeline else None
+            if ev is None:
+                ev, self._g_update_done = getattr(self, '_g_update_done', None), None    # Adam + the whole panel rebuild
             if ev is None:
                 timed_wait(cur, ops._opt_stream(self.device), self.comm_timing['g_update_tail'] if self.comm_timing else None)
             else:

@@ -21,7 +21,8 @@ def durations(path, need_adam):
     c = sqlite3.connect(path)
     rows = c.execute('select name, start, end, grid_x, grid_y, grid_z, workgroup_x from kernels order by start').fetchall()
     if need_adam:       # whole training steps only: between the first and the last Adam launch, warm-up steps dropped
-        adam = [r[2] for r in rows if 'adam_kernel' in r[0]]
+        from stepmarks import step_marks
+        adam = step_marks(rows)
         lo, hi = adam[len(adam) // 3], adam[-1]
         rows = [r for r in rows if r[1] >= lo and r[2] <= hi]
     hit = [r for r in rows if any(k in r[0] for k in KERNELS) and r[3] // max(r[6], 1) == GRID and r[4] == 1 and r[5] == 1]

@@ -24,8 +24,9 @@ def main():
     back = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     c = sqlite3.connect(db)
     rows = c.execute('select name, start, end, queue_id from kernels order by start').fetchall()
-    adam = [r[2] for r in rows if 'adam_kernel' in r[0]]
-    lo, hi = adam[-2 * back - 1], adam[-2 * back + 1] if back > 1 else adam[-1]
+    from stepmarks import step_marks
+    marks = step_marks(rows)
+    lo, hi = marks[-1 - back], marks[-back]
     rows = [r for r in rows if r[1] >= lo and r[2] <= hi + 1]
     mf = sorted((s, e) for n, s, e, q in rows if MFMA.search(n))
     # union of the MFMA intervals

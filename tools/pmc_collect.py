@@ -22,7 +22,10 @@ def main():
                         continue
                     gx = int(row.get('Grid_Size_X', row.get('Grid_Size', 0)) or 0)
                     wg = int(row.get('Workgroup_Size_X', row.get('Workgroup_Size', 256)) or 256)
-                    if want_grid and gx // max(wg, 1) != want_grid and gx != want_grid * wg:
+                    # some rocprofv3 builds report Grid_Size = x * y * z threads: (1128, 4, 1) x 256 -> 4512 workgroups
+                    nwg = gx // max(wg, 1)
+                    if want_grid and nwg != want_grid and gx != want_grid * wg and not (nwg % want_grid == 0 and
+                                                                                        nwg // want_grid <= 64):
                         continue
                     vals.setdefault(row['Counter_Name'], []).append(float(row['Counter_Value']))
     res = {k: sum(v) / len(v) for k, v in vals.items()}

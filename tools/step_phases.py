@@ -21,9 +21,9 @@ def main():
     back = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     c = sqlite3.connect(db)
     rows = c.execute('select name, start, end, queue_id, grid_x, grid_y, grid_z from kernels order by start').fetchall()
-    adam = [r[2] for r in rows if 'adam_kernel' in r[0]]
-    # a step ends with the discriminator's Adam: two adam launches per step
-    lo, hi = adam[-2 * back - 1], adam[-2 * back + 1] if back > 1 else adam[-1]
+    from stepmarks import step_marks
+    marks = step_marks(rows)        # a step ends with the generator's big Adam launch
+    lo, hi = marks[-1 - back], marks[-back]
     rows = [r for r in rows if r[1] >= lo and r[2] <= hi + 1]
     span = hi - lo
     print('step window %.2f ms, %d launches' % (span / 1e6, len(rows)))

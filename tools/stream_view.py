@@ -22,9 +22,10 @@ def main():
         path = sorted(glob.glob(os.path.join(path, '**', '*.db'), recursive=True))[0]
     c = sqlite3.connect(path)
     rows = c.execute('select name, start, end, stream_id, queue_id from kernels order by start').fetchall()
-    adam = [r[2] for r in rows if 'adam_kernel' in r[0]]
-    if len(adam) >= 2 * nsteps + 1:
-        lo, hi = adam[-(2 * nsteps + 1)], adam[-1]
+    from stepmarks import step_marks
+    adam = step_marks(rows)
+    if len(adam) >= nsteps + 1:
+        lo, hi = adam[-(nsteps + 1)], adam[-1]
         rows = [r for r in rows if r[1] >= lo and r[2] <= hi]
     else:
         nsteps = 1

@@ -18,11 +18,12 @@ def main():
         path = sorted(glob.glob(os.path.join(path, '**', '*.db'), recursive=True))[0]
     c = sqlite3.connect(path)
     rows = c.execute('select name, start, end from kernels order by start').fetchall()
-    adam = [r[2] for r in rows if 'adam_kernel' in r[0]]
+    from stepmarks import step_marks
+    adam = step_marks(rows)
     nsteps = 0
-    if len(adam) >= 11:  # two Adam launches per training step: analyse the last 5 whole steps
+    if len(adam) >= 6:  # one mark per training step (the generator's big Adam launch): analyse the last 5 whole steps
         nsteps = 5
-        lo, hi = adam[-11], adam[-1]
+        lo, hi = adam[-6], adam[-1]
         rows = [r for r in rows if r[1] >= lo and r[2] <= hi]
     else:
         t0, t1 = rows[0][1], max(r[2] for r in rows)
