@@ -50,7 +50,9 @@ def main():
     step = parse(step_path)
     print('fp32 MFMA peak %.1f TFLOP/s.  isolated = the layer alone (tools/layer_bench.py under rocprofv3 --kernel-trace, avg of 6 '
           'launches); in-step = the same (kernel, grid) in the traced training step (all streams busy).  One launch of a kernel '
-          'may serve several layers of the same shape (calls/step).' % PEAK)
+          'may serve several layers of the same shape (calls/step): the in-step average is then over ALL of them (g_down4 forward and '
+          'g_up1 data gradient are the same launch shape; d0_l3 and d1_l3 share the weight-gradient grid (32,4,6): read their in-step '
+          'TF/s as a range, the isolated column is per layer).  PMC passes of the rows marked in DESIGN.md: profiles/r05_pmc_*.json.' % PEAK)
     print('%-9s %-36s %-42s %-14s %8s %9s %7s %6s %9s %7s %6s %6s' % (
         'layer', 'what', 'kernel', 'grid', 'GFLOP', 'isol_us', 'TF/s', 'frac', 'instep_us', 'TF/s', 'frac', 'calls'))
     tot = {}
