@@ -102,7 +102,8 @@ typedef struct HimAlgo {
   int wino_fused_chunk; /* reduction channels per K-chunk of the fused Winograd kernel: 0 = default, 8 = the whole 160 KB of a CU's
                            LDS per workgroup (fastest alone: 0.54 ms at VGG conv1_2), 4 = 80 KB (0.69 ms alone, but the
                            workgroup shares its CU with the other streams' kernels inside the training step) */
-  int reserved[1];
+  int wgrad_tile;       /* fast weight-gradient kernel: 0 = default (128x128 where M > 64 and C % 128 == 0: 74 KB of LDS, two
+                           workgroups per CU), 1 = 64-row tiles (64x128: 55 KB), 2 = 64x64 tiles (37 KB: four per CU) */
 } HimAlgo;
 /* out = in with every 0 replaced by the default it selects (in == NULL: all defaults). */
 void him_algo_resolve(const HimAlgo* in, HimAlgo* out);

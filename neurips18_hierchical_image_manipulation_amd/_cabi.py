@@ -17,7 +17,7 @@ class HimAlgo(C.Structure):
     """Kernel-selection overrides carried by every descriptor (include/him.h "Algorithm selection"); zero = defaults."""
     _fields_ = [(n, c_int) for n in ('wino_min_c', 'wino_fused_min_c', 'wino_fused_max_c', 'wino4_min_c', 'ksplit_max',
                                      'tile_wb', 'tile_nb', 'wino_tblock', 'wgrad_splits')] + \
-               [('disable', C.c_uint), ('wino_fused_chunk', c_int), ('reserved', c_int * 1)]
+               [('disable', C.c_uint), ('wino_fused_chunk', c_int), ('wgrad_tile', c_int)]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != 'reserved'}
@@ -176,6 +176,11 @@ class _Lib(object):
             raise HimError('libhim_hip.so not built (%s): run `python -c "import __graft_entry__ as g; g.build()"` '
                            'or `make -C neurips18_hierchical_image_manipulation_amd/csrc` -- there is no CPU '
                            'fallback' % LIB_PATH)
+        # torch FIRST: it ships its own libamdhip64 and the library must bind to THAT runtime (the device pointers and
+        # streams it is handed live there).  Loaded before torch, libhim_hip.so pulls in /opt/rocm's copy instead: two HIP
+        # runtimes in one process, and every launch on a torch stream fails with "no ROCm-capable device is detected"
+        # (round 5: `python __graft_entry__.py smoke` = build() -- which loads the library -- and smoke() in ONE process).
+        import torch  # noqa: F401
         dll = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(dll, name)          # AttributeError if the symbol is not exported

@@ -1293,6 +1293,7 @@ void him_algo_resolve(const HimAlgo* in, HimAlgo* out) {
   r.tile_nb = a.tile_nb == HIM_TILE_DEFAULT ? HIM_TILE_64x128 : a.tile_nb;
   r.wino_tblock = algo_tblock(a);
   r.wino_fused_chunk = algo_wino_fused_chunk(a);
+  r.wgrad_tile = (a.wgrad_tile == 1 || a.wgrad_tile == 2) ? a.wgrad_tile : 0;
   *out = r;
 }
 
@@ -1312,6 +1313,7 @@ void him_algo_from_env(HimAlgo* a) {
   a->wino_tblock = geti("HIM_WINO_TBLOCK", 0);
   a->wgrad_splits = geti("HIM_WGRAD_SPLITS", 0);
   a->wino_fused_chunk = geti("HIM_WINO_FUSED_CHUNK", 0);
+  a->wgrad_tile = geti("HIM_WGRAD_TILE", 0);
   const struct { const char* k; unsigned bit; } flags[] = {
       {"HIM_NO_SPLITK", HIM_ALGO_NO_SPLITK},           {"HIM_NO_DFOLD", HIM_ALGO_NO_DFOLD},
       {"HIM_WINO_PADDED_DGRAD", HIM_ALGO_WINO_PADDED_DGRAD}, {"HIM_NO_SMALL_WIN", HIM_ALGO_NO_SMALL_WIN},
