@@ -375,10 +375,12 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=3, help='timed oracle steps of the cpu_baseline leg')
     ap.add_argument('--fake-comm', action='store_true',
-                    help='1-GPU stand-in for the data-parallel gradient exchange: after the normal timed run, attach '
-                         'reducers whose buckets are device-to-device copies of the same bytes (730 MB G + 34 MB D at C2, '
-                         '64 MB buckets) on the comm streams at the real trigger points, time the same steps again and '
-                         'report the step-time delta + the event-timed exposed waits ("fake_comm" in the JSON line)')
+                    help='1-GPU stand-in for the data-parallel gradient exchange: after the normal timed run, a CHILD process '
+                         'builds the same model with reducers attached BEFORE its first step (as a data-parallel rank has them) '
+                         'whose buckets are device-to-device copies of the same bytes (730 MB G + 34 MB D at C2, 64 MB buckets) '
+                         'on the comm streams at the real trigger points, times the same steps and reports the step-time '
+                         'delta + the event-timed exposed waits ("fake_comm" in the JSON line)')
+    ap.add_argument('--fake-comm-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--rccl-channels', type=int, default=0,
                     help='N > 1: cap RCCL at this many channels (NCCL_MAX_NCHANNELS; each channel is a workgroup = CUs taken '
                          'from the compute streams); 0 = the library default.  Printed under "ranks"')
@@ -417,6 +419,8 @@ def main():
     model.netG.load_state_dict(synth.init_state_dict(model.netG.state_dict(), 1))
     model.netD.load_state_dict(synth.init_state_dict(model.netD.state_dict(), 2))
     attach_data_parallel(model, tail_bytes=int(args.tail_mb * (1 << 20)))
+    if args.fake_comm_child:
+        attach_data_parallel(model, fake=True, tail_bytes=int(args.tail_mb * (1 << 20)))
 
     # synthetic batches, resident in HBM before the timed region (4 distinct batches per rank, cycled; seeded by rank)
     if args.workload == 'box2mask':
@@ -448,7 +452,7 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    timing_on = world > 1 and hasattr(model, 'start_comm_timing')
+    timing_on = (world > 1 or args.fake_comm_child) and hasattr(model, 'start_comm_timing')
     if timing_on:
         model.start_comm_timing()          # event pairs around every wait for the exchange (dist.timed_wait)
     torch.cuda.synchronize()
@@ -461,33 +465,39 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     identical = exposed = fake = None
-    if args.fake_comm and world == 1 and args.workload != 'box2mask':
-        # the exchange stand-in (dist.GradReducer(fake=True)): same step, same batches, reducers attached
-        dt0 = dt
-        attach_data_parallel(model, fake=True, tail_bytes=int(args.tail_mb * (1 << 20)))
-        for i in range(max(args.warmup, 2)):
-            step(i)
-        torch.cuda.synchronize()
-        model.start_comm_timing()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(args.warmup + i)
-        torch.cuda.synchronize()
-        dt1 = time.perf_counter() - t0
+    if args.fake_comm_child:
         ex = model.read_comm_timing(args.steps)
         nbytes = sum(4 * r.flat.numel() for r in (model.reducer_G, model.reducer_D) if r is not None)
-        fake = dict(ms_per_step_without=round(dt0 / args.steps * 1e3, 3), ms_per_step_with=round(dt1 / args.steps * 1e3, 3),
-                    delta_ms=round((dt1 - dt0) / args.steps * 1e3, 3), bytes_per_step=nbytes,
-                    buckets=[len(r.buckets) for r in (model.reducer_G, model.reducer_D) if r is not None],
+        print(json.dumps({'fake_comm_child': dict(ms_per_step=round(dt / args.steps * 1e3, 3), bytes_per_step=nbytes,
+                                                  buckets=[len(r.buckets) for r in (model.reducer_G, model.reducer_D)
+                                                           if r is not None], exposed_comm_ms=ex)}), flush=True)
+        return
+    if args.fake_comm and world == 1 and args.workload != 'box2mask':
+        # The exchange stand-in (dist.GradReducer(fake=True)) in a CHILD process: same workload, same batches, reducers
+        # attached before the first step.  (Rounds 3-4 attached them to THIS process's model after the timed run: the step
+        # time of a model depends on what it ran before -- stream / allocator history; round 5 measured 56.4 ms for reducers
+        # attached after a baseline phase with the early arena fill against 52.9 ms for the same reducers attached from the
+        # start, profiles/r05_ab_log.txt -- and a data-parallel rank has them from the start.)
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), '--steps', str(args.steps), '--warmup', str(max(args.warmup, 2)),
+               '--workload', args.workload, '--tail-mb', str(args.tail_mb), '--fake-comm-child', '--no-roofline',
+               '--no-cpu-baseline'] + (['--g-backward-first'] if args.g_backward_first else [])
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1800)
+        lines = [l for l in r.stdout.splitlines() if l.startswith('{"fake_comm_child"')]
+        if r.returncode != 0 or not lines:
+            raise SystemExit('bench.py --fake-comm: the child run failed:\n' + r.stdout[-1500:] + r.stderr[-3000:])
+        ch = json.loads(lines[-1])['fake_comm_child']
+        ex = ch['exposed_comm_ms']
+        fake = dict(ms_per_step_without=round(dt / args.steps * 1e3, 3), ms_per_step_with=ch['ms_per_step'],
+                    delta_ms=round(ch['ms_per_step'] - dt / args.steps * 1e3, 3), bytes_per_step=ch['bytes_per_step'],
+                    buckets=ch['buckets'],
                     what='device-to-device copies of the gradient buckets on the optimizer streams at the real trigger '
-                         'points (no second GPU): scheduling + HBM cost of the exchange, not xGMI time',
+                         'points (no second GPU), in a child process whose reducers are attached before its first step: '
+                         'scheduling + HBM cost of the exchange, not xGMI time',
                     exposed_comm_ms=ex,
                     main_stream_upper_bound_ms=round(ex['g_update_tail'] + ex['d_update_wait'] +
                                                      min(ex.get('d_update_wait_real', 0.0),
                                                          ex.get('real_branch_join', 0.0)), 4))
-        model.reducer_G = model.reducer_D = None
-        for p in list(model.netG.parameters()) + list(model.netD.parameters()):
-            p.__dict__.pop('_him_reducer', None)
     if world > 1:
         if timing_on:
             mine = model.read_comm_timing(args.steps)
