@@ -223,7 +223,7 @@ def dominant_kernel_roofline(device, bs, ntiles):
                                  executed_tflops=round(flops / (cms * 1e-3) / 1e12, 1)))
 
 
-def step_flop_accounting(ms_per_step, bs):
+def step_flop_accounting(ms_per_step, bs, variant=None):
     """Whole-step roofline of the C2 workload: SURVEY 8(d)'s direct-form count (3 F_G + 9 F_D + 3 F_V = 1225 GFLOP per
     image) minus what this build does not execute, over the measured step time."""
     f_g, f_d, f_v = 246.3, 22.4, 94.7                        # GFLOP per image, forward, direct form (SURVEY appendix A)
@@ -241,6 +241,8 @@ def step_flop_accounting(ms_per_step, bs):
         # round 5: first PatchGAN conv of scale 0 (4x4 s2, 41 -> 64 @ 129x257) reads the 35 one-hot channels as table lookups
         # / run-length sums: 2 forward passes (real, shared fake) + 2 weight gradients
         terms['d_scale0_first_conv_from_label_ids'] = 4 * 2.0 * 64 * 35 * 16 * (bs * 129 * 257) / 1e12
+    if variant == 'f4x4-resblock-fwd':
+        terms['winograd_f4x4_resblock_forward_18_launches'] = 18 * (34.360 - 19.327) / 1e3
     executed = direct - sum(terms.values())
     return dict(direct_form_tflop=round(direct, 3), not_executed_tflop={k: round(v, 3) for k, v in terms.items()},
                 step_executed_tflop=round(executed, 3),
@@ -294,6 +296,8 @@ def g_forward_roofline(model, batch, wl):
         executed = direct
         if 0 < wino <= 1024:            # 18 ResnetBlock convs: 34.36 instead of 77.31 GFLOP each
             executed -= 18 * (77.309 - 34.360) / 1e3
+            if ops.resolved_algo()['disable'] & (1 << 13):      # --variant f4x4-resblock-fwd: 19.33 GFLOP each
+                executed -= 18 * (34.360 - 19.327) / 1e3
         if config.SCHED.onehot_stem:              # stem conv7x7 38->64: the 35 one-hot channels are LDS lookups, 3 dense ones stay
             executed -= 2.0 * 64 * 35 * 49 * (bs * H * W) / 1e12
         out.update(tflops_executed=round(executed / (ms * 1e-3), 2),
@@ -386,6 +390,11 @@ def main():
                          'from the compute streams); 0 = the library default.  Printed under "ranks"')
     ap.add_argument('--tail-mb', type=float, default=8.0,
                     help='gradient reducer: size cap of the LAST bucket to become final (dist.GradReducer tail_bytes); 0 = no split')
+    ap.add_argument('--variant', choices=['f4x4-resblock-fwd'], default=None,
+                    help="OPT-IN reduced-work variant, reported as its OWN line (never the headline; VERDICT r4 item 7): "
+                         "f4x4-resblock-fwd = the forward of the generator's ResnetBlock convolutions as Winograd F(4x4,3x3) "
+                         "(HIM_ALGO_WINO4_TRAIN_FWD: 19.3 instead of 34.4 GFLOP per conv, ~3e-6 instead of 5e-7 relative "
+                         "rounding per convolution); the line carries 'variant' and says so in 'dtype'")
     ap.add_argument('--g-backward-first', action='store_true',
                     help="A/B of the step order (DESIGN.md 6): loss_G.backward() BEFORE loss_D.backward() (the reference's own "
                          "order, train_mask2image.py:78-86) -- G's 730 MB exchange then has D's whole backward to hide under; "
@@ -402,6 +411,10 @@ def main():
     from neurips18_hierchical_image_manipulation_amd import synth, config
     if args.g_backward_first:
         config.SCHED.d_backward_first = False
+    if args.variant == 'f4x4-resblock-fwd':
+        from neurips18_hierchical_image_manipulation_amd import ops as _ops
+        from neurips18_hierchical_image_manipulation_amd._cabi import ALGO_WINO4_TRAIN_FWD
+        _ops.current_algo().disable |= ALGO_WINO4_TRAIN_FWD
     from neurips18_hierchical_image_manipulation_amd.dist import (init_process_group_from_env, attach_data_parallel,
                                                                   replica_checksum_equal)
     from neurips18_hierchical_image_manipulation_amd.models import create_model
@@ -517,10 +530,14 @@ def main():
             'metric': wl['metric'],
             'value': round(bs * world * args.steps / dt, 3), 'unit': 'images/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if not args.variant else 'f32 (Winograd F(4x4,3x3) in the ResnetBlock forward: 3e-6 instead of '
+                                                    '5e-7 relative rounding per convolution; NOT the headline configuration)',
+            'data': 'synthetic',
             'config': {'workload': wl['desc'], 'global_batch': bs * world, 'per_gpu_batch': bs,
                        'parallelism': 'dp%d' % world},
             'last_losses': {k: _f(v) for k, v in losses.items()},
+            **({'variant': args.variant} if args.variant else {}),
             'schedule': {'d_backward_first': bool(config.SCHED.d_backward_first), 'adam_chunked': bool(config.SCHED.adam_chunked),
                          'd_from_ids': bool(config.SCHED.d_from_ids and config.SCHED.label_ids)},
         }
@@ -550,7 +567,7 @@ def main():
                 out['roofline'] = dominant_kernel_roofline(device, bs, ntiles)
                 out['g_forward'] = g_forward_roofline(model, batches[0], wl)
                 if args.workload == 'c2':
-                    out['step_roofline'] = step_flop_accounting(ms, bs)
+                    out['step_roofline'] = step_flop_accounting(ms, bs, args.variant)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.workload, wl, args.cpu_steps)
         print(json.dumps(out), flush=True)

@@ -83,6 +83,11 @@ const char* him_last_error(void);
 #define HIM_ALGO_NO_ONEHOT_RLE (1u << 11)   /* one-hot stem weight gradient per pixel (round-1 kernel) instead of per run of equal class */
 #define HIM_ALGO_NO_FEWIN_FOLD (1u << 12)    /* reflection-padded few-channel data gradient (generator head) through the padded
                                                gradient + reflect_fold pass instead of the fold inside the tiled kernel */
+#define HIM_ALGO_WINO4_TRAIN_FWD (1u << 13)  /* OPT-IN, reduced-work variant: the FORWARD of trainable 3x3 s1 p1
+                                               layers with >= wino4_min_c channels (the ResnetBlock stack) as Winograd
+                                               F(4x4,3x3) -- 1.78x fewer multiplies than F(2x2), ~3e-6 instead of 5e-7 relative
+                                               rounding per convolution; data / weight gradients stay F(2x2).  Never the
+                                               default: reported as its own bench line (bench.py --variant) */
 #define HIM_ALGO_FROZEN_WEIGHTS (1u << 9)   /* the layer's weights never change (VGG19 of the perceptual loss,
                                                models/layer_util.py:380-411): forward / data gradient may use Winograd
                                                F(4x4,3x3), whose 36-position panel is built once per run */

@@ -877,7 +877,8 @@ static bool wino_fused_dgrad_ok(const HimConv2d* d) {
 }
 // F(4x4,3x3) for frozen-weight layers (him_conv_wino4.inc); checked BEFORE the F(2x2,3x3) forms
 static bool wino4_fwd_ok(const HimConv2d* d) {
-  return wino4_shape_ok(d->algo, d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad, d->pad_mode, d->B, d->H, d->W);
+  return wino4_shape_ok(d->algo, d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad, d->pad_mode, d->B, d->H, d->W) ||
+         wino4_shape_ok(d->algo, d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad, d->pad_mode, d->B, d->H, d->W, true);
 }
 static bool wino4_dgrad_ok(const HimConv2d* d) {
   return d->OH == d->H && d->OW == d->W &&
@@ -934,7 +935,8 @@ static int run_fprop(const HimConv2d* d, const float* x, const float* w, const f
       int rc = check_launch("wino4_weight");
       if (rc || build_only) return rc;
     }
-    return run_wino4_conv(d->B, d->Cin, d->H, d->W, d->Cout, x, panel ? panel : U, bias, d->act, d->slope, y, U + pf, st);
+    return run_wino4_conv(d->B, d->Cin, d->H, d->W, d->Cout, x, panel ? panel : U, bias, d->act, d->slope, y, U + pf, st,
+                          nullptr, d->pad_mode == HIM_PAD_REFLECT);
   }
   if (wino_fused_fwd_ok(d)) {
     if (!panel) {
@@ -1320,7 +1322,8 @@ void him_algo_from_env(HimAlgo* a) {
       {"HIM_NO_FEWOUT_TILED", HIM_ALGO_NO_FEWOUT_TILED}, {"HIM_NO_FEWIN_TILED", HIM_ALGO_NO_FEWIN_TILED},
       {"HIM_NO_FEWCH_MFMA", HIM_ALGO_NO_FEWCH_MFMA},   {"HIM_GENERIC_CONV", HIM_ALGO_GENERIC_CONV},
       {"HIM_NO_RESBLOCK_FUSED", HIM_ALGO_NO_RESBLOCK_FUSED}, {"HIM_NO_BGEMM", HIM_ALGO_NO_BGEMM},
-      {"HIM_NO_ONEHOT_RLE", HIM_ALGO_NO_ONEHOT_RLE},   {"HIM_NO_FEWIN_FOLD", HIM_ALGO_NO_FEWIN_FOLD}};
+      {"HIM_NO_ONEHOT_RLE", HIM_ALGO_NO_ONEHOT_RLE},   {"HIM_NO_FEWIN_FOLD", HIM_ALGO_NO_FEWIN_FOLD},
+      {"HIM_WINO4_TRAIN_FWD", HIM_ALGO_WINO4_TRAIN_FWD}};
   for (const auto& f : flags)
     if (getenv(f.k)) a->disable |= f.bit;
 }

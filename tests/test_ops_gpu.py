@@ -1071,3 +1071,36 @@ def test_fused_winograd_kernel_at_80_kb_of_lds(case):
         assert_close('dgrad chunk %d' % ck, gx, gx_ref, rtol=2e-5)
         got[ck] = y.detach()
     assert_close('chunk 4 vs chunk 8', got[4], got[8].cpu(), rtol=2e-6)
+
+
+@pytest.mark.parametrize('case', [(8, 256, 16, 32, 256, 'reflect'), (8, 256, 16, 32, 256, 'zero'), (4, 512, 32, 32, 256, 'reflect')],
+                         ids=str)
+def test_opt_in_f4x4_forward_of_trainable_layers(case):
+    """HIM_ALGO_WINO4_TRAIN_FWD (an OPT-IN reduced-work variant, reported as its own bench line): the
+    FORWARD of a trainable 3x3 stride-1 pad-1 layer with >= 256 channels as Winograd F(4x4,3x3), zero or reflection padding;
+    data and weight gradients stay on the F(2x2) kernels.  Forward within 3e-5 of max|ref| (F(4x4)'s rounding), gradients
+    within 2e-5, and the output differs from the default build's (the switch really selects the other kernels)."""
+    ops = _ops()
+    from neurips18_hierchical_image_manipulation_amd._cabi import ALGO_WINO4_TRAIN_FWD
+    B, Cin, H, W, Cout, mode = case
+    x = _rand(B, Cin, H, W, seed=1).requires_grad_(True)
+    w = _rand(Cout, Cin, 3, 3, seed=2, scale=(Cin * 9) ** -0.5).requires_grad_(True)
+    b = _rand(Cout, seed=3, scale=0.1)
+    y_ref = _ref_conv(x, w, b, 1, 1, mode, 'none')
+    gy = _rand(*y_ref.shape, seed=4)
+    gx_ref, gw_ref = torch.autograd.grad(y_ref, (x, w), gy)
+    got = {}
+    for bit in (ALGO_WINO4_TRAIN_FWD, 0):
+        with ops.algo_scope(disable=bit, wino_min_c=256, wino4_min_c=256):
+            xd = x.detach().to(DEV).requires_grad_(True)
+            wd = torch.nn.Parameter(w.detach().to(DEV))
+            y = ops.conv2d(xd, wd, b.to(DEV), 1, 1, mode, 'none')
+            gx, gw = torch.autograd.grad(y, (xd, wd), gy.to(DEV))
+            if bit:
+                d = ops._conv_desc(xd, wd, 1, 1, 1 if mode == 'reflect' else 0, 0, 0.2)
+                assert int(ops.lib.him_conv2d_panel_layout(ctypes.byref(d), 0)) == 4, 'the switch must select the F(4x4) forward'
+        assert_close('fwd (bit %d)' % bit, y, y_ref, rtol=3e-5 if bit else 2e-5)
+        assert_close('dgrad (bit %d)' % bit, gx, gx_ref, rtol=2e-5)
+        assert_close('wgrad (bit %d)' % bit, gw, gw_ref, rtol=2e-5)
+        got[bit] = y.detach()
+    assert not torch.equal(got[0], got[ALGO_WINO4_TRAIN_FWD])
