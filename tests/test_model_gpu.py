@@ -299,7 +299,7 @@ def _post_step_state_errors(model, om, before):
 # of 6), so a quantile of a handful of steps is a lottery between the modes while a kernel defect raises the baseline of
 # EVERY step; when the regular steps hold no baseline-level HIP sample of some bimodal tensor, extra (HIP step, float64 step)
 # samples are drawn from the oracle's current state on fresh batches (~1.5 s each, no fp32 host step) until one appears --
-# at most 40, after which the bound fails.  Unimodal tensors (every generator tensor) keep quartile + median.
+# at most 100, after which the bound fails.  Unimodal tensors (every generator tensor) keep quartile + median.
 PARITY_K_TYPICAL, PARITY_K_TYPICAL_WINOGRAD, PARITY_K_EVENT, PARITY_FLOOR = 4.0, 6.0, 10.0, 1e-5
 PARITY_LOSS_TOL = 5e-6
 ADAM_TOL = dict(exp_avg=1e-6, exp_avg_sq=1e-6, delta=2.5e-4)    # measured worst over 20 C1 steps: 1.7e-7 / 8.3e-8 / 1.25e-4
@@ -433,7 +433,7 @@ def _teacher_forced_run(tag, steps, loss_tol, anchor, golden, batch_fn, plumbing
     # baseline".  What a kernel defect raises is the BASELINE -- it is there in every step -- so for these tensors the bound is
     # on the MINIMUM over the samples, and samples are cheap now: a HIP step + the float64 step on the GPU from the oracle's
     # current state on a fresh batch cost ~1.5 s (no fp32 host step: the oracle's yard-stick comes from the steps above and
-    # the committed anchor).  Drawn only while some bimodal tensor has no baseline-level HIP sample yet, at most 40.
+    # the committed anchor).  Drawn only while some bimodal tensor has no baseline-level HIP sample yet, at most 100.
     extra, extra_min, extra_base = 0, {}, {}
     if om64 is not None and len(e_hip_steps) >= 6:
         names_ = list(e_hip_steps[0].keys())
@@ -447,7 +447,7 @@ def _teacher_forced_run(tag, steps, loss_tol, anchor, golden, batch_fn, plumbing
         # (arena + moments of the HIP model, parameters + Adam state of the float64 oracle) -- a host round trip of 183 M
         # parameters per sample would cost more than the two steps
         snap_hip = snap64 = None
-        while extra < 40 and any(extra_min[n_] > k_typical * max(o_min[n_], PARITY_FLOOR) for n_ in bimodal):
+        while extra < 100 and any(extra_min[n_] > k_typical * max(o_min[n_], PARITY_FLOOR) for n_ in bimodal):
             if snap_hip is None:
                 _adopt(model, om)
                 fa.adopt64(om64, om)
