@@ -240,6 +240,18 @@ int him_conv2d_onehot_fwd_dense(const HimConv2d* d, const float* label, int n_on
 int him_conv2d_onehot_bwd_weight_dense(const HimConv2d* d, const float* label, int n_onehot, const float* xdense,
                                        const float* dy, float* dw, float* dbias, int accumulate, void* ws,
                                        size_t ws_bytes, void* stream);
+/* (3) The weight gradient in two independently launchable parts, for callers that own two streams: HIM_ONEHOT_PART_IDS = the
+ * label-id channels' slice of dw (run-length kernel: LDS-bound, one workgroup per CU, 1.1 ms at the generator stem of
+ * 512x256 bs 8), HIM_ONEHOT_PART_DENSE = the dense channels' slice of dw (an MFMA weight gradient) + dbias.  The parts write
+ * disjoint elements of dw and use disjoint regions of ws; on two streams they run next to each other (the stem's weight
+ * gradient is the LAST kernel chain of the generator's backward, netG.model[1] of models/Pix2Pix_NET.py:74, and what the
+ * next step's generator forward waits for).  x: the (B, Cin, H, W) concatenation, or the dense channels alone when
+ * x_is_dense != 0.  parts == IDS | DENSE is the one-call form above. */
+#define HIM_ONEHOT_PART_IDS 1
+#define HIM_ONEHOT_PART_DENSE 2
+int him_conv2d_onehot_bwd_weight_part(const HimConv2d* d, const float* label, int n_onehot, const float* x, int x_is_dense,
+                                      const float* dy, float* dw, float* dbias, int accumulate, void* ws, size_t ws_bytes,
+                                      int parts, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Weight panels.  The MFMA kernels read the weights regrouped (forward: [Cout][Cin/16][KH][KW][16]; data

@@ -38,13 +38,14 @@ class Schedule(object):
         'dead_bias_skip': ('HIM_DEAD_BIAS_SKIP', True, 'no bias gradient in front of a mean-subtracting norm'),
         'panel_pipeline': ('HIM_PANEL_PIPELINE', False, "the next generator forward waits for G's Adam kernel and, per layer, for that layer's rebuilt weight panel -- not for the whole panel rebuild pass"),
         'lincomb': ('HIM_LINCOMB', True, 'scalar loss arithmetic as one launch (him_lincomb) instead of one-element ATen ops'),
-        'd_update_early': ('HIM_D_UPDATE_EARLY', False, "D's exchange + Adam step start inside loss_G.backward(), as soon as the gradient has passed back through the discriminator (its last reader of the step), instead of after the generator's whole backward"),
+        'd_update_early': ('HIM_D_UPDATE_EARLY', True, "D's exchange + Adam step start inside loss_G.backward(), as soon as the gradient has passed back through the discriminator (its last reader of the step), instead of after the generator's whole backward"),
         'inputs_on_real_stream': ('HIM_INPUTS_ON_REAL_STREAM', False, "input encoding on the real-image stream: with D updated early, the NEXT step's encoding + D(real) + VGG(real) run under this step's generator backward / Adam instead of behind them"),
         'real_vgg_first': ('HIM_REAL_VGG_FIRST', False, "real-image stream: VGG(real) in front of the wait for D's update and D(real)"),
         'zero_grad_side': ('HIM_ZERO_GRAD_SIDE', True, 'one rank: optimize_parameters() zeroes the gradient arenas on the weight-gradient stream before the forward pass (under it) instead of on the main stream in front of the backward pass; with a gradient exchange attached the fill stays on the main stream'),
         'conv_in_fused': ('HIM_CONV_IN_FUSED', True, 'Conv2d -> InstanceNorm [-> act] blocks through him_conv2d_in_act_fwd: split-K layers hand their slabs to the InstanceNorm kernel (no finish pass)'),
         'adam_chunked': ('HIM_ADAM_CHUNKED', False, "the generator's Adam step + panel rebuild bucket by bucket DURING its backward pass, as each 64 MB gradient bucket becomes final (and, data parallel, has been exchanged), instead of one 5 GB pass behind the last weight gradient"),
         'adam_split_stem': ('HIM_ADAM_SPLIT_STEM', True, "GlobalGenerator: the generator's Adam step + panel rebuild for everything but the stem starts behind the LAST data gradient, next to the stem's run-length weight gradient (0.5 ms, LDS-bound, the last kernel of the backward pass) instead of behind it; the stem's slice follows (FusedAdam.begin_step / step_range / step: bit-identical)"),
+        'stem_wgrad_fork': ('HIM_STEM_WGRAD_FORK', True, "one-hot stem convolutions with dense channels: the dense channels' slice of the weight gradient (MFMA) + the bias gradient on the data-gradient stream, next to the label-id slice (run-length kernel, LDS-bound) on the weight-gradient stream (him_conv2d_onehot_bwd_weight_part) instead of behind it: the generator stem's weight gradient is the last kernel chain of the step and what the next generator forward waits for"),
         'd_prefill_cond': ('HIM_D_PREFILL_COND', True, "the condition channels of the first PatchGAN conv's input buffers copied at the start of the step (ops.cond_pyramid), only the image channels per pass"),
         'keep_wino_input': ('HIM_KEEP_WINO_INPUT', True, "forward keeps the Winograd-transformed input for the layer's weight gradient"),
     }
@@ -68,7 +69,7 @@ SCHED = Schedule()
 # every stream of the step switched off: the reference's own order on ONE stream
 SERIAL = dict(wgrad_stream=False, d_wgrad_routes=False, real_ahead=False, d_backward_first=False, vgg_stream=False,
               vgg_backward_early=False, d_scale_streams=False, d_update_early=False, inputs_on_real_stream=False,
-              zero_grad_side=False, real_vgg_first=False, adam_chunked=False, adam_split_stem=False)
+              zero_grad_side=False, real_vgg_first=False, adam_chunked=False, adam_split_stem=False, stem_wgrad_fork=False)
 
 
 @contextlib.contextmanager

@@ -1589,9 +1589,15 @@ size_t him_conv2d_onehot_bwd_weight_ws(const HimConv2d* d, int n_onehot) {
   return (d && !check_conv(d) && onehot_ok(d, n_onehot)) ? onehot_wgrad_ws_bytes(d, n_onehot) + bias_ws_bytes(d->Cout) : 0;
 }
 
+// parts: HIM_ONEHOT_PART_IDS = the label-id channels' slice of dw (run-length kernel + reduce), HIM_ONEHOT_PART_DENSE = the
+// dense channels' slice of dw (MFMA weight gradient) + dbias.  The two write disjoint elements and use disjoint regions of ws.
 static int onehot_bwd_weight_impl(const HimConv2d* d, const float* label, int n_onehot, const float* x, bool x_dense,
                                   const float* dy, float* dw, float* dbias, int accumulate, void* ws, size_t ws_bytes,
-                                  void* stream) {
+                                  void* stream, int parts = HIM_ONEHOT_PART_IDS | HIM_ONEHOT_PART_DENSE) {
+  float* const dw_ids = (parts & HIM_ONEHOT_PART_IDS) ? dw : nullptr;
+  if (!(parts & HIM_ONEHOT_PART_DENSE)) dbias = nullptr;
+  float* const dw_all = dw;
+  dw = dw_ids;
   int rc = check_conv(d);
   if (rc) return rc;
   if (!onehot_ok(d, n_onehot)) return fail(HIM_E_UNSUPPORTED, "onehot conv: unsupported descriptor");
@@ -1649,6 +1655,7 @@ static int onehot_bwd_weight_impl(const HimConv2d* d, const float* label, int n_
     rc = check_launch("onehot_wgrad");
     if (rc) return rc;
   }
+  dw = (parts & HIM_ONEHOT_PART_DENSE) ? dw_all : nullptr;
   if (dw) {
     if (Cd > 0) {
       float* dwd = xd + ((size_t)d->B * Cd * HW + 63) / 64 * 64;
@@ -1683,6 +1690,15 @@ int him_conv2d_onehot_bwd_weight_dense(const HimConv2d* d, const float* label, i
   if (d && d->Cin > n_onehot && dw && !xdense)
     return fail(HIM_E_INVALID, "onehot conv: %d dense channels but no dense tensor", d->Cin - n_onehot);
   return onehot_bwd_weight_impl(d, label, n_onehot, xdense, true, dy, dw, dbias, accumulate, ws, ws_bytes, stream);
+}
+int him_conv2d_onehot_bwd_weight_part(const HimConv2d* d, const float* label, int n_onehot, const float* x, int x_is_dense,
+                                      const float* dy, float* dw, float* dbias, int accumulate, void* ws, size_t ws_bytes,
+                                      int parts, void* stream) {
+  if (!(parts & (HIM_ONEHOT_PART_IDS | HIM_ONEHOT_PART_DENSE)) || (parts & ~(HIM_ONEHOT_PART_IDS | HIM_ONEHOT_PART_DENSE)))
+    return fail(HIM_E_INVALID, "onehot conv bwd_weight: parts = %d", parts);
+  if (d && d->Cin > n_onehot && dw && (parts & HIM_ONEHOT_PART_DENSE) && !x)
+    return fail(HIM_E_INVALID, "onehot conv: %d dense channels but no input tensor", d->Cin - n_onehot);
+  return onehot_bwd_weight_impl(d, label, n_onehot, x, x_is_dense != 0, dy, dw, dbias, accumulate, ws, ws_bytes, stream, parts);
 }
 
 size_t him_deconv2d_fwd_ws(const HimDeconv2d* t) {

@@ -17,7 +17,7 @@ import threading
 import torch
 
 from ._cabi import (lib, HimAlgo, HimConv2d, HimDeconv2d, HimResBlock, ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID,
-                    PAD_ZERO, PAD_REFLECT, HimError)
+                    PAD_ZERO, PAD_REFLECT, HimError, ONEHOT_PART_IDS, ONEHOT_PART_DENSE)
 
 ACTS = {'none': ACT_NONE, 'relu': ACT_RELU, 'lrelu': ACT_LRELU, 'tanh': ACT_TANH, 'sigmoid': ACT_SIGMOID}
 
@@ -556,10 +556,28 @@ class _OneHotConv2d(torch.autograd.Function):
                     ev_main.record(cur)
                     ev_side.record(side)
                     _STEM_PRE[dev] = (ev_main, ev_side, tuple(w._him_arena_range), id(w))
+                fork = SCHED.stem_wgrad_fork and SCHED.wgrad_stream and d.Cin > ctx.n_onehot
+                if fork:
+                    # the dense channels' slice (an MFMA weight gradient) + the bias gradient on THIS stream -- it has just
+                    # delivered dz and, for a generator stem, has nothing left to do -- next to the label-id slice (run-length
+                    # kernel, LDS-bound, 1.1 ms at C2) on the weight-gradient stream: disjoint elements of w.grad, disjoint
+                    # workspace regions, a workspace each (a block of the other stream's pool may still be in use there)
+                    ws_d = _ws(nb, label)
+                    lib.him_conv2d_onehot_bwd_weight_part(ctypes.byref(d), _p(label), ctx.n_onehot, _p(x), int(ctx.dense_only),
+                                                          _p(dz), _p(w.grad), _p(b.grad) if need_b else 0, 1, _p(ws_d), nb,
+                                                          ONEHOT_PART_DENSE, st)
+                    dense_done = torch.cuda.Event()
+                    dense_done.record(torch.cuda.current_stream(label.device))
                 with _wgrad_stream(x, dz, label):
                     ws = _ws(nb, label)
-                    bw(ctypes.byref(d), _p(label), ctx.n_onehot, _p(x), _p(dz), _p(w.grad),
-                       _p(b.grad) if need_b else 0, 1, _p(ws), nb, _stream())
+                    if fork:
+                        lib.him_conv2d_onehot_bwd_weight_part(ctypes.byref(d), _p(label), ctx.n_onehot, _p(x),
+                                                              int(ctx.dense_only), _p(dz), _p(w.grad), 0, 1, _p(ws), nb,
+                                                              ONEHOT_PART_IDS, _stream())
+                        torch.cuda.current_stream(label.device).wait_event(dense_done)   # w.grad is final behind BOTH parts
+                    else:
+                        bw(ctypes.byref(d), _p(label), ctx.n_onehot, _p(x), _p(dz), _p(w.grad),
+                           _p(b.grad) if need_b else 0, 1, _p(ws), nb, _stream())
                     _notify(w)
                     if need_b:
                         _notify(b)
