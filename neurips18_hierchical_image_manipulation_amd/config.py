@@ -38,7 +38,7 @@ class Schedule(object):
         'dead_bias_skip': ('HIM_DEAD_BIAS_SKIP', True, 'no bias gradient in front of a mean-subtracting norm'),
         'panel_pipeline': ('HIM_PANEL_PIPELINE', False, "the next generator forward waits for G's Adam kernel and, per layer, for that layer's rebuilt weight panel -- not for the whole panel rebuild pass"),
         'lincomb': ('HIM_LINCOMB', True, 'scalar loss arithmetic as one launch (him_lincomb) instead of one-element ATen ops'),
-        'd_update_early': ('HIM_D_UPDATE_EARLY', True, "D's exchange + Adam step start inside loss_G.backward(), as soon as the gradient has passed back through the discriminator (its last reader of the step), instead of after the generator's whole backward"),
+        'd_update_early': ('HIM_D_UPDATE_EARLY', True, "one rank: D's Adam step starts inside loss_G.backward(), as soon as the gradient has passed back through the discriminator (its last reader of the step), instead of after the generator's whole backward -- the next step's real-image branch then starts under the generator's Adam step; with a gradient exchange attached the update stays behind the backward pass"),
         'inputs_on_real_stream': ('HIM_INPUTS_ON_REAL_STREAM', False, "input encoding on the real-image stream: with D updated early, the NEXT step's encoding + D(real) + VGG(real) run under this step's generator backward / Adam instead of behind them"),
         'real_vgg_first': ('HIM_REAL_VGG_FIRST', False, "real-image stream: VGG(real) in front of the wait for D's update and D(real)"),
         'zero_grad_side': ('HIM_ZERO_GRAD_SIDE', True, 'one rank: optimize_parameters() zeroes the gradient arenas on the weight-gradient stream before the forward pass (under it) instead of on the main stream in front of the backward pass; with a gradient exchange attached the fill stays on the main stream'),

@@ -611,11 +611,15 @@ class Pix2PixHDModel_condImg(BaseModel):
             # discriminator to the fake image (ops._GradSwitch.backward, autograd's thread) -- nothing reads D's weights
             # after that, so the update (and with it the next step's real-image branch, which waits for nothing else) no
             # longer queues behind the generator's whole backward.  Without a shared fake pass: after the backward, as before.
-            if SCHED.d_update_early and self._fake_gate is not None:
+            # One rank only: next to a gradient exchange the early update measures the same step (52.33 vs 52.28 ms with the
+            # exchange stand-in, profiles/r05_ab_log.txt) and would move D's collectives in front of G's in issue order --
+            # data-parallel ranks keep the order every multi-rank test has run
+            d_early = SCHED.d_update_early and self.reducer_G is None and self.reducer_D is None
+            if d_early and self._fake_gate is not None:
                 self._fake_gate['on_open_backward'] = self._d_update
             ops.take_stem_pre(self.device)      # a stale record of an earlier backward (backward_G(), another model)
             self._run_backward_G(last=True, extra_root=early)
-            if self._fake_gate is None or self._fake_gate.pop('on_open_backward', None) is not None or not SCHED.d_update_early:
+            if self._fake_gate is None or self._fake_gate.pop('on_open_backward', None) is not None or not d_early:
                 self._d_update()
             # GlobalGenerator is a chain: its stem's backward is the last node, and the stem's run-length weight gradient
             # (0.5 ms, LDS-bound, one workgroup per CU) the last kernel of the pass.  Everything ELSE is final one kernel
