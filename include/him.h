@@ -83,6 +83,9 @@ const char* him_last_error(void);
 #define HIM_ALGO_NO_ONEHOT_RLE (1u << 11)   /* one-hot stem weight gradient per pixel (round-1 kernel) instead of per run of equal class */
 #define HIM_ALGO_NO_FEWIN_FOLD (1u << 12)    /* reflection-padded few-channel data gradient (generator head) through the padded
                                                gradient + reflect_fold pass instead of the fold inside the tiled kernel */
+#define HIM_ALGO_NO_FEWIN_REFLECT (1u << 14) /* forward of a reflection-padded conv with <= 4 input channels (the dense channels of a
+                                               generator stem: 3 -> 64, 7x7) on the generic implicit-GEMM kernel (K = 147 is too
+                                               ragged for it: 0.55 ms at C2) instead of the tiled few-channel kernel (0.3 ms) */
 #define HIM_ALGO_WINO4_TRAIN_FWD (1u << 13)  /* OPT-IN, reduced-work variant: the FORWARD of trainable 3x3 s1 p1
                                                layers with >= wino4_min_c channels (the ResnetBlock stack) as Winograd
                                                F(4x4,3x3) -- 1.78x fewer multiplies than F(2x2), ~3e-6 instead of 5e-7 relative

@@ -1323,7 +1323,7 @@ void him_algo_from_env(HimAlgo* a) {
       {"HIM_NO_FEWCH_MFMA", HIM_ALGO_NO_FEWCH_MFMA},   {"HIM_GENERIC_CONV", HIM_ALGO_GENERIC_CONV},
       {"HIM_NO_RESBLOCK_FUSED", HIM_ALGO_NO_RESBLOCK_FUSED}, {"HIM_NO_BGEMM", HIM_ALGO_NO_BGEMM},
       {"HIM_NO_ONEHOT_RLE", HIM_ALGO_NO_ONEHOT_RLE},   {"HIM_NO_FEWIN_FOLD", HIM_ALGO_NO_FEWIN_FOLD},
-      {"HIM_WINO4_TRAIN_FWD", HIM_ALGO_WINO4_TRAIN_FWD}};
+      {"HIM_WINO4_TRAIN_FWD", HIM_ALGO_WINO4_TRAIN_FWD}, {"HIM_NO_FEWIN_REFLECT", HIM_ALGO_NO_FEWIN_REFLECT}};
   for (const auto& f : flags)
     if (getenv(f.k)) a->disable |= f.bit;
 }

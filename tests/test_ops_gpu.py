@@ -959,6 +959,29 @@ def test_piecewise_adam_step_is_bit_identical_to_the_whole_step():
         ob.step_range(0, 10)                             # outside begin_step() ... step()
 
 
+@pytest.mark.parametrize('case', [(4, 3, 256, 512, 32, 7), (2, 4, 250, 516, 16, 3), (8, 2, 128, 256, 16, 7)],
+                         ids=lambda c: 'x'.join(map(str, c)))
+def test_reflection_padded_few_channel_forward_on_the_tiled_kernel(case):
+    """The dense channels of a generator stem (ReflectionPad2d(3) + Conv2d(3, ngf, 7), models/Pix2Pix_NET.py:74) ran on the
+    generic implicit-GEMM kernel (K = 147: 0.55 ms at C2); the tiled few-channel kernel now mirrors its patch loads
+    (HIM_ALGO_NO_FEWIN_REFLECT switches back).  Against the fp32 torch conv, and bit-identical to the generic kernel."""
+    ops = _ops()
+    from neurips18_hierchical_image_manipulation_amd._cabi import ALGO_NO_FEWIN_REFLECT
+    B, C, H, W, Cout, k = case
+    x, w, b = _rand(B, C, H, W, seed=1), _rand(Cout, C, k, k, seed=2, scale=0.05), _rand(Cout, seed=3, scale=0.1)
+    ref = _ref_conv(x, w, b, 1, k // 2, 'reflect', 'none')
+    got = {}
+    for off in (0, ALGO_NO_FEWIN_REFLECT):
+        with ops.algo_scope(disable=off):
+            got[off] = ops.conv2d(x.to(DEV), w.to(DEV), b.to(DEV), 1, k // 2, 'reflect', 'none')
+    assert_close('reflect few-channel fwd (tiled)', got[0], ref, rtol=2e-5)
+    assert_close('reflect few-channel fwd (generic)', got[ALGO_NO_FEWIN_REFLECT], ref, rtol=2e-5)
+    # same products, same order (channel, tap row, tap column; one fp32 accumulator per output -- the fp32 MFMA adds its two
+    # k-terms one after the other): the tiled kernel reproduces the generic one bit for bit, so switching kernels moved no
+    # parity figure (which kernel ran is visible in a trace only: gconv_fewin_tiled_kernel<7, false, false>, 0.31 vs 0.55 ms)
+    assert torch.equal(got[0], got[ALGO_NO_FEWIN_REFLECT])
+
+
 @pytest.mark.parametrize('n', [1, 3, 8, 9, 19])
 def test_scalar_loss_arithmetic_in_one_launch_matches_the_torch_chain(n):
     """ops.lincomb = the trainer's scalar loss arithmetic (train_mask2image.py:70-71, the per-scale GAN sums of
