@@ -43,4 +43,6 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES 
 done
 python $ROOT/tools/pmc_collect.py wino_fused_kernel 0 $OUT/${TAG}_pmc_wino_fused.json $OUT/pmcf_FETCH_SIZE $OUT/pmcf_WRITE_SIZE $OUT/pmcf_TCC_HIT_sum $OUT/pmcf_SQ_WAVE_CYCLES $OUT/pmcf_SQ_LDS_BANK_CONFLICT > $OUT/pmcf_collect.log 2>&1
 rm -rf $OUT/pmcf_FETCH_SIZE $OUT/pmcf_WRITE_SIZE $OUT/pmcf_TCC_HIT_sum $OUT/pmcf_SQ_WAVE_CYCLES $OUT/pmcf_SQ_LDS_BANK_CONFLICT
+# 5. the schedule from a trace that is not launch-starved (timeline, stream view, step phases, gap map, by-grid stats)
+bash $ROOT/tools/trace_unbound.sh $TAG
 cd $ROOT
