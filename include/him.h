@@ -101,8 +101,9 @@ typedef struct HimAlgo {
   int wino_fused_min_c; /* lower end of the fused single-launch Winograd kernel's channel range; 0 = default (64); < 0: off */
   int wino_fused_max_c; /* upper end; 0 = default (255) */
   int wino4_min_c;      /* FROZEN_WEIGHTS layers with Cin and Cout >= this AND at least 64 output tiles of 4x4 in the batch
-                           (B*H*W >= 1024) run as F(4x4,3x3); 0 = default (256); < 0: off */
-  int ksplit_max;       /* cap of the split-K factor; 0 = default (8) */
+                           (B*H*W >= 1024) run as F(4x4,3x3); 0 = default (128: VGG conv2_2 upwards; 256 until
+                           the last session of round 5 -- in the step -0.34 ms, profiles/r05_ab_log.txt); < 0: off */
+  int ksplit_max;       /* cap of the split-K factor; 0 = default (4; 8 until the last session of round 5: -0.24 ms in the step) */
   int tile_wb, tile_nb; /* HIM_TILE_*: batched Winograd GEMMs / direct-form convolutions */
   int wino_tblock;      /* threads per workgroup of the Winograd transform kernels: 64 (default), 128, 256 */
   int wgrad_splits;     /* fast weight-gradient kernel: split count; 0 = automatic */

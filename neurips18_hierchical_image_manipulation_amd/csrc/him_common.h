@@ -100,8 +100,8 @@ __device__ __forceinline__ unsigned lds_addr_u(const void* p) {
 inline int algo_wino_min_c(const HimAlgo& a) { return a.wino_min_c == 0 ? 256 : a.wino_min_c; }          // <= 0: off
 inline int algo_wino_fused_min_c(const HimAlgo& a) { return a.wino_fused_min_c == 0 ? 64 : a.wino_fused_min_c; }
 inline int algo_wino_fused_max_c(const HimAlgo& a) { return a.wino_fused_max_c == 0 ? 255 : a.wino_fused_max_c; }
-inline int algo_wino4_min_c(const HimAlgo& a) { return a.wino4_min_c == 0 ? 256 : a.wino4_min_c; }
-inline int algo_ksplit_max(const HimAlgo& a) { return a.ksplit_max <= 0 ? 8 : a.ksplit_max; }
+inline int algo_wino4_min_c(const HimAlgo& a) { return a.wino4_min_c == 0 ? 128 : a.wino4_min_c; }
+inline int algo_ksplit_max(const HimAlgo& a) { return a.ksplit_max <= 0 ? 4 : a.ksplit_max; }
 inline int algo_wino_fused_chunk(const HimAlgo& a) { return a.wino_fused_chunk == 4 ? 4 : 8; }
 inline int algo_tblock(const HimAlgo& a) { return (a.wino_tblock == 128 || a.wino_tblock == 256) ? a.wino_tblock : 64; }
 inline bool algo_off(const HimAlgo& a, unsigned bit) { return (a.disable & bit) != 0; }

@@ -140,7 +140,7 @@ def test_kernel_selection_is_a_pure_function_of_the_descriptor():
                     raise AssertionError('mutable static in %s: %s' % (fn, ln.strip()))
     out = _cabi.HimAlgo()
     _cabi.lib.him_algo_resolve(None, ctypes.byref(out))
-    assert out.as_dict() == dict(wino_min_c=256, wino_fused_min_c=64, wino_fused_max_c=255, wino4_min_c=256, ksplit_max=8,
+    assert out.as_dict() == dict(wino_min_c=256, wino_fused_min_c=64, wino_fused_max_c=255, wino4_min_c=128, ksplit_max=4,
                                  tile_wb=_cabi.TILE_64x128, tile_nb=_cabi.TILE_64x128, wino_tblock=64, wgrad_splits=0,
                                  disable=0, wino_fused_chunk=8, wgrad_tile=0)
 

@@ -305,7 +305,7 @@ PARITY_LOSS_TOL = 5e-6
 ADAM_TOL = dict(exp_avg=1e-6, exp_avg_sq=1e-6, delta=2.5e-4)    # measured worst over 20 C1 steps: 1.7e-7 / 8.3e-8 / 1.25e-4
 # Kernel selection is PINNED for the parity runs (it decides the fp32 summation order: split-K depth, tile shape, which
 # layers take a Winograd form) and recorded in every report -- not whatever a process environment would select.
-PINNED_ALGO = dict(wino_min_c=256, wino_fused_min_c=64, wino_fused_max_c=255, ksplit_max=8, tile_wb=4, tile_nb=4,
+PINNED_ALGO = dict(wino_min_c=256, wino_fused_min_c=64, wino_fused_max_c=255, wino4_min_c=128, ksplit_max=4, tile_wb=4, tile_nb=4,
                    wino_tblock=64, wgrad_splits=0, disable=0, wino_fused_chunk=8, wgrad_tile=0)
 
 
