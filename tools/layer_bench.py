@@ -27,8 +27,8 @@ LAYERS = {
     'd1_l3': ('conv', 8, 256, 17, 33, 512, 4, 1, 2, 'zero', False, 'PatchGAN scale 1 layer 3'),
     'vgg1_2': ('conv', 8, 64, 256, 512, 64, 3, 1, 1, 'zero', True, 'VGG conv1_2 (fused Winograd)'),
     'vgg2_1': ('conv', 8, 64, 128, 256, 128, 3, 1, 1, 'zero', True, 'VGG conv2_1 (fused Winograd)'),
-    'vgg2_2': ('conv', 8, 128, 128, 256, 128, 3, 1, 1, 'zero', True, 'VGG conv2_2 (fused Winograd)'),
-    'vgg3_1': ('conv', 8, 128, 64, 128, 256, 3, 1, 1, 'zero', True, 'VGG conv3_1 (fused Winograd)'),
+    'vgg2_2': ('conv', 8, 128, 128, 256, 128, 3, 1, 1, 'zero', True, 'VGG conv2_2 (F(4x4))'),
+    'vgg3_1': ('conv', 8, 128, 64, 128, 256, 3, 1, 1, 'zero', True, 'VGG conv3_1 (F(4x4))'),
     'vgg3_2': ('conv', 8, 256, 64, 128, 256, 3, 1, 1, 'zero', True, 'VGG conv3_2..3_4 (F(4x4))'),
     'vgg4_2': ('conv', 8, 512, 32, 64, 512, 3, 1, 1, 'zero', True, 'VGG conv4_2..4_4 (F(4x4))'),
 }

@@ -39,7 +39,7 @@ def executed_gflop(kernel, spec):
         OH, OW = H * s, W * s
     direct = 2.0 * B * OH * OW * Cin * Cout * k * k / (s * s if kind == 'deconv' else 1) / 1e9
     if kernel.startswith('bgemm_kernel'):
-        return direct / (4.0 if (frozen and Cin >= 256) else 2.25)
+        return direct / (4.0 if (frozen and min(Cin, Cout) >= 128) else 2.25)      # HimAlgo.wino4_min_c = 128
     if kernel.startswith('wino_fused_kernel'):
         return direct / 2.25
     return direct
