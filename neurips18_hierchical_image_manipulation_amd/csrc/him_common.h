@@ -87,6 +87,21 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
       : "v"(gsrc), "s"(lds_dst)
       : "memory");
 }
+// four of them with ONE M0 setup: instruction q moves 1 KB from gsrc + 1024 q (per lane) to lds_dst + 1024 q (the
+// instruction offset applies to the global AND the LDS address)
+__device__ __forceinline__ void glds16x4(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+      "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+      "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
 // wave-uniform LDS byte address of a __shared__ pointer
 __device__ __forceinline__ unsigned lds_addr_u(const void* p) {
   return (unsigned)__builtin_amdgcn_readfirstlane(

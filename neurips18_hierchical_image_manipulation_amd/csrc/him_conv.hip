@@ -27,6 +27,7 @@ namespace him {
 
 #include "him_gconv_fast.inc"
 #include "him_wino_fused.inc"
+#include "him_wino_fused2.inc"
 #include "him_bgemm.inc"
 
 // ---- weight regrouping for the fast path: out[m][cb][jh][jw][c16] = W[base + m*sm + (16cb+c16)*sc + jh*sh + jw*sw]
@@ -867,6 +868,20 @@ static bool wino_fused_ok(const HimAlgo& a, int Co, int Ci, int KH, int KW, int 
   return mc > 0 && algo_wino_min_c(a) > 0 && Ci >= mc && Ci <= algo_wino_fused_max_c(a) && Co >= 64 &&
          wino_fused_shape_ok(Co, Ci, KH, KW, stride, pad, B, H, W);
 }
+// The persistent, wave-specialised form of the fused kernel (him_wino_fused2.inc) takes the launches of the fused range it
+// supports (even W, reduction channels % 8 == 0 and >= 32, NONE / RELU / LRELU epilogue); everything else -- and everything
+// under HIM_ALGO_NO_WINO_FUSED2 -- stays on him_wino_fused.inc.  Same weight panel: the choice is per launch, not per panel.
+static bool wino_fused2_ok(const HimAlgo& a, int Co, int Ci, int B, int H, int W, int act) {
+  return !algo_off(a, HIM_ALGO_NO_WINO_FUSED2) && algo_wino_fused_chunk(a) != 4 && wino_fused2_act_ok(act) &&
+         wino_fused2_shape_ok(Co, Ci, 3, 3, 1, 1, B, H, W);
+}
+// compute units of the current device = workgroups of a persistent launch (a query, not cached: no mutable state)
+static int device_cus() {
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+    return 256;
+  return n > 0 ? n : 256;
+}
 static bool wino_fused_fwd_ok(const HimConv2d* d) {
   return wino_fused_ok(d->algo, d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad, d->B, d->H, d->W);
 }
@@ -947,6 +962,9 @@ static int run_fprop(const HimConv2d* d, const float* x, const float* w, const f
       int rc = check_launch("wino_fused_weight");
       if (rc || build_only) return rc;
     }
+    if (wino_fused2_ok(d->algo, d->Cout, d->Cin, d->B, d->H, d->W, d->act))     // persistent form (round 6), same panel
+      return run_wino_fused2(d->B, d->Cin, d->H, d->W, d->Cout, d->pad_mode == HIM_PAD_REFLECT, x,
+                             panel ? panel : (const float*)ws, bias, d->act, d->slope, y, st, nullptr, device_cus());
     return run_wino_fused(d->B, d->Cin, d->H, d->W, d->Cout, d->pad_mode == HIM_PAD_REFLECT, x,
                           panel ? panel : (const float*)ws, bias, d->act, d->slope, y, st, nullptr,
                           algo_wino_fused_chunk(d->algo) == 4);
@@ -1089,6 +1107,9 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
       if (rcu || build_only) return rcu;
     }
     if (mask_done) *mask_done = relu_mask != nullptr;   // the gate rides in this kernel's epilogue
+    if (wino_fused2_ok(d->algo, d->Cin, d->Cout, d->B, d->OH, d->OW, act))
+      return run_wino_fused2(d->B, d->Cout, d->OH, d->OW, d->Cin, false, gy, panel ? panel : (const float*)ws, bias, act,
+                             slope, out, st, relu_mask, device_cus());
     return run_wino_fused(d->B, d->Cout, d->OH, d->OW, d->Cin, false, gy, panel ? panel : (const float*)ws, bias, act, slope,
                           out, st, relu_mask, algo_wino_fused_chunk(d->algo) == 4);
   }
@@ -1323,7 +1344,8 @@ void him_algo_from_env(HimAlgo* a) {
       {"HIM_NO_FEWCH_MFMA", HIM_ALGO_NO_FEWCH_MFMA},   {"HIM_GENERIC_CONV", HIM_ALGO_GENERIC_CONV},
       {"HIM_NO_RESBLOCK_FUSED", HIM_ALGO_NO_RESBLOCK_FUSED}, {"HIM_NO_BGEMM", HIM_ALGO_NO_BGEMM},
       {"HIM_NO_ONEHOT_RLE", HIM_ALGO_NO_ONEHOT_RLE},   {"HIM_NO_FEWIN_FOLD", HIM_ALGO_NO_FEWIN_FOLD},
-      {"HIM_WINO4_TRAIN_FWD", HIM_ALGO_WINO4_TRAIN_FWD}, {"HIM_NO_FEWIN_REFLECT", HIM_ALGO_NO_FEWIN_REFLECT}};
+      {"HIM_WINO4_TRAIN_FWD", HIM_ALGO_WINO4_TRAIN_FWD}, {"HIM_NO_FEWIN_REFLECT", HIM_ALGO_NO_FEWIN_REFLECT},
+      {"HIM_NO_WINO_FUSED2", HIM_ALGO_NO_WINO_FUSED2}};
   for (const auto& f : flags)
     if (getenv(f.k)) a->disable |= f.bit;
 }

@@ -629,6 +629,7 @@ class Pix2PixHDModel_condImg(BaseModel):
             if (pre is not None and SCHED.adam_split_stem and self.netG_type == 'global' and self.reducer_G is None
                     and pre[3] == id(self.netG.model[1].weight)):
                 ev_main, ev_side, (lo, hi), _ = pre
+                hi = min((hi + 63) // 64 * 64, self.optimizer_G.arena.total)     # whole 256-byte slots (padding: zero gradient)
                 with torch.cuda.stream(opt_stream):
                     opt_stream.wait_event(ev_main)
                     opt_stream.wait_event(ev_side)

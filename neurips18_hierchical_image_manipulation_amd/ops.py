@@ -331,12 +331,13 @@ def _build_panel(w, e):
     e.stream_id = _stream()
 
 
+_PANEL_KEYS = {}     # (descriptor bytes, kind asked for, is_deconv) -> (cache key, panel bytes, kind of the panel that serves it)
+
+
 def _panel(w, d, kind, is_deconv):
     """Device pointer of the cached panel of parameter ``w`` for descriptor ``d`` (0: use the plain entry point)."""
     if not SCHED.panel_cache or not isinstance(w, torch.nn.Parameter):
         return 0
-    if kind == PANEL_BWD_DATA and not is_deconv and lib.him_conv2d_bwd_data_shares_fwd_panel(ctypes.byref(d)):
-        kind = PANEL_FWD        # separate-transform Winograd layers: ONE panel per weight serves both directions
     cache = w.__dict__.get('_him_panels')
     if cache is None:
         cache = w.__dict__['_him_panels'] = {}
@@ -346,14 +347,25 @@ def _panel(w, d, kind, is_deconv):
     # The layout is the LIBRARY's choice for this descriptor (him_conv2d_panel_layout: implicit GEMM / Winograd F(2x2) /
     # fused Winograd / F(4x4)) and depends on batch and plane size, not on the weight alone: the same frozen VGG weight on
     # the last, smaller batch of an epoch leaves F(4x4) (a 36-position panel read as a 16-position one).
-    nbytes = int((lib.him_deconv2d_panel_bytes if is_deconv else lib.him_conv2d_panel_bytes)(ctypes.byref(d), kind))
-    if is_deconv:
-        key = (kind, d.stride, d.pad, d.out_pad, nbytes, bytes(d.algo))
-    else:
-        key = (kind, int(lib.him_conv2d_panel_layout(ctypes.byref(d), kind)), nbytes, d.stride, d.pad, d.pad_mode,
-               d.H >= 2 and d.W >= 2, d.OH == d.H and d.OW == d.W,
-               d.B * d.OH * d.OW < 131072, d.B * d.Cin * d.H * d.W < (1 << 29), d.B * d.Cout * d.H * d.W < (1 << 29),
-               bytes(d.algo))
+    #  the two size / layout queries are ctypes calls; their answer is a pure function of (descriptor, kind):
+    # memoised per descriptor bytes so a cache hit stays pure Python on the launch path
+    mk = (bytes(d), kind, is_deconv)
+    hit = _PANEL_KEYS.get(mk)
+    if hit is None:
+        if kind == PANEL_BWD_DATA and not is_deconv and lib.him_conv2d_bwd_data_shares_fwd_panel(ctypes.byref(d)):
+            kind = PANEL_FWD        # separate-transform Winograd layers: ONE panel per weight serves both directions
+        nbytes = int((lib.him_deconv2d_panel_bytes if is_deconv else lib.him_conv2d_panel_bytes)(ctypes.byref(d), kind))
+        if is_deconv:
+            key = (kind, d.stride, d.pad, d.out_pad, nbytes, bytes(d.algo))
+        else:
+            key = (kind, int(lib.him_conv2d_panel_layout(ctypes.byref(d), kind)), nbytes, d.stride, d.pad, d.pad_mode,
+                   d.H >= 2 and d.W >= 2, d.OH == d.H and d.OW == d.W,
+                   d.B * d.OH * d.OW < 131072, d.B * d.Cin * d.H * d.W < (1 << 29), d.B * d.Cout * d.H * d.W < (1 << 29),
+                   bytes(d.algo))
+        if len(_PANEL_KEYS) > 4096:
+            _PANEL_KEYS.clear()
+        hit = _PANEL_KEYS[mk] = (key, nbytes, kind)
+    key, nbytes, kind = hit
     e = cache.get(key)
     if e is None:
         e = cache[key] = _Panel()
@@ -544,7 +556,20 @@ class _OneHotConv2d(torch.autograd.Function):
         if need_w or need_b:
             nb = lib.him_conv2d_onehot_bwd_weight_ws(ctypes.byref(d), ctx.n_onehot)
             if need_w and _direct(w) and (not need_b or _direct(b)):
-                if SCHED.adam_split_stem and SCHED.wgrad_stream and hasattr(w, '_him_arena_range'):
+                # the range the early Adam pieces must leave alone: the weight's slot and, when the bias gradient is live
+                # (dead_bias_skip off, BatchNorm in eval mode), the bias slot behind it -- run_bias_grad writes b.grad in
+                # the SAME launches as w.grad, i.e. after the two events below (the early step_range(hi, total)
+                # read a zeroed / partial b.grad).  A bias slot that is not the weight's neighbour: no split.
+                stem_range = tuple(w._him_arena_range) if hasattr(w, '_him_arena_range') else None
+                if stem_range is not None and need_b:
+                    br = getattr(b, '_him_arena_range', None)
+                    if br is not None and 0 <= br[0] - stem_range[1] < 64:
+                        stem_range = (stem_range[0], br[1])
+                    elif br is not None and 0 <= stem_range[0] - br[1] < 64:
+                        stem_range = (br[0], stem_range[1])
+                    else:
+                        stem_range = None
+                if SCHED.adam_split_stem and SCHED.wgrad_stream and stem_range is not None:
                     # A generator stem is the LAST node of a chain-shaped generator's backward pass: what the streams hold
                     # at this moment is every data gradient (current stream) and every OTHER weight gradient (weight-gradient
                     # stream) of the network.  A trainer may start the optimizer step of everything else behind these two
@@ -555,7 +580,7 @@ class _OneHotConv2d(torch.autograd.Function):
                     ev_main, ev_side = torch.cuda.Event(), torch.cuda.Event()
                     ev_main.record(cur)
                     ev_side.record(side)
-                    _STEM_PRE[dev] = (ev_main, ev_side, tuple(w._him_arena_range), id(w))
+                    _STEM_PRE[dev] = (ev_main, ev_side, stem_range, id(w))
                 fork = SCHED.stem_wgrad_fork and SCHED.wgrad_stream and d.Cin > ctx.n_onehot
                 if fork:
                     # the dense channels' slice (an MFMA weight gradient) + the bias gradient on THIS stream -- it has just
@@ -619,6 +644,7 @@ class LabelCond(object):
             dense = None
         self.label, self.n_onehot, self.dense = label, int(n_onehot), dense
         self._full = self._pooled = None
+        self._made = {}      # 'full' / 'pooled' -> (stream that materialised it, event behind its kernels)
 
     @property
     def n_dense(self):
@@ -649,8 +675,27 @@ class LabelCond(object):
             if t is not None:
                 t.record_stream(stream)
 
+    def _made_on(self, what, t):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._made[what] = (_stream(), ev)
+        return t
+
+    def _cross_stream(self, what, t):
+        """A cache hit from a stream other than the one that materialised ``t`` (the first caller is the real-image
+        side stream when the discriminator input is not split): order the reader behind the producer and tell the caching
+        allocator about the second user -- the model's own record_stream calls ran before the buffer existed."""
+        made = self._made.get(what)
+        if made is not None and made[0] != _stream():
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(made[1])
+            t.record_stream(cur)
+        return t
+
     def full(self):
         """The (B, n_onehot + n_dense, H, W) tensor itself (him_onehot + one channel copy), cached."""
+        if self._full is not None:
+            return self._cross_stream('full', self._full)
         if self._full is None:
             B, C, H, W = self.shape
             buf = torch.empty((B, C, H, W), dtype=torch.float32, device=self.device)
@@ -659,7 +704,7 @@ class LabelCond(object):
             if self.dense is not None:
                 lib.him_copy_channels(_p(self.dense), self.n_dense, 0, _p(buf), C, self.n_onehot, self.n_dense, B, H * W,
                                       0, 0, 0, st)
-            self._full = mark_onehot(buf, self.label, self.n_onehot)
+            self._full = self._made_on('full', mark_onehot(buf, self.label, self.n_onehot))
         return self._full
 
     def slice(self, c0, n):
@@ -677,6 +722,8 @@ class LabelCond(object):
         """AvgPool2d(3, 2, 1, count_include_pad=False) of the whole thing (reference Discriminator_NET.py:31-32, LocalEnhancer
         Pix2Pix_NET.py:50-53): the one-hot channels as class counts of the 3x3 windows straight from the ids
         (him_onehot_pool3s2, bit-identical to pooling the one-hot), the dense channels through the ordinary pool."""
+        if self._pooled is not None:
+            return self._cross_stream('pooled', self._pooled)
         if self._pooled is None:
             with torch.no_grad():
                 B, C, H, W = self.shape
@@ -688,7 +735,7 @@ class LabelCond(object):
                     pd = avgpool3s2(self.dense)
                     lib.him_copy_channels(_p(pd), self.n_dense, 0, _p(out), C, self.n_onehot, self.n_dense, B, OH * OW,
                                           0, 0, 0, st)
-                self._pooled = out
+                self._pooled = self._made_on('pooled', out)
         return self._pooled
 
 

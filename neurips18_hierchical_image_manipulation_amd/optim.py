@@ -105,17 +105,20 @@ class FusedAdam(object):
     # ---- one optimizer step in pieces (bucket by bucket, as the gradients become final during the backward pass) ----
     def begin_step(self):
         """Open a step that ``step_range`` will carry out piecewise; ``step()`` closes it (whatever is left)."""
+        if getattr(self, '_done', None):
+            raise RuntimeError('a piecewise optimizer step is still open (aborted after part of the arena was updated): '
+                               'step() completes it')
         self.step_count += 1
         self._done = []
 
     def abort_step(self):
-        """Forget an open piecewise step (an exception between ``begin_step`` and ``step``): the next ``step()`` is a whole
-        step again instead of 'the complement of what step_range covered' (ADVICE r4).  Ranges already updated stay updated --
-        the caller is unwinding an error -- but the step count only stays advanced if something was applied."""
+        """An exception between ``begin_step`` and ``step``.  Nothing applied yet: the step is forgotten (count restored,
+        the next ``step()`` is a whole step).  Part of the arena already updated: the step STAYS OPEN with its
+        coverage -- the next ``step()`` completes the complement under the same step count, so no range is ever updated
+        twice by one step and none is skipped; ``begin_step`` refuses to open another step on top of it."""
         done = getattr(self, '_done', None)
-        if done is not None:
-            if not done:
-                self.step_count -= 1
+        if done is not None and not done:
+            self.step_count -= 1
             self._done = None
 
     def _adam(self, lo, hi):

@@ -797,6 +797,22 @@ def test_multi_stream_schedule_is_bit_identical_to_the_serial_one(tag):
     assert not bad, '%d parameter tensors differ between the multi-stream and the serial schedule' % len(bad)
 
 
+def test_adam_split_around_the_stem_with_live_bias_gradients_is_bit_identical_to_serial():
+    """with the dead-bias skip OFF the stem's bias gradient is written by the stem's weight-gradient launches --
+    behind the two events the early Adam pieces wait for -- so the stem's bias slot belongs to the slice the closing
+    ``step()`` updates, not to ``step_range(hi, total)``.  Multi-stream schedule (Adam split on) against the serial one with
+    live bias gradients on both sides: losses and every parameter bit-identical after full-size C1 steps."""
+    from neurips18_hierchical_image_manipulation_amd import config
+    g = load_golden('c1_traj')
+    flags = json.loads(str(g['flags']))
+    B, H, W = int(g['B']), int(g['H']), int(g['W'])
+    la, pa = _run_steps(flags, B, H, W, 3, dead_bias_skip=False)
+    ls, ps = _run_steps(flags, B, H, W, 3, **dict(config.SERIAL, dead_bias_skip=False))
+    assert la == ls, 'losses differ: %s vs %s' % (la[-1], ls[-1])
+    bad = [i for i, (a, b) in enumerate(zip(pa, ps)) if not torch.equal(a, b)]
+    assert not bad, '%d parameter tensors differ between the split and the serial schedule (live bias gradients)' % len(bad)
+
+
 @pytest.mark.parametrize('tag', ['c2_traj', 'tiny_twostream', 'tiny_inst'])
 def test_label_id_inputs_change_one_layers_rounding_and_nothing_else(tag):
     """Round 5 (f3, second half): encode_input keeps [one-hot | dense] as (id map, dense channels) (ops.LabelCond).  With the

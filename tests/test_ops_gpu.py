@@ -414,6 +414,11 @@ WINO4_CASES = [
     (3, 512, 4, 4, 512),         # form) -- the frozen mark must NOT change the kernel selection here
     (8, 256, 64, 128, 256),      # conv3_2..3_4 at the benchmark size (C2)
     (8, 512, 32, 64, 512),       # conv4_2..4_4 at the benchmark size
+    # round 6: the 128-channel shapes that moved to F(4x4) when wino4_min_c went 256 -> 128 -- K = 128
+    # per position = 8 K-steps, the shortest GEMM the batched kernel ever runs
+    (8, 128, 128, 256, 128),     # conv2_2 at the benchmark size
+    (8, 128, 64, 128, 256),      # conv3_1 at the benchmark size
+    (3, 128, 20, 36, 128),       # Cin = 128, odd tile count: 5 x 9 tiles per image = 135 tiles, padded to 256 columns
 ]
 
 
@@ -1147,6 +1152,62 @@ def test_fused_winograd_kernel_at_80_kb_of_lds(case):
         assert_close('dgrad chunk %d' % ck, gx, gx_ref, rtol=2e-5)
         got[ck] = y.detach()
     assert_close('chunk 4 vs chunk 8', got[4], got[8].cpu(), rtol=2e-6)
+
+
+FUSED2_CASES = [
+    # B, Cin, H, W, Cout, padding
+    (8, 64, 256, 512, 64, 'zero'),       # VGG conv1_2 at the benchmark size (C2): 4096 jobs, 16 per workgroup
+    (8, 64, 128, 256, 128, 'zero'),      # VGG conv2_1 at C2: two channel blocks
+    (16, 64, 256, 256, 64, 'zero'),      # conv1_2 at C4 (256x256, bs 16)
+    (1, 64, 128, 256, 64, 'zero'),       # C1: fewer jobs than compute units
+    (2, 128, 36, 70, 192, 'reflect'),    # ragged: blocks cut by the bottom / right border, 3 channel blocks, 16 chunks
+    (3, 32, 50, 36, 128, 'reflect'),     # 4 chunks (the shortest K the kernel takes), H not a multiple of 8
+    (2, 72, 18, 34, 64, 'zero'),         # odd chunk count (9): jobs start on either register set / V buffer
+]
+
+
+@pytest.mark.parametrize('case', FUSED2_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_persistent_fused_winograd_kernel(case):
+    """him_wino_fused2.inc (round 6): the persistent, wave-specialised fused Winograd kernel -- forward
+    (conv + bias + ReLU / none, zero or reflection padding), the plain zero-pad data gradient and the ReLU-GATED data gradient
+    (the VGG chain's form: gate tensor in the epilogue) against the fp32 torch reference of the same op, at the full benchmark
+    shapes and on ragged planes; within 2e-6 of the round-2 kernel it replaces (HIM_ALGO_NO_WINO_FUSED2 selects that one:
+    same panel, same products, another order of the 8 channels of a chunk) and NOT bit-equal to it (the switch selects)."""
+    ops = _ops()
+    from neurips18_hierchical_image_manipulation_amd._cabi import ALGO_NO_WINO_FUSED2
+    B, Cin, H, W, Cout, mode = case
+    x = _rand(B, Cin, H, W, seed=1)
+    xin = torch.relu(x).requires_grad_(True)
+    w = _rand(Cout, Cin, 3, 3, seed=2, scale=(Cin * 9) ** -0.5)
+    b = _rand(Cout, seed=3, scale=0.1)
+    # gradients through a layer WITHOUT an activation on its output: among the outputs a few land within rounding of 0, their
+    # ReLU decision flips between two fp32 summation orders and moves the data gradient by O(|gy w|) there (seen: 4e-2 of
+    # max|ref| at one element); the ReLU / LeakyReLU epilogues are compared on the forward output
+    y_ref = _ref_conv(xin, w, b, 1, 1, mode, 'none')
+    gy = _rand(*y_ref.shape, seed=4)
+    (gx_ref,) = torch.autograd.grad(y_ref, xin, gy)
+    gx_gated_ref = gx_ref * (xin.detach() > 0)
+    got = {}
+    for bit in (0, ALGO_NO_WINO_FUSED2):
+        with ops.algo_scope(disable=bit, wino_fused_min_c=32, wino_fused_max_c=255, wino_min_c=256, wino4_min_c=-1,
+                            wino_fused_chunk=8):
+            wd = torch.nn.Parameter(w.to(DEV), requires_grad=False)
+            with torch.no_grad():
+                for act in ('relu', 'lrelu'):
+                    ya = ops.conv2d(xin.detach().to(DEV), wd, b.to(DEV), 1, 1, mode, act, 0.2)
+                    assert_close('fwd %s (bit %d)' % (act, bit), ya, _ref_conv(xin.detach(), w, b, 1, 1, mode, act), rtol=2e-5)
+            for gate in ((False, True) if mode == 'zero' else (False,)):
+                xd = xin.detach().to(DEV).requires_grad_(True)
+                y = ops.conv2d(xd, wd, b.to(DEV), 1, 1, mode, 'none', 0.2, gate_dx=gate)
+                (gx,) = torch.autograd.grad(y, xd, gy.to(DEV))
+                assert_close('fwd (bit %d)' % bit, y, y_ref, rtol=2e-5)
+                assert_close('dgrad (bit %d, gate %s)' % (bit, gate), gx, gx_gated_ref if gate else gx_ref, rtol=2e-5)
+                got[(bit, gate)] = (y.detach(), gx.detach())
+    for gate in ((False, True) if mode == 'zero' else (False,)):
+        a, o = got[(0, gate)], got[(ALGO_NO_WINO_FUSED2, gate)]
+        assert_close('fwd new vs round-2 kernel', a[0], o[0].cpu(), rtol=2e-6)
+        assert_close('dgrad new vs round-2 kernel', a[1], o[1].cpu(), rtol=2e-6)
+    assert not torch.equal(got[(0, False)][0], got[(ALGO_NO_WINO_FUSED2, False)][0]), 'the switch must select the other kernel'
 
 
 @pytest.mark.parametrize('case', [(8, 256, 16, 32, 256, 'reflect'), (8, 256, 16, 32, 256, 'zero'), (4, 512, 32, 32, 256, 'reflect')],

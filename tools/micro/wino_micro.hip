@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "../../neurips18_hierchical_image_manipulation_amd/csrc/him_common.h"
@@ -18,6 +19,7 @@ char* err_buf() {
   return b;
 }
 #include "../../neurips18_hierchical_image_manipulation_amd/csrc/him_wino_fused.inc"
+#include "../../neurips18_hierchical_image_manipulation_amd/csrc/him_wino_fused2.inc"
 }  // namespace him
 using namespace him;
 
@@ -26,6 +28,9 @@ int main(int argc, char** argv) {
   const int W = argc > 4 ? atoi(argv[4]) : 128, Co = argc > 5 ? atoi(argv[5]) : 256, refl = argc > 6 ? atoi(argv[6]) : 0;
   const int iters = argc > 7 ? atoi(argv[7]) : 20;
   const bool chunk4 = argc > 8 && atoi(argv[8]) == 4;      // 4-channel chunks (80 KB of LDS)
+  const bool v2 = argc > 8 && atoi(argv[8]) == 2;          // persistent kernel (him_wino_fused2.inc)
+  const int wgs = argc > 9 ? atoi(argv[9]) : 0;
+  const bool gate = argc > 10 && atoi(argv[10]) != 0;      // ReLU-gate mask epilogue (the gated data gradient's form)
   if (!wino_fused_shape_ok(Co, Ci, 3, 3, 1, 1, B, H, W)) { printf("shape not supported\n"); return 2; }
   const size_t nx = (size_t)B * Ci * H * W, nw = (size_t)Co * Ci * 9, ny = (size_t)B * Co * H * W;
   std::vector<float> hx(nx), hw(nw), hb(Co), hy(ny);
@@ -44,11 +49,23 @@ int main(int argc, char** argv) {
   hipStream_t st;
   hipStreamCreate(&st);
   hipLaunchKernelGGL((wino_fused_weight_kernel<0>), dim3((Ci + 255) / 256, Co), dim3(256), 0, st, w, Uf, Co, Ci);
-  for (int i = 0; i < 3; ++i) run_wino_fused(B, Ci, H, W, Co, refl != 0, x, Uf, bias, HIM_ACT_RELU, 0.f, y, st, nullptr, chunk4);
+  float* gmask = nullptr;
+  std::vector<float> hm;
+  if (gate) {
+    hm.resize(ny);
+    for (auto& v : hm) v = rnd();
+    hipMalloc(&gmask, ny * 4);
+    hipMemcpy(gmask, hm.data(), ny * 4, hipMemcpyHostToDevice);
+  }
+  auto launch = [&]() {
+    if (v2) run_wino_fused2(B, Ci, H, W, Co, refl != 0, x, Uf, bias, HIM_ACT_RELU, 0.f, y, st, gmask, wgs);
+    else run_wino_fused(B, Ci, H, W, Co, refl != 0, x, Uf, bias, HIM_ACT_RELU, 0.f, y, st, gmask, chunk4);
+  };
+  for (int i = 0; i < 3; ++i) launch();
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0, st);
-  for (int i = 0; i < iters; ++i) run_wino_fused(B, Ci, H, W, Co, refl != 0, x, Uf, bias, HIM_ACT_RELU, 0.f, y, st, nullptr, chunk4);
+  for (int i = 0; i < iters; ++i) launch();
   hipEventRecord(e1, st);
   hipEventSynchronize(e1);
   float ms = 0;
@@ -76,12 +93,13 @@ int main(int argc, char** argv) {
       for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) r += (double)hw[((size_t)co * Ci + c) * 9 + i * 3 + j] * at(b, c, oy - 1 + i, ox - 1 + j);
     r = r > 0 ? r : 0;
+    if (gate && !(hm[(((size_t)b * Co + co) * H + oy) * W + ox] > 0.f)) r = 0;
     worst = fmax(worst, fabs(r - hy[(((size_t)b * Co + co) * H + oy) * W + ox]));
     scale = fmax(scale, fabs(r));
   }
   const double direct = 2.0 * B * Co * (double)H * W * Ci * 9;
-  printf("wino_fused B%d %d->%d %dx%d %s: %.4f ms  %.1f TFLOP/s direct-form equivalent (%.1f executed)  max rel err %.2e  (%s)\n",
-         B, Ci, Co, H, W, refl ? "reflect" : "zero", ms, direct / ms / 1e9, direct / 2.25 / ms / 1e9, worst / scale,
+  printf("wino_fused%s B%d %d->%d %dx%d %s: %.4f ms  %.1f TFLOP/s direct-form equivalent (%.1f executed)  max rel err %.2e  (%s)\n",
+         v2 ? "2" : "", B, Ci, Co, H, W, refl ? "reflect" : "zero", ms, direct / ms / 1e9, direct / 2.25 / ms / 1e9, worst / scale,
          hipGetErrorString(err));
   return worst / scale < 1e-4 ? 0 : 1;
 }
