@@ -40,15 +40,20 @@ def default_dtype(dt):
         torch.set_default_dtype(prev)
 
 
-def make_oracle(flags, dtype=torch.float32, device='cpu'):
+def make_oracle(flags, dtype=torch.float32, device='cpu', yardstick=False):
     """oracle/ref_cpu.Mask2ImageModel with the build's seeded weights (G 1, D 2, VGG 3), in fp32 or fp64.
     ``device='cuda'`` (float64 only): the ANCHOR step runs through torch's own double-precision operators on the GPU --
     the same oracle code, the same float64 arithmetic, a summation order that differs from the host's at the 1e-15 level
     (tests/test_model_gpu.py::test_float64_anchor_on_the_gpu_equals_the_host_anchor).  The fp32 oracle -- the thing the
-    HIP path is compared with -- always runs on the host."""
+    HIP path is compared with -- always runs on the host.
+    ``yardstick=True`` (round 6): the oracle's code in fp32 on torch's GPU operators (cuDNN/MIOpen switched off: ATen's native
+    im2col + rocBLAS convolution, i.e. "the reference on another summation order", as tests/golden/chaos_envelope.json uses
+    on the host) -- NOT a parity oracle, nothing is asserted against its values: it only counts how often an independent fp32
+    implementation sits at a bimodal tensor's rounding baseline, over as many samples as the HIP path is sampled on (a host
+    fp32 step costs 20 s at C2, this one a second)."""
     from oracle import ref_cpu
     from neurips18_hierchical_image_manipulation_amd import synth
-    if device != 'cpu' and dtype != torch.float64:
+    if device != 'cpu' and dtype != torch.float64 and not yardstick:
         raise ValueError('only the float64 anchor may leave the host: the fp32 oracle is pinned to the reference on the CPU')
     with default_dtype(dtype):
         om = ref_cpu.Mask2ImageModel(ref_cpu.Opt(**flags))
@@ -79,6 +84,14 @@ def step64(om64, batch, **kw):
     with default_dtype(torch.float64), dev:
         b = type(batch)((k, (v.double() if torch.is_floating_point(v) else v).to(dev)) for k, v in batch.items())
         return om64.optimize_parameters(b, **kw)
+
+
+def step32_yardstick(om32g, batch, **kw):
+    """one fp32 step of a ``yardstick=True`` oracle (GPU, native convolutions)"""
+    dev = om32g.anchor_device
+    with torch.backends.cudnn.flags(enabled=False), dev:
+        b = type(batch)((k, v.to(dev)) for k, v in batch.items())
+        return om32g.optimize_parameters(b, **kw)
 
 
 def snapshot(om):
