@@ -601,7 +601,8 @@ class Pix2PixHDModel_condImg(BaseModel):
                 self.reducer_D.begin(contributions=2)
             self._run_backward_D(first=True)
             if self.reducer_G is not None:
-                self._g_chunked = SCHED.adam_chunked and self.reducer_G.bucket_hook is not None
+                self._g_chunked = self.reducer_G.bucket_hook is not None and (
+                    SCHED.adam_chunked or (SCHED.adam_chunked_dp and not getattr(self.reducer_G, 'local', False)))
                 if self._g_chunked:
                     self.optimizer_G.begin_step()
                 self.reducer_G.begin()
@@ -657,7 +658,8 @@ class Pix2PixHDModel_condImg(BaseModel):
             self._g_update_pending = True
         else:
             if self.reducer_G is not None:
-                self._g_chunked = SCHED.adam_chunked and self.reducer_G.bucket_hook is not None
+                self._g_chunked = self.reducer_G.bucket_hook is not None and (
+                    SCHED.adam_chunked or (SCHED.adam_chunked_dp and not getattr(self.reducer_G, 'local', False)))
                 if self._g_chunked:
                     self.optimizer_G.begin_step()
                 self.reducer_G.begin()

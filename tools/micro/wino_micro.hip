@@ -73,6 +73,22 @@ int main(int argc, char** argv) {
   ms /= iters;
   hipError_t err = hipGetLastError();
   hipMemcpy(hy.data(), y, ny * 4, hipMemcpyDeviceToHost);
+  if (v2 && argc > 11) {      // determinism / partition independence: the same input under other workgroup counts, bit for bit
+    std::vector<float> h2(ny);
+    int bad_runs = 0;
+    for (int rep = 0; rep < 12; ++rep) {
+      const int w2 = rep < 4 ? wgs : (rep % 4 == 0 ? 97 : rep % 4 == 1 ? 64 : rep % 4 == 2 ? 200 : 13);
+      hipMemsetAsync(y, 0xff, ny * 4, st);
+      run_wino_fused2(B, Ci, H, W, Co, refl != 0, x, Uf, bias, HIM_ACT_RELU, 0.f, y, st, gmask, w2);
+      hipStreamSynchronize(st);
+      hipMemcpy(h2.data(), y, ny * 4, hipMemcpyDeviceToHost);
+      size_t diff = 0, first = 0;
+      for (size_t i = 0; i < ny; ++i)
+        if (memcmp(&h2[i], &hy[i], 4) != 0) { if (!diff) first = i; ++diff; }
+      if (diff) { ++bad_runs; printf("  rep %d (wgs %d): %zu of %zu outputs differ, first at %zu: %g vs %g\n", rep, w2, diff, ny, first, h2[first], hy[first]); }
+    }
+    printf("  partition / repeat check: %d of 12 runs differ\n", bad_runs);
+  }
   double worst = 0, scale = 0;
   auto at = [&](int b, int c, int yy, int xx) -> double {
     if (refl) {
