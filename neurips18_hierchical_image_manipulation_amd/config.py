@@ -44,6 +44,8 @@ class Schedule(object):
         'zero_grad_side': ('HIM_ZERO_GRAD_SIDE', True, 'one rank: optimize_parameters() zeroes the gradient arenas on the weight-gradient stream before the forward pass (under it) instead of on the main stream in front of the backward pass; with a gradient exchange attached the fill stays on the main stream'),
         'conv_in_fused': ('HIM_CONV_IN_FUSED', True, 'Conv2d -> InstanceNorm [-> act] blocks through him_conv2d_in_act_fwd: split-K layers hand their slabs to the InstanceNorm kernel (no finish pass)'),
         'adam_chunked': ('HIM_ADAM_CHUNKED', False, "the generator's Adam step + panel rebuild bucket by bucket DURING its backward pass, as each 64 MB gradient bucket becomes final (and, data parallel, has been exchanged), instead of one 5 GB pass behind the last weight gradient"),
+        'g_tail_wgrad_alt': ('HIM_G_TAIL_WGRAD_ALT', True, "GlobalGenerator: the weight gradients of the down-convolutions (the last of the backward pass) on the VGG stream -- idle since VGG's backward -- next to the ResnetBlock stack's weight-gradient GEMMs still queued on the weight-gradient stream, instead of behind them (r06g trace: 2.5 ms at the end of the step with one stream working)"),
+        'g_head_wgrad_alt': ('HIM_G_HEAD_WGRAD_ALT', True, "GlobalGenerator: the weight gradients of the up-convolutions (the first MFMA weight gradients of the backward pass) on the VGG stream too, so that the weight-gradient stream reaches the ResnetBlock stack together with the data-gradient chain"),
         'adam_chunked_dp': ('HIM_ADAM_CHUNKED_DP', True, "with a gradient EXCHANGE attached (data parallel, or bench.py --fake-comm's stand-in): the generator's Adam step + panel rebuild bucket by bucket, each right behind its bucket's all-reduce on the optimizer stream (round 6 default: measured +0.06 ms per step next to the exchange stand-in against +0.51 ms for one pass behind the last bucket, profiles/r05_ab_log.txt); one rank without an exchange: see adam_chunked"),
         'adam_split_stem': ('HIM_ADAM_SPLIT_STEM', True, "GlobalGenerator: the generator's Adam step + panel rebuild for everything but the stem starts behind the LAST data gradient, next to the stem's run-length weight gradient (0.5 ms, LDS-bound, the last kernel of the backward pass) instead of behind it; the stem's slice follows (FusedAdam.begin_step / step_range / step: bit-identical)"),
         'stem_wgrad_fork': ('HIM_STEM_WGRAD_FORK', True, "one-hot stem convolutions with dense channels: the dense channels' slice of the weight gradient (MFMA) + the bias gradient on the data-gradient stream, next to the label-id slice (run-length kernel, LDS-bound) on the weight-gradient stream (him_conv2d_onehot_bwd_weight_part) instead of behind it: the generator stem's weight gradient is the last kernel chain of the step and what the next generator forward waits for"),
@@ -70,7 +72,7 @@ SCHED = Schedule()
 # every stream of the step switched off: the reference's own order on ONE stream
 SERIAL = dict(wgrad_stream=False, d_wgrad_routes=False, real_ahead=False, d_backward_first=False, vgg_stream=False,
               vgg_backward_early=False, d_scale_streams=False, d_update_early=False, inputs_on_real_stream=False,
-              zero_grad_side=False, real_vgg_first=False, adam_chunked=False, adam_chunked_dp=False, adam_split_stem=False,
+              zero_grad_side=False, real_vgg_first=False, adam_chunked=False, adam_chunked_dp=False, adam_split_stem=False, g_tail_wgrad_alt=False, g_head_wgrad_alt=False,
               stem_wgrad_fork=False)
 
 

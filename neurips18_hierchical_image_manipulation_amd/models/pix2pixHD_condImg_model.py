@@ -90,6 +90,14 @@ class Pix2PixHDModel_condImg(BaseModel):
         else:
             raise NameError('global generator name is not defined properly: %s' % opt.netG)
         self.netG.to(self.device)
+        if opt.netG == 'global':
+            # the down-convolutions' weight gradients are the last of the backward pass (config.SCHED.g_tail_wgrad_alt)
+            from ..nn import Conv2d as _HimConv2d, ConvTranspose2d as _HimDeconv2d
+            for m in self.netG.model:
+                if isinstance(m, _HimConv2d) and getattr(m, 'stride', 1) in (2, (2, 2)):
+                    m.weight._him_wgrad_alt = 'tail'
+                elif isinstance(m, _HimDeconv2d):
+                    m.weight._him_wgrad_alt = 'head'     # config.SCHED.g_head_wgrad_alt
 
         if self.isTrain:
             self.no_imgCond = opt.no_imgCond
@@ -634,6 +642,8 @@ class Pix2PixHDModel_condImg(BaseModel):
                 with torch.cuda.stream(opt_stream):
                     opt_stream.wait_event(ev_main)
                     opt_stream.wait_event(ev_side)
+                    for ev in ops.wgrad_waitables(self.device)[1]:     # weight gradients routed to other streams (all issued
+                        opt_stream.wait_event(ev)                      # before the stem's backward, the last node)
                     self.optimizer_G.begin_step()
                     try:
                         if lo > 0:

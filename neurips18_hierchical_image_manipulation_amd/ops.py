@@ -165,8 +165,9 @@ class _wgrad_stream(object):
     """Context: run the enclosed launches on the weight-gradient stream (the side stream, or the stream the issuing stream
     is routed to), after everything enqueued so far on the current one."""
 
-    def __init__(self, *tensors):
+    def __init__(self, *tensors, weight=None):
         self.tensors = [t for t in tensors if t is not None]
+        self.weight = weight
 
     def __enter__(self):
         self.on = SCHED.wgrad_stream
@@ -175,6 +176,12 @@ class _wgrad_stream(object):
         dev = self.tensors[0].device
         main = torch.cuda.current_stream(dev)
         side = _WGRAD_ROUTE.get(main.cuda_stream)
+        alt = getattr(self.weight, '_him_wgrad_alt', None)
+        if side is None and ((alt == 'tail' and SCHED.g_tail_wgrad_alt) or (alt == 'head' and SCHED.g_head_wgrad_alt)):
+            # the LAST weight gradients of a chain-shaped generator's backward (its down-convolutions): on the VGG stream
+            # (idle since VGG's backward) next to the ResnetBlock stack's weight-gradient GEMMs still queued on the
+            # weight-gradient stream, instead of behind them (Pix2PixHDModel_condImg marks the weights)
+            side = _vgg_stream(dev)
         self.routed = side is not None
         if side is None:
             side = _side_stream(dev)
@@ -488,7 +495,7 @@ class _Conv2d(torch.autograd.Function):
         if need_w or need_b:
             nb = lib.him_conv2d_bwd_weight_ws(ctypes.byref(d))
             if need_w and _direct(w) and (not need_b or _direct(b)):
-                with _wgrad_stream(x, dz, ctx.keep):
+                with _wgrad_stream(x, dz, ctx.keep, weight=w):
                     ws = _ws(nb, x)
                     if ctx.keep is not None:
                         lib.him_conv2d_bwd_weight_kept(ctypes.byref(d), _p(ctx.keep), _p(dz), _p(w.grad),
@@ -887,7 +894,7 @@ class _CondImageConv2d(torch.autograd.Function):
         if need_w or need_b:
             nb = lib.him_conv2d_bwd_weight_ws(ctypes.byref(d))
             if need_w and _direct(w) and (not need_b or _direct(b)):
-                with _wgrad_stream(x, dz):
+                with _wgrad_stream(x, dz, weight=w):
                     ws = _ws(nb, x)
                     lib.him_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dz), _p(w.grad),
                                               _p(b.grad) if need_b else 0, 1, _p(ws), nb, _stream())
@@ -1049,7 +1056,7 @@ class _Deconv2d(torch.autograd.Function):
         if need_w or need_b:
             nb = lib.him_deconv2d_bwd_weight_ws(ctypes.byref(d))
             if need_w and _direct(w) and (not need_b or _direct(b)):
-                with _wgrad_stream(x, dz):
+                with _wgrad_stream(x, dz, weight=w):
                     ws = _ws(nb, x)
                     lib.him_deconv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dz), _p(w.grad),
                                                 _p(b.grad) if need_b else 0, 1, _p(ws), nb, _stream())
