@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..nn import InstanceNorm2d, BatchNorm2d, LeakyReLU, FusedSequential, AvgPool3s2, _pw
+from ..nn import InstanceNorm2d, BatchNorm2d, LeakyReLU, Sigmoid, FusedSequential, AvgPool3s2, _pw
 from .layer_util import weights_init
 
 
@@ -75,12 +75,13 @@ class MultiscaleDiscriminator(nn.Module):
         if norm_layer not in ('instance', 'batch'):
             raise NotImplementedError('normalization layer [%s] is not found' % norm_layer)
         norm = InstanceNorm2d if norm_layer == 'instance' else BatchNorm2d   # 'batch': the box2mask discriminator
-        if use_sigmoid:
+        if use_sigmoid and getIntermFeat:
             # The reference cannot run this either: MultiscaleDiscriminator copies only model0..model<n_layers+1> of each
             # NLayerDiscriminator when getIntermFeat is set (Discriminator_NET.py:24-27), which drops the trailing Sigmoid,
             # so GANLoss's nn.BCELoss (losses.py:19-20) is fed raw logits (an error in torch >= 0.4, NaNs before).
-            raise NotImplementedError('--no_lsgan: the reference drops the Sigmoid in front of its BCELoss on this path '
-                                      '(Discriminator_NET.py:24-27); LSGAN only')
+            # With --no_ganFeat_loss the Sigmoid sits inside ``layer<i>`` (:27-28, :95-96) and the flag works (round 6).
+            raise NotImplementedError('--no_lsgan needs --no_ganFeat_loss: with feature matching the reference drops the '
+                                      'Sigmoid in front of its BCELoss (Discriminator_NET.py:24-27)')
         self.num_D, self.n_layers, self.getIntermFeat = num_D, n_layers, bool(getIntermFeat)
         if not getIntermFeat:
             # --no_ganFeat_loss: the reference keeps each scale as ONE flattened Sequential ``layer<i>`` (:27-28) -- the same
@@ -96,7 +97,7 @@ class MultiscaleDiscriminator(nn.Module):
                 blocks.append([Conv2d(nf_prev, nf, 4, 2, 2), norm(nf), LeakyReLU(0.2)])
             nf_prev, nf = nf, min(nf * 2, 512)
             blocks.append([Conv2d(nf_prev, nf, 4, 1, 2), norm(nf), LeakyReLU(0.2)])
-            blocks.append([Conv2d(nf, 1, 4, 1, 2)])
+            blocks.append([Conv2d(nf, 1, 4, 1, 2)] + ([Sigmoid()] if use_sigmoid else []))     # reference :95-96
             for j, b in enumerate(blocks):
                 setattr(self, 'scale%d_layer%d' % (i, j), FusedSequential(*b))
         self.downsample = AvgPool3s2()

@@ -7,21 +7,27 @@ from .layer_util import Vgg19
 
 
 class GANLoss(nn.Module):
-    """LSGAN: sum over scales of mean((logits - target)^2) on the last tensor of each scale (:40-50).
-    The constant target tensor of the reference is never materialised."""
+    """LSGAN: sum over scales of mean((logits - target)^2) on the last tensor of each scale (:40-50); ``use_lsgan=False``
+    (``--no_lsgan``): nn.BCELoss on the Sigmoid outputs (:17-20; ops.bce_mean = him_bce_mean_*).  The constant target tensor
+    of the reference is a fill (BCE) or never materialised (LSGAN)."""
 
     def __init__(self, use_lsgan=True, target_real_label=1.0, target_fake_label=0.0, tensor=None):
         super().__init__()
-        if not use_lsgan:
-            raise NotImplementedError('vanilla GAN (BCE) loss is not on the HIP path; LSGAN only')
+        self.use_lsgan = bool(use_lsgan)
         self.real_label, self.fake_label = target_real_label, target_fake_label
+
+    def _one(self, pred, t):
+        if self.use_lsgan:
+            return ops.mse_const(pred, t)
+        import torch
+        return ops.bce_mean(pred, torch.full_like(pred, t))
 
     def __call__(self, input, target_is_real):
         t = self.real_label if target_is_real else self.fake_label
         if isinstance(input[0], list):
             # loss = 0; loss += criterion(pred_i, target) per scale (:44-49): one launch instead of a chain of scalar adds
-            return ops.lincomb([ops.mse_const(input_i[-1], t) for input_i in input])
-        return ops.mse_const(input[-1], t)
+            return ops.lincomb([self._one(input_i[-1], t) for input_i in input])
+        return self._one(input[-1], t)
 
 
 # ReLU backward of the VGG chain folded into the kernels that produce the gradients (see Vgg19.forward); 0 = separate passes

@@ -129,7 +129,11 @@ class Tanh(nn.Module):
     act, slope = 'tanh', 0.0
 
 
-_ACTS = (ReLU, LeakyReLU, Tanh)
+class Sigmoid(nn.Module):
+    act, slope = 'sigmoid', 0.0
+
+
+_ACTS = (ReLU, LeakyReLU, Tanh, Sigmoid)
 
 
 def run_layers(layers, x, final_residual=None, relu_gated=None):

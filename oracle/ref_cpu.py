@@ -216,9 +216,15 @@ class MultiscaleDiscriminator(nn.Module):
     Sequential ``layer<i>`` (:27-28, keys ``layer<i>.<n>.*``) -- the same modules on the same inputs, so the blocks stay
     separate here and only the state-dict names follow the reference."""
 
-    def __init__(self, input_nc, ndf=64, n_layers=3, num_D=3, norm='instance', spectral_norm=False, getIntermFeat=True):
+    def __init__(self, input_nc, ndf=64, n_layers=3, num_D=3, norm='instance', spectral_norm=False, getIntermFeat=True,
+                 use_sigmoid=False):
         super().__init__()
         self.num_D, self.n_layers = num_D, n_layers
+        if use_sigmoid and getIntermFeat:
+            # models/Discriminator_NET.py:24-27 copies only model0 .. model<n_layers+1> of each NLayerDiscriminator: the
+            # trailing nn.Sigmoid (:95-96) is dropped and nn.BCELoss (losses.py:19-20) is fed raw logits -- an error in torch
+            raise ValueError('--no_lsgan needs --no_ganFeat_loss: with feature matching the reference drops the Sigmoid in '
+                             'front of its BCELoss (models/Discriminator_NET.py:24-27)')
         if not getIntermFeat:
             self._register_state_dict_hook(_d_keys_out)
             self._register_load_state_dict_pre_hook(_d_keys_in, with_module=True)
@@ -232,7 +238,7 @@ class MultiscaleDiscriminator(nn.Module):
                 blocks.append([conv(nf_prev, nf, 4, 2, 2), _in_layer(nf), nn.LeakyReLU(0.2, False)])
             nf_prev, nf = nf, min(nf * 2, 512)
             blocks.append([conv(nf_prev, nf, 4, 1, 2), _in_layer(nf), nn.LeakyReLU(0.2, False)])
-            blocks.append([conv(nf, 1, 4, 1, 2)])
+            blocks.append([conv(nf, 1, 4, 1, 2)] + ([nn.Sigmoid()] if use_sigmoid else []))   # :95-96, inside ``layer<i>`` (:27-28)
             for j, b in enumerate(blocks):
                 setattr(self, 'scale%d_layer%d' % (i, j), nn.Sequential(*b))
         self.downsample = nn.AvgPool2d(3, stride=2, padding=1, count_include_pad=False)
@@ -286,10 +292,12 @@ class Vgg19(nn.Module):
 # ----------------------------------------------------------------------------------------------
 # losses
 # ----------------------------------------------------------------------------------------------
-def gan_loss(pred_scales, target_is_real):
-    """LSGAN: sum over scales of mean((logits - t)^2) on the LAST tensor of each scale (models/losses.py:40-50)."""
+def gan_loss(pred_scales, target_is_real, use_lsgan=True):
+    """LSGAN: sum over scales of mean((logits - t)^2) on the LAST tensor of each scale (models/losses.py:40-50);
+    ``--no_lsgan``: nn.BCELoss on the Sigmoid outputs instead (losses.py:17-20)."""
     t = 1.0 if target_is_real else 0.0
-    return sum(F.mse_loss(s[-1], torch.full_like(s[-1], t)) for s in pred_scales)
+    crit = F.mse_loss if use_lsgan else F.binary_cross_entropy
+    return sum(crit(s[-1], torch.full_like(s[-1], t)) for s in pred_scales)
 
 
 VGG_WEIGHTS = [1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0]
@@ -429,7 +437,7 @@ class Mask2ImageModel(nn.Module):
             d_in = 3
         self.d_in = d_in
         self.netD = MultiscaleDiscriminator(d_in, opt.ndf, opt.n_layers_D, opt.num_D, spectral_norm=opt.sn_D,
-                                            getIntermFeat=not opt.no_ganFeat_loss)
+                                            getIntermFeat=not opt.no_ganFeat_loss, use_sigmoid=opt.no_lsgan)
         self.vgg = None if opt.no_vgg_loss else Vgg19()
         self.optimizer_G = torch.optim.Adam(self.netG.parameters(), lr=opt.lr, betas=(opt.beta1, 0.999))
         self.optimizer_D = torch.optim.Adam(self.netD.parameters(), lr=opt.lr, betas=(opt.beta1, 0.999))
@@ -471,11 +479,11 @@ class Mask2ImageModel(nn.Module):
         d_cond = onehot if o.no_imgCond else torch.cat((onehot, cond), 1)
         m = mask_out if o.use_soft_mask else mask_in
         pred_fake_pool = self.netD(self._d_input(d_cond, fake.detach(), m))
-        loss_D_fake = gan_loss(pred_fake_pool, False)
+        loss_D_fake = gan_loss(pred_fake_pool, False, not o.no_lsgan)
         pred_real = self.netD(self._d_input(d_cond, image, m))
-        loss_D_real = gan_loss(pred_real, True)
+        loss_D_real = gan_loss(pred_real, True, not o.no_lsgan)
         pred_fake = self.netD(self._d_input(d_cond, fake, m))
-        loss_G_GAN = gan_loss(pred_fake, True)
+        loss_G_GAN = gan_loss(pred_fake, True, not o.no_lsgan)
         loss_feat = torch.zeros(1)
         if not o.no_ganFeat_loss:
             feat_w, d_w = 4.0 / (o.n_layers_D + 1), 1.0 / o.num_D

@@ -422,7 +422,10 @@ TINY2 = dict(TINY, n_downsample_global=2)
 FLAG_VARIANTS = {'tiny_flag_lambda_rec': dict(TINY2, lambda_rec=5.0),
                  'tiny_flag_soft_mask': dict(TINY2, use_soft_mask=True, mask_gan_input=True),
                  'tiny_flag_rec_no_ganfeat': dict(TINY2, lambda_rec=2.0, no_ganFeat_loss=True),
-                 'tiny_flag_no_vgg_no_imgcond': dict(TINY2, no_vgg_loss=True, no_imgCond=True)}
+                 'tiny_flag_no_vgg_no_imgcond': dict(TINY2, no_vgg_loss=True, no_imgCond=True),
+                 # round 6: the vanilla-GAN loss (nn.BCELoss on Sigmoid outputs, models/losses.py:17-20) -- runnable in the
+                 # reference only with --no_ganFeat_loss (with feature matching it drops the Sigmoid, Discriminator_NET.py:24-27)
+                 'tiny_flag_no_lsgan': dict(TINY2, no_lsgan=True, no_ganFeat_loss=True)}
 # encoder choices of the two-stream generator (--which_encoder ctx | label | ctx_label, models/Pix2Pix_NET.py:126-136;
 # 'ctx' is the parser's default and feeds the discriminator the IMAGE ONLY, pix2pixHD_condImg_model.py:70-71,179-180),
 # with and without --use_skip / --use_output_gate; 'label' + --use_skip fails inside the reference's own decoder
@@ -453,8 +456,10 @@ if __name__ == '__main__':
         trajectory('tiny_inst', TINY_INST, 2, 32, 64, 5, save_outputs=True)
         trajectory('tiny_twostream', TINY_TWO, 2, 64, 64, 20, save_outputs=True)
         trajectory('tiny_color', TINY_COLOR, 2, 64, 64, 5, color=True)
-    if 'flags' in what:
+    if 'flags' in what or any(w in FLAG_VARIANTS for w in what):
         for tag, fl in FLAG_VARIANTS.items():
+            if 'flags' not in what and tag not in what:
+                continue
             trajectory(tag, fl, 2, 64 if fl['netG'] == 'global_twostream' else 32, 64, 5, save_keys=True)
     if 'c1' in what:
         trajectory('c1_traj', C1, 1, 128, 256, 20)

@@ -188,6 +188,7 @@ def test_state_dict_keys_match_oracle_for_every_generator():
 
 
 FLAG_GOLDENS = ('tiny_flag_lambda_rec', 'tiny_flag_soft_mask', 'tiny_flag_rec_no_ganfeat', 'tiny_flag_no_vgg_no_imgcond',
+                'tiny_flag_no_lsgan',
                 'tiny_two_ctx', 'tiny_two_ctx_gate_skip', 'tiny_two_ctxlabel_plain', 'tiny_two_label', 'tiny_two_label_gate')
 
 

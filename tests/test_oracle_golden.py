@@ -25,6 +25,7 @@ def _model(flags):
 @pytest.mark.parametrize('tag,steps', [('tiny_global', 4), ('tiny_gate3', 3), ('tiny_inst', 3), ('tiny_twostream', 3),
                                        ('tiny_color', 3), ('tiny_flag_lambda_rec', 3), ('tiny_flag_soft_mask', 3),
                                        ('tiny_flag_rec_no_ganfeat', 3), ('tiny_flag_no_vgg_no_imgcond', 3),
+                                       ('tiny_flag_no_lsgan', 3),
                                        ('tiny_two_ctx', 2), ('tiny_two_ctx_gate_skip', 2), ('tiny_two_ctxlabel_plain', 2),
                                        ('tiny_two_label', 2), ('tiny_two_label_gate', 2)])
 def test_oracle_reproduces_reference_losses(tag, steps):

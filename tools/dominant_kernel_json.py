@@ -3,7 +3,7 @@
 <1,1> for the data gradients on the forward panel, <0,0> for the weight gradients on the kept input transform -- on a grid
 of 16 * (1024/128)^2 = 1024 workgroups; rounds 2-3: gconv_fast_kernel on 2048 / 1024) as rocprofv3 --kernel-trace saw it
 (a) alone, in the trace of tools/gemm_bench.py, and (b) inside the traced training step of bench.py.
-Usage: python tools/dominant_kernel_json.py <gemm_trace dir|db> <bench_trace dir|db> <out.json>"""
+Usage: python tools/dominant_kernel_json.py <gemm_trace dir|db> <step trace dir|db> <out.json> [tag of the step trace]"""
 import glob
 import json
 import os
@@ -59,6 +59,9 @@ def main():
         un = durations.union_ns / len(step)
         out.update(in_step_union_ms_per_launch=round(un / 1e6, 4),
                    in_step_union_frac_of_f32_mfma_peak=round(FLOP / (un * 1e-9) / 1e12 / PEAK, 4))
+    if len(sys.argv) > 4:
+        out['in_step_source'] = ('profiles/%s_* (tools/trace_unbound.sh: a trace that is not launch-starved, every launch of 8 '
+                                 'steps queued behind a spin kernel)' % sys.argv[4])
     out['command'] = ('rocprofv3 --kernel-trace --stats -- python tools/gemm_bench.py 20 (isolated) and rocprofv3 --kernel-trace '
                       '-- python bench.py --steps 6 --warmup 3 (in step); tools/collect_profiles.sh')
     with open(sys.argv[3], 'w') as f:
