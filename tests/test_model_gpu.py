@@ -1213,7 +1213,9 @@ def test_loss_flag_variants_teacher_forced(extra):
     tag = 'tiny_' + '_'.join(sorted(extra))
     # these runs pin the flag plumbing (which terms enter which loss), not kernel numerics: a mis-routed term is an O(1)
     # error; one LeakyReLU / L1-sign decision flipping moves the toy nets' gradients by up to ~1e-3
-    _teacher_forced(tag, 3, golden=dict(flags=dict(TINY, **extra), B=2, H=32, W=64), plumbing_tol=5e-3)
+    # (--no_lsgan: 5.8e-3 measured -- one flipped decision in front of BCE's log on an 8-channel toy discriminator)
+    _teacher_forced(tag, 3, golden=dict(flags=dict(TINY, **extra), B=2, H=32, W=64),
+                    plumbing_tol=2e-2 if extra.get('no_lsgan') else 5e-3)
 
 
 @pytest.mark.parametrize('tag', ['tiny_two_ctx', 'tiny_two_ctx_gate_skip', 'tiny_two_ctxlabel_plain', 'tiny_two_label',
