@@ -89,6 +89,8 @@ const char* him_last_error(void);
 #define HIM_ALGO_NO_WINO_FUSED2 (1u << 15)   /* fused Winograd launches on the round-2 kernel (one workgroup per spatial block, all
                                                waves producer + consumer) instead of the persistent wave-specialised kernel
                                                (csrc/him_wino_fused2.inc, round 6) */
+#define HIM_ALGO_NO_BGEMM_PERSISTENT (1u << 16) /* F(4x4) GEMMs with K <= 256 on one workgroup per tile instead of the persistent
+                                               form of the batched GEMM (csrc/him_bgemm.inc: bgemm_p_kernel, round 6) */
 #define HIM_ALGO_WINO4_TRAIN_FWD (1u << 13)  /* OPT-IN, reduced-work variant: the FORWARD of trainable 3x3 s1 p1
                                                layers with >= wino4_min_c channels (the ResnetBlock stack) as Winograd
                                                F(4x4,3x3) -- 1.78x fewer multiplies than F(2x2), ~3e-6 instead of 5e-7 relative
@@ -123,7 +125,7 @@ void him_algo_resolve(const HimAlgo* in, HimAlgo* out);
  * HIM_WINO_MIN_C, HIM_NO_WINO_FUSED, HIM_WINO_FUSED_MIN_C / _MAX_C, HIM_WINO4_MIN_C, HIM_KSPLIT_MAX, HIM_NO_SPLITK,
  * HIM_GCONV_TILE[_WB|_NB], HIM_WINO_TBLOCK, HIM_WGRAD_SPLITS, HIM_NO_DFOLD, HIM_WINO_PADDED_DGRAD, HIM_NO_SMALL_WIN,
  * HIM_NO_FEWOUT_TILED, HIM_NO_FEWIN_TILED, HIM_NO_FEWCH_MFMA, HIM_GENERIC_CONV, HIM_NO_RESBLOCK_FUSED, HIM_NO_BGEMM, HIM_NO_ONEHOT_RLE,
- * HIM_NO_WINO_FUSED2).  The ONLY place
+ * HIM_NO_WINO_FUSED2, HIM_NO_BGEMM_PERSISTENT).  The ONLY place
  * the library reads the environment; nothing else calls it. */
 void him_algo_from_env(HimAlgo* a);
 

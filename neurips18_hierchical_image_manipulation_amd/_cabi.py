@@ -30,6 +30,7 @@ ALGO_NO_FEWIN_FOLD = 1 << 12
 ALGO_WINO4_TRAIN_FWD = 1 << 13
 ALGO_NO_FEWIN_REFLECT = 1 << 14
 ALGO_NO_WINO_FUSED2 = 1 << 15
+ALGO_NO_BGEMM_PERSISTENT = 1 << 16
 ONEHOT_PART_IDS, ONEHOT_PART_DENSE = 1, 2      # him_conv2d_onehot_bwd_weight_part
 TILE_DEFAULT, TILE_128x128, TILE_128x128_8W, TILE_128x256, TILE_64x128, TILE_64x64, TILE_MIXED, TILE_128x64 = range(8)
 

@@ -71,6 +71,14 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh) {
 
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// compute units of the current device = what a persistent launch sizes its grid by (a query, not cached: no mutable state)
+inline int device_cus() {
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+    return 256;
+  return n > 0 ? n : 256;
+}
+
 // ---- LDS-DMA: 16 bytes per lane, global -> LDS, no VGPR staging (global_load_lds_dwordx4) ---------------------------
 // The 64 lanes of the wave fill 1 KB of LDS at the WAVE-UNIFORM byte address `lds_dst` in lane order; `gsrc` is per lane.
 // Issued through inline asm ON PURPOSE: hipcc (ROCm 7.2) tracks a __builtin_amdgcn_global_load_lds as a pending LDS store

@@ -875,13 +875,6 @@ static bool wino_fused2_ok(const HimAlgo& a, int Co, int Ci, int B, int H, int W
   return !algo_off(a, HIM_ALGO_NO_WINO_FUSED2) && algo_wino_fused_chunk(a) != 4 && wino_fused2_act_ok(act) &&
          wino_fused2_shape_ok(Co, Ci, 3, 3, 1, 1, B, H, W);
 }
-// compute units of the current device = workgroups of a persistent launch (a query, not cached: no mutable state)
-static int device_cus() {
-  int dev = 0, n = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-    return 256;
-  return n > 0 ? n : 256;
-}
 static bool wino_fused_fwd_ok(const HimConv2d* d) {
   return wino_fused_ok(d->algo, d->Cout, d->Cin, d->KH, d->KW, d->stride, d->pad, d->B, d->H, d->W);
 }
@@ -951,7 +944,7 @@ static int run_fprop(const HimConv2d* d, const float* x, const float* w, const f
       if (rc || build_only) return rc;
     }
     return run_wino4_conv(d->B, d->Cin, d->H, d->W, d->Cout, x, panel ? panel : U, bias, d->act, d->slope, y, U + pf, st,
-                          nullptr, d->pad_mode == HIM_PAD_REFLECT);
+                          nullptr, d->pad_mode == HIM_PAD_REFLECT, !algo_off(d->algo, HIM_ALGO_NO_BGEMM_PERSISTENT));
   }
   if (wino_fused_fwd_ok(d)) {
     if (!panel) {
@@ -1097,7 +1090,7 @@ static int run_dgrad(const HimConv2d* d, const float* gy, const float* w, float*
     }
     if (mask_done) *mask_done = relu_mask != nullptr;   // the gate rides in the output transform
     return run_wino4_conv(d->B, d->Cout, d->OH, d->OW, d->Cin, gy, panel ? panel : U, bias, act, slope, out, U + pf, st,
-                          relu_mask);
+                          relu_mask, false, !algo_off(d->algo, HIM_ALGO_NO_BGEMM_PERSISTENT));
   }
   if (wino_fused_dgrad_ok(d)) {   // zero-padded 3x3 stride-1: the convolution of gy with the flipped / transposed filter
     if (!panel) {
@@ -1345,7 +1338,7 @@ void him_algo_from_env(HimAlgo* a) {
       {"HIM_NO_RESBLOCK_FUSED", HIM_ALGO_NO_RESBLOCK_FUSED}, {"HIM_NO_BGEMM", HIM_ALGO_NO_BGEMM},
       {"HIM_NO_ONEHOT_RLE", HIM_ALGO_NO_ONEHOT_RLE},   {"HIM_NO_FEWIN_FOLD", HIM_ALGO_NO_FEWIN_FOLD},
       {"HIM_WINO4_TRAIN_FWD", HIM_ALGO_WINO4_TRAIN_FWD}, {"HIM_NO_FEWIN_REFLECT", HIM_ALGO_NO_FEWIN_REFLECT},
-      {"HIM_NO_WINO_FUSED2", HIM_ALGO_NO_WINO_FUSED2}};
+      {"HIM_NO_WINO_FUSED2", HIM_ALGO_NO_WINO_FUSED2}, {"HIM_NO_BGEMM_PERSISTENT", HIM_ALGO_NO_BGEMM_PERSISTENT}};
   for (const auto& f : flags)
     if (getenv(f.k)) a->disable |= f.bit;
 }

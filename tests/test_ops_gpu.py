@@ -455,6 +455,15 @@ def test_winograd_f4x4_frozen_conv_fwd_and_gated_dgrad(case):
         got[frozen] = y.detach()
     if B * (H // 4) * (W // 4) >= 64:
         assert not torch.equal(got[True], got[False]), 'the frozen mark must select the F(4x4) kernels'
+        # round 6: reductions of <= 256 channels run the PERSISTENT form of the batched GEMM (two workgroups per compute unit
+        # walk the tiles, the stage ring runs across tile boundaries): the same sums in the same order, bit for bit
+        from neurips18_hierchical_image_manipulation_amd._cabi import ALGO_NO_BGEMM_PERSISTENT
+        with ops.algo_scope(disable=ALGO_NO_BGEMM_PERSISTENT):
+            wd = torch.nn.Parameter(w.to(DEV), requires_grad=False)
+            wd._him_frozen = True
+            xd = xin.detach().to(DEV).requires_grad_(True)
+            y1 = ops.conv2d(xd, wd, b.to(DEV), 1, 1, 'zero', act, 0.2, gate_dx=True)
+        assert torch.equal(y1.detach(), got[True]), 'persistent and per-tile GEMM must agree bit for bit'
     else:
         assert torch.equal(got[True], got[False]), 'F(4x4) selected for fewer than 64 tiles (him_conv_wino4.inc: wino4_shape_ok)'
 

@@ -24,6 +24,7 @@ using namespace him;
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 1024, K = argc > 2 ? atoi(argv[2]) : 1024, N = argc > 3 ? atoi(argv[3]) : 1024;
   const int iters = argc > 4 ? atoi(argv[4]) : 20, nz = argc > 5 ? atoi(argv[5]) : 16;
+  const int pwgs = argc > 6 ? atoi(argv[6]) : 0;       // > 0: the persistent kernel on that many workgroups
   const size_t na = (size_t)nz * M * K, nb = (size_t)nz * K * N, nc = (size_t)nz * M * N;
   std::vector<float> ha(na), hb(nb), hc(nc);
   unsigned s = 12345u;
@@ -42,12 +43,12 @@ int main(int argc, char** argv) {
   // (al, bl, mirror): element accessors of the SAME host arrays under each layout interpretation
   const int cfg[3][3] = {{0, 1, 0}, {1, 1, 1}, {0, 0, 0}};
   const char* names[3] = {"fwd   A[z][M][K] B[z][K][N]", "dgrad A[s(z)][K][M] B[z][K][N]", "wgrad A[z][M][K] B[z][N][K]"};
-  for (int v = 0; v < 3; ++v) {
+  for (int v = 0; v < (nz == 16 ? 3 : 1); ++v) {      // 36 positions (F(4x4)): the forward layout only (the mirror table here is F(2x2)'s)
     const int al = cfg[v][0], bl = cfg[v][1], mir = cfg[v][2];
     hipMemsetAsync(c, 0xff, nc * 4, st);
-    for (int i = 0; i < 3; ++i) launch_bgemm(a, b, c, M, K, N, nz, 4, al, bl, mir, st);
+    for (int i = 0; i < 3; ++i) launch_bgemm(a, b, c, M, K, N, nz, 4, al, bl, mir, st, pwgs);
     hipEventRecord(e0, st);
-    for (int i = 0; i < iters; ++i) launch_bgemm(a, b, c, M, K, N, nz, 4, al, bl, mir, st);
+    for (int i = 0; i < iters; ++i) launch_bgemm(a, b, c, M, K, N, nz, 4, al, bl, mir, st, pwgs);
     hipEventRecord(e1, st);
     hipEventSynchronize(e1);
     float ms = 0;
