@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from layer_bench import LAYERS      # noqa: E402
 
 PEAK = 157.3
-MFMA = ('gconv_fast_kernel', 'wgrad_fast_kernel', 'bgemm_kernel', 'wino_fused_kernel', 'wino_fused2_kernel', 'wgrad_kernel', 'gconv_kernel',
+MFMA = ('gconv_fast_kernel', 'wgrad_fast_kernel', 'bgemm_kernel', 'bgemm_p_kernel', 'wino_fused_kernel', 'wino_fused2_kernel', 'wgrad_kernel', 'gconv_kernel',
         'wgrad_fewch_mfma_kernel')
 ROW = re.compile(r'^(.*?)\s{2}grid=\((\d+),(\d+),(\d+)\)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)')
 
@@ -38,7 +38,7 @@ def executed_gflop(kernel, spec):
     else:
         OH, OW = H * s, W * s
     direct = 2.0 * B * OH * OW * Cin * Cout * k * k / (s * s if kind == 'deconv' else 1) / 1e9
-    if kernel.startswith('bgemm_kernel'):
+    if kernel.startswith('bgemm_'):
         return direct / (4.0 if (frozen and min(Cin, Cout) >= 128) else 2.25)      # HimAlgo.wino4_min_c = 128
     if kernel.startswith('wino_fused'):
         return direct / 2.25
@@ -52,7 +52,7 @@ def main():
           'launches); in-step = the same (kernel, grid) in the traced training step (all streams busy).  One launch of a kernel '
           'may serve several layers of the same shape (calls/step): the in-step average is then over ALL of them (g_down4 forward and '
           'g_up1 data gradient are the same launch shape; d0_l3 and d1_l3 share the weight-gradient grid (32,4,6): read their in-step '
-          'TF/s as a range, the isolated column is per layer).  PMC passes of the rows marked in DESIGN.md: profiles/r0N_pmc_*.json.' % PEAK)
+          'TF/s as a range, the isolated column is per layer; the PERSISTENT kernels -- wino_fused2_kernel on one workgroup per compute unit, bgemm_p_kernel on two -- launch the same grid for every layer, so their in-step columns average over all of VGG conv1_2 + conv2_1, resp. conv2_2 .. conv3_4).  PMC passes of the rows marked in DESIGN.md: profiles/r0N_pmc_*.json.' % PEAK)
     print('%-9s %-36s %-42s %-14s %8s %9s %7s %6s %9s %7s %6s %6s' % (
         'layer', 'what', 'kernel', 'grid', 'GFLOP', 'isol_us', 'TF/s', 'frac', 'instep_us', 'TF/s', 'frac', 'calls'))
     tot = {}

@@ -13,5 +13,10 @@ for L in $(python $ROOT/tools/layer_bench.py --list); do
   python $ROOT/tools/prof_summary.py $OUT/layers/trace_$L --by-grid > $OUT/layers/$L.txt 2>&1
   rm -rf $OUT/layers/trace_$L
 done
-python $ROOT/tools/roofline_table.py $OUT/layers $OUT/${TAG}_bench_kernel_stats_by_grid.txt 9 > $OUT/${TAG}_roofline_table.txt 2>&1
+# in-step columns: the trace that is not launch-starved when there is one (tools/trace_unbound.sh: 12 steps), else the plain one (9)
+if [ -s $OUT/${TAG}_unbound_kernel_stats_by_grid.txt ]; then
+  python $ROOT/tools/roofline_table.py $OUT/layers $OUT/${TAG}_unbound_kernel_stats_by_grid.txt 12 > $OUT/${TAG}_roofline_table.txt 2>&1
+else
+  python $ROOT/tools/roofline_table.py $OUT/layers $OUT/${TAG}_bench_kernel_stats_by_grid.txt 9 > $OUT/${TAG}_roofline_table.txt 2>&1
+fi
 cd $ROOT

@@ -8,7 +8,7 @@ import re
 import sqlite3
 import sys
 
-MFMA = re.compile(r'gconv_fast_kernel|wgrad_fast_kernel|gconv_kernel|wgrad_kernel|wino_gemm_nt_kernel|wino_fused_kernel|wino_fused2_kernel|bgemm_kernel|wgrad_fewch_mfma_kernel')
+MFMA = re.compile(r'gconv_fast_kernel|wgrad_fast_kernel|gconv_kernel|wgrad_kernel|wino_gemm_nt_kernel|wino_fused_kernel|wino_fused2_kernel|bgemm_kernel|bgemm_p_kernel|wgrad_fewch_mfma_kernel')
 
 
 def main():
