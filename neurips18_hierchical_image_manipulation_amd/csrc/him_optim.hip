@@ -154,7 +154,7 @@ using namespace him;
 
 extern "C" {
 
-const char* him_version(void) { return "him-hip 0.5 (round 5)"; }
+const char* him_version(void) { return "him-hip 0.6 (round 6)"; }
 const char* him_arch(void) { return "gfx950"; }
 const char* him_last_error(void) { return err_buf(); }
 
