@@ -3,7 +3,7 @@
 import torch
 import torch.nn as nn
 
-from ..nn import Conv2d, InstanceNorm2d, ReLU, MaxPool, ResnetBlock, FusedSequential  # noqa: F401
+from ..nn import Conv2d, InstanceNorm2d, BatchNorm2d, ReLU, MaxPool, ResnetBlock, FusedSequential  # noqa: F401
 
 
 def weights_init(m, conv_sigma=0.02, bnorm_sigma=0.02):
@@ -43,9 +43,13 @@ def print_network(net):
 
 
 def get_norm_layer(norm_type='instance'):
+    """reference :19-26: 'instance' -> InstanceNorm2d(affine=False), 'batch' -> BatchNorm2d(affine=True); anything else
+    raises, as there."""
     if norm_type == 'instance':
         return InstanceNorm2d
-    raise NotImplementedError('normalization layer [%s] is not found on the HIP path' % norm_type)
+    if norm_type == 'batch':
+        return BatchNorm2d
+    raise NotImplementedError('normalization layer [%s] is not found' % norm_type)
 
 
 VGG19_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512]

@@ -219,6 +219,11 @@ class Pix2PixHDModel_condImg(BaseModel):
         """Batch dict -> ``forward`` (reference :188-196; train_mask2image.py:57 keeps the call commented out)."""
         return self.forward(data['label'], data['inst'], data['image'], None, data['mask_in'], data['mask_out'], infer)
 
+    def _d_stateful(self):
+        """True when a discriminator forward changes persisted state: --sn_D (power-iteration vectors) or --norm batch
+        in training (BatchNorm running statistics, three updates per step in the reference: fake detached, real, fake)."""
+        return bool(getattr(self.opt, 'sn_D', False)) or getattr(self.opt, 'norm', 'instance') == 'batch'
+
     def _d_split(self):
         """True when the discriminators get (condition, image) as an ``ops.CondImage`` pair instead of their concatenation:
         no mask on the input, no image pool (it stores concatenated tensors), a condition at all."""
@@ -251,9 +256,10 @@ class Pix2PixHDModel_condImg(BaseModel):
         else:
             side.wait_stream(main)
         out = {'stream': side, 'y_vgg': None}
-        # --sn_D: every discriminator forward moves the persisted power-iteration vectors, so the three passes must run
-        # in the reference's order (fake-detached, real, fake): only the VGG features of the real image run ahead
-        with_d = not getattr(self.opt, 'sn_D', False)
+        # --sn_D / --norm batch: every discriminator forward moves persisted state (power-iteration vectors / BatchNorm
+        # running statistics), so the three passes must run in the reference's order (fake-detached, real, fake): only
+        # the VGG features of the real image run ahead
+        with_d = not self._d_stateful()
         vgg_first = SCHED.real_vgg_first and not self.opt.no_vgg_loss
         with torch.cuda.stream(side):
             if vgg_first:
@@ -369,7 +375,7 @@ class Pix2PixHDModel_condImg(BaseModel):
         # train_mask2image.py:84); during loss_D.backward() they reach D's weights and stop in front of the generator.
         # only optimize_parameters() owns both backward calls; --sn_D: every discriminator forward moves the persisted
         # power-iteration vectors, so the reference's three passes are kept as three passes
-        share = opt.pool_size == 0 and self._share_fake_pass and not getattr(opt, 'sn_D', False)
+        share = opt.pool_size == 0 and self._share_fake_pass and not self._d_stateful()
         if share:
             self._fake_gate = {'open': True}
             pred_fake = self.netD.forward(self._d_input(netD_cond, ops.grad_switch(fake_image, self._fake_gate),

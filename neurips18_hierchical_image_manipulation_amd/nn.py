@@ -238,24 +238,28 @@ class FusedSequential(nn.Sequential):
 
 
 class ResnetBlock(nn.Module):
-    """x + IN(conv3(refpad(ReLU(IN(conv3(refpad(x)))))))  (reference models/layer_util.py:333-378);
-    parameters at ``conv_block.1`` and ``conv_block.5``."""
+    """x + N(conv3(refpad(ReLU(N(conv3(refpad(x)))))))  (reference models/layer_util.py:333-378), N = InstanceNorm2d or,
+    under --norm batch, BatchNorm2d(affine=True); convolutions at ``conv_block.1`` / ``conv_block.5``, BatchNorm
+    parameters and statistics at ``conv_block.2`` / ``conv_block.6``."""
 
     def __init__(self, dim, padding_type='reflect', norm_layer=None, activation=None, use_dropout=False):
-        """Constructor arguments of the reference (:334-335); every call site of the hot path passes reflection padding,
-        the instance norm of ``get_norm_layer`` and ``nn.ReLU(True)`` (Pix2Pix_NET.py:80-83,129-131) -- the one block the
-        HIP executor builds.  Anything else fails here, loudly, instead of being computed as that block."""
+        """Constructor arguments of the reference (:334-335).  Every call site there passes reflection padding, the layer
+        of ``get_norm_layer`` and ``nn.ReLU(True)`` and leaves ``use_dropout`` False (Pix2Pix_NET.py:32,84,173;
+        MaskTwoStreamConv*_NET.py: ``use_dropout=False``; the parsers' --use_dropout reaches no constructor), so the
+        dropout form is unreachable from the reference's entry points: it fails here instead of being computed as the
+        plain block."""
         super().__init__()
         if padding_type != 'reflect':
             raise NotImplementedError('ResnetBlock: padding [%s] is not on the HIP path (reflect only)' % padding_type)
         if use_dropout:
-            raise NotImplementedError('ResnetBlock: use_dropout is not on the HIP path')
-        if norm_layer is not None and not isinstance(norm_layer(dim), InstanceNorm2d):
-            raise NotImplementedError('ResnetBlock: norm_layer must be get_norm_layer("instance")')
+            raise NotImplementedError('ResnetBlock: use_dropout is not on the HIP path (no reference call site sets it)')
+        norm_layer = InstanceNorm2d if norm_layer is None else norm_layer
+        if not isinstance(norm_layer(dim), (InstanceNorm2d, BatchNorm2d)):
+            raise NotImplementedError('ResnetBlock: norm_layer must come from get_norm_layer("instance" | "batch")')
         if activation is not None and not isinstance(activation, (ReLU, nn.ReLU)):
             raise NotImplementedError('ResnetBlock: activation must be ReLU')
-        self.conv_block = nn.Sequential(ReflectionPad2d(1), Conv2d(dim, dim, 3), InstanceNorm2d(dim), ReLU(),
-                                        ReflectionPad2d(1), Conv2d(dim, dim, 3), InstanceNorm2d(dim))
+        self.conv_block = nn.Sequential(ReflectionPad2d(1), Conv2d(dim, dim, 3), norm_layer(dim), ReLU(),
+                                        ReflectionPad2d(1), Conv2d(dim, dim, 3), norm_layer(dim))
 
     def forward(self, x):
         cb = self.conv_block

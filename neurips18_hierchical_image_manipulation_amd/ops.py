@@ -1592,7 +1592,8 @@ def maxpool(x, k, relu_gate=False):
 # channel plumbing: cat / slice / mask-multiply / blend
 # ------------------------------------------------------------------------------------------------
 class _CatMask(torch.autograd.Function):
-    """out = f(mask) * cat(tensors, dim=1); mask (B,1,H,W) or None; mode 0 none, 1 mask, 2 (1-mask)."""
+    """out = cat(f_i(mask) * tensor_i, dim=1); mask (B,1,H,W) or None; mode 0 none, 1 mask, 2 (1-mask) -- one int for every
+    tensor or a tuple with one mode per tensor."""
 
     @staticmethod
     def forward(ctx, mask, mode, *ts):
@@ -1602,11 +1603,14 @@ class _CatMask(torch.autograd.Function):
         B, _, H, W = ts[0].shape
         Ctot = sum(t.shape[1] for t in ts)
         out = torch.empty((B, Ctot, H, W), dtype=torch.float32, device=ts[0].device)
+        modes = tuple(mode) if isinstance(mode, (tuple, list)) else (mode,) * len(ts)
+        if len(modes) != len(ts):
+            raise ValueError('cat_channels: %d mask modes for %d tensors' % (len(modes), len(ts)))
         st, c0 = _stream(), 0
-        for t in ts:
-            lib.him_copy_channels(_p(t), t.shape[1], 0, _p(out), Ctot, c0, t.shape[1], B, H * W, _p(mask), mode, 0, st)
+        for t, md in zip(ts, modes):
+            lib.him_copy_channels(_p(t), t.shape[1], 0, _p(out), Ctot, c0, t.shape[1], B, H * W, _p(mask), md, 0, st)
             c0 += t.shape[1]
-        ctx.mask, ctx.mode = mask, mode
+        ctx.mask, ctx.modes = mask, modes
         ctx.chs = [t.shape[1] for t in ts]
         return out
 
@@ -1620,7 +1624,7 @@ class _CatMask(torch.autograd.Function):
         for i, ch in enumerate(ctx.chs):
             if ctx.needs_input_grad[2 + i]:
                 g = torch.empty((B, ch, H, W), dtype=torch.float32, device=dout.device)
-                lib.him_copy_channels(_p(dout), Ctot, c0, _p(g), ch, 0, ch, B, H * W, _p(ctx.mask), ctx.mode, 0, st)
+                lib.him_copy_channels(_p(dout), Ctot, c0, _p(g), ch, 0, ch, B, H * W, _p(ctx.mask), ctx.modes[i], 0, st)
                 grads.append(g)
             else:
                 grads.append(None)
@@ -1629,8 +1633,16 @@ class _CatMask(torch.autograd.Function):
 
 
 def cat_channels(tensors, mask=None, mask_mode=0):
+    """cat(tensors, 1), optionally times the mask (mode 1) or its complement (mode 2); ``mask_mode`` may hold one mode per
+    tensor (the 'concat' feature fusion: cat((1-m)*ctx, m*obj))."""
     tensors = [t.full() if isinstance(t, LabelCond) else t for t in tensors]
-    out = _CatMask.apply(mask, int(mask_mode if mask is not None else 0), *tensors)
+    if mask is None:
+        mask_mode = 0
+    elif isinstance(mask_mode, (tuple, list)):
+        mask_mode = tuple(int(m) for m in mask_mode)
+    else:
+        mask_mode = int(mask_mode)
+    out = _CatMask.apply(mask, mask_mode, *tensors)
     need = [bool(t.requires_grad) for t in tensors]
     if torch.is_grad_enabled() and any(need) and not all(need):
         # only a channel slice of this tensor can receive a gradient (discriminator input = [data | image]): consumers

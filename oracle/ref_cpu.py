@@ -30,31 +30,46 @@ def _in_layer(ch):
     return nn.InstanceNorm2d(ch, affine=False)
 
 
-class ResnetBlock(nn.Module):
-    """x + IN(conv3(refpad(ReLU(IN(conv3(refpad(x)))))))   (models/layer_util.py:333-378)."""
+def _bn_layer(ch):
+    # models/layer_util.py:20-21  -> BatchNorm2d(affine=True): weight / bias parameters + running statistics
+    return nn.BatchNorm2d(ch, affine=True)
 
-    def __init__(self, dim):
+
+def get_norm_layer(norm_type='instance'):
+    """models/layer_util.py:19-26 ('instance' | 'batch'; anything else raises there too)."""
+    if norm_type == 'batch':
+        return _bn_layer
+    if norm_type == 'instance':
+        return _in_layer
+    raise NotImplementedError('normalization layer [%s] is not found' % norm_type)
+
+
+class ResnetBlock(nn.Module):
+    """x + N(conv3(refpad(ReLU(N(conv3(refpad(x)))))))   (models/layer_util.py:333-378; no call site of the reference
+    passes use_dropout=True)."""
+
+    def __init__(self, dim, norm=_in_layer):
         super().__init__()
-        # indices 1 and 5 carry the parameters, as in the reference Sequential
+        # indices 1 and 5 carry the convolutions (2 and 6 the BatchNorm parameters), as in the reference Sequential
         self.conv_block = nn.Sequential(
-            nn.ReflectionPad2d(1), nn.Conv2d(dim, dim, 3), _in_layer(dim), nn.ReLU(False),
-            nn.ReflectionPad2d(1), nn.Conv2d(dim, dim, 3), _in_layer(dim))
+            nn.ReflectionPad2d(1), nn.Conv2d(dim, dim, 3), norm(dim), nn.ReLU(False),
+            nn.ReflectionPad2d(1), nn.Conv2d(dim, dim, 3), norm(dim))
 
     def forward(self, x):
         return x + self.conv_block(x)
 
 
-def _stem(cin, ngf):
-    return [nn.ReflectionPad2d(3), nn.Conv2d(cin, ngf, 7), _in_layer(ngf), nn.ReLU(False)]
+def _stem(cin, ngf, norm=_in_layer):
+    return [nn.ReflectionPad2d(3), nn.Conv2d(cin, ngf, 7), norm(ngf), nn.ReLU(False)]
 
 
-def _down(c):
-    return [nn.Conv2d(c, 2 * c, 3, stride=2, padding=1), _in_layer(2 * c), nn.ReLU(False)]
+def _down(c, norm=_in_layer):
+    return [nn.Conv2d(c, 2 * c, 3, stride=2, padding=1), norm(2 * c), nn.ReLU(False)]
 
 
-def _up(cin, cout):
+def _up(cin, cout, norm=_in_layer):
     return [nn.ConvTranspose2d(cin, cout, 3, stride=2, padding=1, output_padding=1),
-            _in_layer(cout), nn.ReLU(False)]
+            norm(cout), nn.ReLU(False)]
 
 
 def _head(ngf, out_nc):
@@ -64,16 +79,18 @@ def _head(ngf, out_nc):
 class GlobalGenerator(nn.Module):
     """models/Pix2Pix_NET.py:63-101 (keys ``model.<i>.*``)."""
 
-    def __init__(self, input_nc, output_nc, ngf=64, n_downsampling=3, n_blocks=9, use_output_gate=False):
+    def __init__(self, input_nc, output_nc, ngf=64, n_downsampling=3, n_blocks=9, use_output_gate=False,
+                 norm_layer='instance'):
         super().__init__()
         self.input_nc, self.output_nc, self.use_output_gate = input_nc, output_nc, use_output_gate
-        seq = _stem(input_nc, ngf)
+        norm = get_norm_layer(norm_layer)
+        seq = _stem(input_nc, ngf, norm)
         for i in range(n_downsampling):
-            seq += _down(ngf * 2 ** i)
-        seq += [ResnetBlock(ngf * 2 ** n_downsampling) for _ in range(n_blocks)]
+            seq += _down(ngf * 2 ** i, norm)
+        seq += [ResnetBlock(ngf * 2 ** n_downsampling, norm) for _ in range(n_blocks)]
         for i in range(n_downsampling):
             c = ngf * 2 ** (n_downsampling - i)
-            seq += _up(c, c // 2)
+            seq += _up(c, c // 2, norm)
         seq += _head(ngf, output_nc)
         self.model = nn.Sequential(*seq)
 
@@ -89,16 +106,17 @@ class LocalEnhancer(nn.Module):
     """models/Pix2Pix_NET.py:8-61 (defined in the reference, not reachable from its models)."""
 
     def __init__(self, input_nc, output_nc, ngf=32, n_downsample_global=3, n_blocks_global=9,
-                 n_local_enhancers=1, n_blocks_local=3):
+                 n_local_enhancers=1, n_blocks_local=3, norm_layer='instance'):
         super().__init__()
         self.n_local_enhancers = n_local_enhancers
+        norm = get_norm_layer(norm_layer)
         g = GlobalGenerator(input_nc, output_nc, ngf * 2 ** n_local_enhancers, n_downsample_global,
-                            n_blocks_global).model
+                            n_blocks_global, norm_layer=norm_layer).model
         self.model = nn.Sequential(*list(g.children())[:-3])                # :18
         for n in range(1, n_local_enhancers + 1):
             c = ngf * 2 ** (n_local_enhancers - n)
-            down = _stem(input_nc, c) + _down(c)
-            up = [ResnetBlock(2 * c) for _ in range(n_blocks_local)] + _up(2 * c, c)
+            down = _stem(input_nc, c, norm) + _down(c, norm)
+            up = [ResnetBlock(2 * c, norm) for _ in range(n_blocks_local)] + _up(2 * c, c, norm)
             if n == n_local_enhancers:
                 up += _head(ngf, output_nc)
             setattr(self, 'model%d_1' % n, nn.Sequential(*down))
@@ -116,34 +134,67 @@ class LocalEnhancer(nn.Module):
         return out
 
 
+class FeatureFusionBlock(nn.Module):
+    """models/layer_util.py:295-330.  'add': x + y.  'concat': norm(conv1x1(ReLU(cat(x, y)))) with parameters at
+    ``conv1`` (and ``norm1`` under --norm batch); ``main_module`` is an Identity at the one call site (Pix2Pix_NET.py:135)."""
+
+    def __init__(self, planes, fusion_type, norm):
+        super().__init__()
+        assert fusion_type in ('add', 'concat')                            # :300
+        self.fusion_type = fusion_type
+        if fusion_type == 'concat':                                        # :310-314
+            self.conv1 = nn.Conv2d(planes * 2, planes, kernel_size=1, stride=1, padding=0)
+            self.norm1 = norm(planes)
+
+    def forward(self, x, y):
+        if self.fusion_type == 'add':
+            return x + y
+        return self.norm1(self.conv1(F.relu(torch.cat([x, y], 1))))          # :325-328
+
+
 class GlobalTwoStreamGenerator(nn.Module):
-    """models/Pix2Pix_NET.py:103-247, restricted to feat_fusion='early_add' (the only shipped mode)."""
+    """models/Pix2Pix_NET.py:103-247: --feat_fusion early_add (the shipped mode) | early_concat | late_add | late_concat,
+    --norm instance | batch."""
 
     def __init__(self, input_nc, output_nc, ngf=64, n_downsampling=3, n_blocks=9, use_skip=False,
-                 which_stream='ctx', use_output_gate=False, extra_embed=False):
+                 which_stream='ctx', use_output_gate=False, extra_embed=False, feat_fusion='early_add',
+                 norm_layer='instance'):
         super().__init__()
+        assert not ('label' not in which_stream and 'late' in feat_fusion)   # :108
+        assert not ('ctx' not in which_stream and 'late' in feat_fusion)     # :109
         self.nd, self.use_skip, self.which_stream = n_downsampling, use_skip, which_stream
-        self.use_output_gate, self.output_nc = use_output_gate, output_nc
+        self.use_output_gate, self.output_nc, self.feat_fusion = use_output_gate, output_nc, feat_fusion
+        norm = get_norm_layer(norm_layer)
         feat = ngf * 2 ** n_downsampling
         self.feat_dim = feat
 
         def downs():
             seq = []
             for i in range(n_downsampling):
-                seq += _down(ngf * 2 ** i)
+                seq += _down(ngf * 2 ** i, norm)
             return nn.Sequential(*seq)
 
+        def embedder(n):                                                     # :166-174
+            return nn.Sequential(*[ResnetBlock(feat, norm) for _ in range(n)])
+
         if 'ctx' in which_stream:
-            self.ctx_inputEmbedder = nn.Sequential(*_stem(6 if extra_embed else 3, ngf))
+            self.ctx_inputEmbedder = nn.Sequential(*_stem(6 if extra_embed else 3, ngf, norm))
             self.ctx_downsampler = downs()
         if 'label' in which_stream:
-            self.obj_inputEmbedder = nn.Sequential(*_stem(input_nc, ngf))
+            self.obj_inputEmbedder = nn.Sequential(*_stem(input_nc, ngf, norm))
             self.obj_downsampler = downs()
-        self.latent_embedder = nn.Sequential(*[ResnetBlock(feat) for _ in range(n_blocks)])
+        if which_stream == 'ctx_label':                                      # :133-136
+            self.feat_fuser = FeatureFusionBlock(feat, feat_fusion.split('_')[1], norm)
+        if 'early' in feat_fusion:                                           # :137-144
+            self.latent_embedder = embedder(n_blocks)
+        elif 'late' in feat_fusion:
+            self.obj_latent_embedder = embedder(n_blocks // 2)
+            self.ctx_latent_embedder = embedder(n_blocks // 2)
+            self.latent_embedder = embedder(n_blocks - n_blocks // 2)
         dec = []
         for i in range(n_downsampling):
             c = ngf * 2 ** (n_downsampling - i)
-            dec += _up(2 * c if (use_skip and i > 0) else c, c // 2)          # :183-184
+            dec += _up(2 * c if (use_skip and i > 0) else c, c // 2, norm)    # :183-184
         self.decoder = nn.Sequential(*dec)
         self.outputEmbedder = nn.Sequential(*_head(ngf, output_nc))
 
@@ -164,7 +215,10 @@ class GlobalTwoStreamGenerator(nn.Module):
             obj, _ = self._encode(self.obj_inputEmbedder, self.obj_downsampler, label, False)
         if self.which_stream == 'ctx_label':
             m = F.max_pool2d(mask, 2 ** self.nd, 2 ** self.nd)              # :134,237-238
-            h = (1 - m) * ctx + m * obj                                     # :215-217 ('add' fusion)
+            if 'late' in self.feat_fusion:                                  # :212-214
+                ctx = self.ctx_latent_embedder(ctx)
+                obj = self.obj_latent_embedder(obj)
+            h = self.feat_fuser((1 - m) * ctx, m * obj)                     # :215-217
         elif self.which_stream == 'ctx':
             h = ctx
         else:
@@ -422,21 +476,23 @@ class Mask2ImageModel(nn.Module):
         nc = opt.label_nc + (0 if opt.no_instance else 1)
         if opt.netG == 'global':
             self.netG = GlobalGenerator(nc + 3, opt.output_nc, opt.ngf, opt.n_downsample_global,
-                                        opt.n_blocks_global, opt.use_output_gate)
+                                        opt.n_blocks_global, opt.use_output_gate, norm_layer=opt.norm)
         elif opt.netG == 'global_twostream':
             self.netG = GlobalTwoStreamGenerator(nc, opt.output_nc, opt.ngf, opt.n_downsample_global,
                                                  opt.n_blocks_global, opt.use_skip, opt.which_encoder,
-                                                 opt.use_output_gate, extra_embed=self.color)
+                                                 opt.use_output_gate, extra_embed=self.color,
+                                                 feat_fusion=opt.feat_fusion, norm_layer=opt.norm)
         elif opt.netG == 'local':
             self.netG = LocalEnhancer(nc + 3, opt.output_nc, opt.ngf, opt.n_downsample_global,
-                                      opt.n_blocks_global, opt.n_local_enhancers, opt.n_blocks_local)
+                                      opt.n_blocks_global, opt.n_local_enhancers, opt.n_blocks_local,
+                                      norm_layer=opt.norm)
         else:
             raise NameError('global generator name is not defined properly: %s' % opt.netG)
         d_in = nc + opt.output_nc + (0 if opt.no_imgCond else 3)             # :66-71
         if opt.netG == 'global_twostream' and opt.which_encoder == 'ctx':
             d_in = 3
         self.d_in = d_in
-        self.netD = MultiscaleDiscriminator(d_in, opt.ndf, opt.n_layers_D, opt.num_D, spectral_norm=opt.sn_D,
+        self.netD = MultiscaleDiscriminator(d_in, opt.ndf, opt.n_layers_D, opt.num_D, norm=opt.norm, spectral_norm=opt.sn_D,
                                             getIntermFeat=not opt.no_ganFeat_loss, use_sigmoid=opt.no_lsgan)
         self.vgg = None if opt.no_vgg_loss else Vgg19()
         self.optimizer_G = torch.optim.Adam(self.netG.parameters(), lr=opt.lr, betas=(opt.beta1, 0.999))

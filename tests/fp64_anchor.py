@@ -122,16 +122,19 @@ def oracle_quantities(om, before):
 
 
 def dead_biases(net, tag):
-    """'<tag>/<name>' of the conv biases that feed an InstanceNorm2d(affine=False): their true gradient is exactly zero
-    (the plane mean is subtracted), every implementation holds rounding noise there -- no relative error exists."""
+    """'<tag>/<name>' of the conv biases that feed an InstanceNorm2d(affine=False) or a BatchNorm2d in training mode: their
+    true gradient is exactly zero (the plane / batch mean is subtracted), every implementation holds rounding noise there --
+    no relative error exists.  Sequential neighbours, and ``conv1`` -> ``norm1`` of the 'concat' FeatureFusionBlock."""
     names = set()
+    convs, norms = ('Conv2d', 'ConvTranspose2d', 'SNConv2d'), ('InstanceNorm2d', 'BatchNorm2d')
     for mname, mod in net.named_modules():
         if mod.__class__.__name__ in ('Sequential', 'FusedSequential'):
             kids = list(mod.named_children())
             for (n0, c0), (_, c1) in zip(kids[:-1], kids[1:]):
-                if c0.__class__.__name__ in ('Conv2d', 'ConvTranspose2d', 'SNConv2d') and c1.__class__.__name__ == 'InstanceNorm2d' \
-                        and getattr(c0, 'bias', None) is not None:
+                if c0.__class__.__name__ in convs and c1.__class__.__name__ in norms and getattr(c0, 'bias', None) is not None:
                     names.add('%s/%s%s.bias' % (tag, mname + '.' if mname else '', n0))
+        elif mod.__class__.__name__ == 'FeatureFusionBlock' and hasattr(mod, 'conv1') and mod.conv1.bias is not None:
+            names.add('%s/%s.conv1.bias' % (tag, mname))
     return names
 
 

@@ -100,6 +100,18 @@ def trajectory(tag, fl, B, H, W, steps, color=False, save_outputs=False, save_ke
             ora_l.append([o[k] for k in NAMES])
     finally:
         torch.Tensor.uniform_ = uni
+    if fl.get('norm') == 'batch':
+        # BatchNorm bookkeeping after the last step: the running statistics and forward counts of the first BatchNorm of
+        # each net (the reference runs the discriminator three times per step: fake detached, real, fake)
+        for tagn, rn, on in (('g', rm.netG, om.netG), ('d', rm.netD, om.netD)):
+            rs, os_ = rn.state_dict(), on.state_dict()
+            k = [k for k in rs if k.endswith('running_mean')][0]
+            for kk in (k, k[:-4] + 'var', k[:-12] + 'num_batches_tracked'):
+                assert torch.equal(rs[kk], os_[kk]), kk
+            extra['bn_%s_key' % tagn] = np.array(k)
+            extra['bn_%s_running_mean' % tagn] = rs[k].numpy()
+            extra['bn_%s_running_var' % tagn] = rs[k[:-4] + 'var'].numpy()
+            extra['bn_%s_batches' % tagn] = rs[k[:-12] + 'num_batches_tracked'].numpy()
     ref_l, ora_l = np.array(ref_l, np.float64), np.array(ora_l, np.float64)
     rel = np.abs(ref_l - ora_l) / np.maximum(np.abs(ref_l), 1e-12)
     print('%s: %d steps, max rel(oracle vs reference) = %.3e, %.1fs' % (tag, steps, rel.max(), time.time() - t0))
@@ -437,6 +449,16 @@ FLAG_VARIANTS.update({
     'tiny_two_ctxlabel_plain': dict(TINY_TWO3, which_encoder='ctx_label'),
     'tiny_two_label': dict(TINY_TWO3, which_encoder='label'),
     'tiny_two_label_gate': dict(TINY_TWO3, which_encoder='label', use_output_gate=True, mask_gan_input=True)})
+# round 6 (second half): the generator flags the HIP path used to refuse -- --norm batch (models/layer_util.py:20-21:
+# BatchNorm2d(affine=True) in the generator AND the discriminator) and --feat_fusion early_concat | late_add | late_concat
+# (models/Pix2Pix_NET.py:133-144,212-217; layer_util.py:295-330).  Three blocks: late fusion splits them 1 + 1 | 2.
+FLAG_VARIANTS.update({
+    'tiny_flag_norm_batch': dict(TINY2, norm='batch'),
+    'tiny_two_early_concat': dict(TINY_TWO3, which_encoder='ctx_label', feat_fusion='early_concat'),
+    'tiny_two_late_add': dict(TINY_TWO3, which_encoder='ctx_label', feat_fusion='late_add', n_blocks_global=3),
+    'tiny_two_late_concat_batch': dict(TINY_TWO3, which_encoder='ctx_label', feat_fusion='late_concat', norm='batch',
+                                       n_blocks_global=3, use_skip=True, use_output_gate=True, no_imgCond=True,
+                                       mask_gan_input=True)})
 C1 = dict(model='pix2pixHD_condImg', netG='global', ngf=64, ndf=64, n_downsample_global=4, n_blocks_global=9,
           num_D=1, n_layers_D=3, label_nc=35, no_instance=True)
 C2 = dict(C1, num_D=3)

@@ -189,7 +189,9 @@ def test_state_dict_keys_match_oracle_for_every_generator():
 
 FLAG_GOLDENS = ('tiny_flag_lambda_rec', 'tiny_flag_soft_mask', 'tiny_flag_rec_no_ganfeat', 'tiny_flag_no_vgg_no_imgcond',
                 'tiny_flag_no_lsgan',
-                'tiny_two_ctx', 'tiny_two_ctx_gate_skip', 'tiny_two_ctxlabel_plain', 'tiny_two_label', 'tiny_two_label_gate')
+                'tiny_two_ctx', 'tiny_two_ctx_gate_skip', 'tiny_two_ctxlabel_plain', 'tiny_two_label', 'tiny_two_label_gate',
+                # --norm batch (BatchNorm2d parameters + statistics in both nets) and --feat_fusion early_concat | late_*
+                'tiny_flag_norm_batch', 'tiny_two_early_concat', 'tiny_two_late_add', 'tiny_two_late_concat_batch')
 
 
 @pytest.mark.parametrize('tag', FLAG_GOLDENS)
@@ -211,17 +213,20 @@ def test_checkpoint_keys_follow_the_reference_for_every_flag_set(tag):
     om = ref_cpu.Mask2ImageModel(ref_cpu.Opt(**flags))
     assert list(om.netG.state_dict().keys()) == g_keys and list(om.netD.state_dict().keys()) == d_keys
     nc = flags['label_nc']
+    norm = flags.get('norm', 'instance')
     d_in = nc + 3 + (0 if flags.get('no_imgCond') else 3)
     if flags['netG'] == 'global_twostream':
         if flags['which_encoder'] == 'ctx':
             d_in = 3        # the discriminator sees the image only (pix2pixHD_condImg_model.py:70-71)
         netG = P.GlobalTwoStreamGenerator(nc, 3, flags['ngf'], flags['n_downsample_global'], flags['n_blocks_global'],
-                                          use_skip=bool(flags.get('use_skip')), which_stream=flags['which_encoder'],
-                                          use_output_gate=bool(flags.get('use_output_gate')))
+                                          norm_layer=norm, use_skip=bool(flags.get('use_skip')),
+                                          which_stream=flags['which_encoder'],
+                                          use_output_gate=bool(flags.get('use_output_gate')),
+                                          feat_fusion=flags.get('feat_fusion', 'early_add'))
     else:
         netG = P.GlobalGenerator(nc + (0 if flags.get('no_imgCond') else 3), 3, flags['ngf'], flags['n_downsample_global'],
-                                 flags['n_blocks_global'])
-    netD = MultiscaleDiscriminator(d_in, flags['ndf'], flags['n_layers_D'], 'instance', False, flags['num_D'], not flat)
+                                 flags['n_blocks_global'], norm_layer=norm)
+    netD = MultiscaleDiscriminator(d_in, flags['ndf'], flags['n_layers_D'], norm, False, flags['num_D'], not flat)
     assert list(netG.state_dict().keys()) == g_keys
     sd = netD.state_dict()
     assert list(sd.keys()) == d_keys

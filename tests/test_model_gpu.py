@@ -81,9 +81,27 @@ def test_tiny_global_forward_tensors_match_reference():
                                  'tiny_flag_no_lsgan',
                                  # --which_encoder ctx (image-only discriminator input) | label | ctx_label, +- skip / gate
                                  'tiny_two_ctx', 'tiny_two_ctx_gate_skip', 'tiny_two_ctxlabel_plain', 'tiny_two_label',
-                                 'tiny_two_label_gate'])
+                                 'tiny_two_label_gate',
+                                 # round 6: --norm batch (generator + discriminator) and --feat_fusion early_concat | late_*
+                                 'tiny_flag_norm_batch', 'tiny_two_early_concat', 'tiny_two_late_add',
+                                 'tiny_two_late_concat_batch'])
 def test_tiny_trajectories_match_reference(tag):
-    rel, _, _, _ = run_traj(tag)
+    rel, model, g, flags = run_traj(tag)
+    if flags.get('norm') == 'batch':
+        # BatchNorm bookkeeping after the five steps, against the REAL reference's: one generator forward and THREE
+        # discriminator forwards per step (fake detached, real, fake) in that order -- the running statistics are an
+        # exponential average of per-pass batch statistics, so a shared or re-ordered pass shows up here
+        model.sync()
+        for net, name in ((model.netG, 'g'), (model.netD, 'd')):
+            sd, key = net.state_dict(), str(g['bn_%s_key' % name])
+            assert int(sd[key[:-12] + 'num_batches_tracked']) == int(g['bn_%s_batches' % name]), key
+            # five free-running steps (the weights have drifted by the step's own rounding): 1 % of the layer's
+            # activation scale; one missing / extra / re-ordered pass moves the averages by ~10 % of it
+            scale = float(np.sqrt(g['bn_%s_running_var' % name]).max())
+            for what in ('mean', 'var'):
+                got, ref = sd[key[:-4] + what].cpu().numpy(), g['bn_%s_running_%s' % (name, what)]
+                assert np.abs(got - ref).max() <= 1e-2 * scale ** (2 if what == 'var' else 1), (
+                    key, what, np.abs(got - ref).max(), scale)
     assert rel[0].max() < 1e-4, 'step-0 losses: %s' % rel[0]
     # the 32x64 toy nets normalise 2x3-pixel maps, which amplifies rounding; the 1e-3 bar is for the real sizes.  The
     # two-stream variants WITHOUT the output gate repaint the whole image from 8x8 latent planes and leave the rounding
@@ -364,6 +382,15 @@ def _adam_arithmetic_errors(model, before, moments_before, t_before):
 # oracle's own -- at least a third of it, over at least this many (HIP step, float64 step) samples -- instead of "in one
 # sample of up to 100"
 PARITY_MIN_SAMPLES, PARITY_FRACTION_OF_ORACLE = 30, 1.0 / 3.0
+# round 6, live-only toy runs: a discriminator event (one LeakyReLU gate on the other side of zero than in float64) strikes
+# about one step in 24 on EACH fp32 side of an 8-channel toy net (host oracle, torch's GPU operators and the HIP path,
+# measured over 24 steps on two configurations, profiles/r06_ab_log.txt section 6) and, with atomics in the split-K weight
+# gradients, not in the same step from run to run: "HIP's largest event <= K x the oracle's largest" then fails one run
+# in ~5 on a sample in which the fp32 references happen to show none.  ONE step in twelve of a net may therefore exceed
+# the event bound, up to the largest fp32-vs-float64 event the host oracle itself has produced on these nets; 6-step
+# full-size runs get no such step (their oracle samples always hold events), and a defect that is there in every step is
+# what the TYPICAL bounds catch.
+PARITY_ISOLATED_EVENT_EVERY, PARITY_EVENT_CEILING = 12, 3e-2
 
 
 def _teacher_forced(tag, steps, loss_tol=PARITY_LOSS_TOL, anchor=None, golden=None, batch_fn=None, plumbing_tol=None,
@@ -401,6 +428,14 @@ def _teacher_forced_run(tag, steps, loss_tol, anchor, golden, batch_fn, plumbing
     # instead of 57 s per C2 step, 7e-14 from the host's float64 step: test_float64_anchor_on_the_gpu_equals_the_host_anchor).
     # The fp32 oracle -- what the HIP path is compared WITH -- stays on the host, pinned to the reference.
     om64 = None if plumbing_tol is not None else fa.make_oracle(flags, torch.float64, device='cuda')
+    # live-only runs (no committed anchor): the EVENT scale of an fp32 implementation is read off the host oracle's few
+    # live steps alone -- when those happen to hold no event, one HIP event fails the run (toy discriminators: an event
+    # every ~10 steps on either side).  The oracle's code in fp32 on torch's GPU operators (fa.make_oracle(yardstick=True),
+    # the implementation the fraction rule already pools) takes every regular step too and doubles the sample the event
+    # scale is read from; the TYPICAL bounds keep the host oracle alone.
+    om32y = (fa.make_oracle(flags, torch.float32, device='cuda', yardstick=True)
+             if om64 is not None and anchor is None and min(steps, fp64_steps) >= 6 else None)
+    e_y_steps = []
     dead = fa.dead_biases(om.netG, 'G') | fa.dead_biases(om.netD, 'D')
     worst_loss, log, e_hip_steps, e_32_steps, adam_log, vs_oracle = 0.0, [], [], [], [], 0.0
     for s in range(steps):
@@ -439,6 +474,15 @@ def _teacher_forced_run(tag, steps, loss_tol, anchor, golden, batch_fn, plumbing
                                     'delta': fa.rel_l2(q_hip[n]['delta'], q64[n]['delta'])} for n in live})
             e_32_steps.append({n: {'grad': fa.rel_l2(q32[n]['grad'], q64[n]['grad']),
                                    'delta': fa.rel_l2(q32[n]['delta'], q64[n]['delta'])} for n in live})
+            if om32y is not None:
+                with torch.no_grad():
+                    for tg, net in (('G', om32y.netG), ('D', om32y.netD)):
+                        for k, p_ in net.named_parameters():
+                            p_.copy_(before[tg][k])
+                fa.step32_yardstick(om32y, b)
+                gy = {'%s/%s' % (tg, k): p_.grad for tg, net in (('G', om32y.netG), ('D', om32y.netD))
+                      for k, p_ in net.named_parameters()}
+                e_y_steps.append({n: {'grad': fa.rel_l2(gy[n], q64[n]['grad'])} for n in live})
     # ---- extra float64 samples for the BIMODAL tensors (round 5) ---------------------------------------------------------
     # A discriminator tensor's distance from float64 is either at its rounding baseline (1e-6) or at an event (1e-4..1e-3),
     # and at full size an event strikes most steps on EITHER side (C4 bs 16: HIP 5 of 6, oracle 3-4 of 6; LocalEnhancer
@@ -467,7 +511,7 @@ def _teacher_forced_run(tag, steps, loss_tol, anchor, golden, batch_fn, plumbing
         # a second instead of the 20 s of a host step) -- pooled with the host oracle's samples as "what an fp32
         # implementation does"; nothing is asserted against its values
         y_base = {n_: 0 for n_ in bimodal}
-        om32g = fa.make_oracle(flags, torch.float32, device='cuda', yardstick=True) if bimodal else None
+        om32g = (om32y or fa.make_oracle(flags, torch.float32, device='cuda', yardstick=True)) if bimodal else None
         # the state every extra sample starts from = the oracle's current one: adopted ONCE, then restored on the device
         # (arena + moments of the HIP model, parameters + Adam state of the float64 oracle) -- a host round trip of 183 M
         # parameters per sample would cost more than the two steps
@@ -605,10 +649,12 @@ def _teacher_forced_run(tag, steps, loss_tol, anchor, golden, batch_fn, plumbing
             baseline.sort(reverse=True)
         for net in 'GD':       # EVENTS: over the regular steps (the oracle's events are known for those only)
             mh = max((st[n]['grad'], s, n) for s, st in enumerate(regular) for n in names if n.startswith(net))
-            mo = max(max(st[n]['grad'] for st in oracle_steps for n in names if n.startswith(net)), PARITY_FLOOR)
-            events.append((mh[0] / mo, net, mh[0], mh[1], mh[2], mo))
-            if not mh[0] <= PARITY_K_EVENT * mo:
-                bad.append(('event', net, mh[0], PARITY_K_EVENT * mo))
+            mo = max(max(st[n]['grad'] for st in oracle_steps + e_y_steps for n in names if n.startswith(net)), PARITY_FLOOR)
+            over = [s for s, st in enumerate(regular)
+                    if not max(st[n]['grad'] for n in names if n.startswith(net)) <= PARITY_K_EVENT * mo]
+            events.append((mh[0] / mo, net, mh[0], mh[1], mh[2], mo, over))
+            if over and (len(over) > len(regular) // PARITY_ISOLATED_EVENT_EVERY or not mh[0] <= PARITY_EVENT_CEILING):
+                bad.append(('event', net, mh[0], PARITY_K_EVENT * mo, 'steps over the bound: %s' % over))
         med = _median
         per_step = [dict(step=s, loss_rel=log[s][1],
                          **{'%s_%s_%s' % (net, q, who): med([st[n][q] for n in names if n.startswith(net)])
@@ -629,8 +675,13 @@ def _teacher_forced_run(tag, steps, loss_tol, anchor, golden, batch_fn, plumbing
                       watch=watch_log,
                       grad_distance_from_fp64=dict(tensors=names,
                                                    hip=[[st[n]['grad'] for n in names] for st in e_hip_steps],
-                                                   oracle_live=[[st[n]['grad'] for n in names] for st in e_32_steps]),
-                      event_columns=['ratio', 'net', 'hip_max', 'step', 'tensor', 'oracle_max_or_floor'], events=events,
+                                                   oracle_live=[[st[n]['grad'] for n in names] for st in e_32_steps],
+                                                   torch_gpu_fp32=[[st[n]['grad'] for n in names] for st in e_y_steps]),
+                      event_scale_yardstick_steps=len(e_y_steps),
+                      event_columns=['ratio', 'net', 'hip_max', 'step', 'tensor', 'oracle_max_or_floor (host oracle + GPU fp32 yard-stick steps)',
+                                     'steps over K_event x that (tolerated: one in %d, <= %g)' % (PARITY_ISOLATED_EVENT_EVERY,
+                                                                                                  PARITY_EVENT_CEILING)],
+                      events=events,
                       median_over_tensors_per_step=per_step)
     with open(os.path.join(OUT, 'teacher_forced_%s.json' % (out_tag or tag)), 'w') as f:
         json.dump(report, f)
@@ -1205,7 +1256,7 @@ TINY = dict(model='pix2pixHD_condImg', netG='global', ngf=8, ndf=8, n_downsample
 
 @pytest.mark.parametrize('extra', [dict(lambda_rec=5.0), dict(use_soft_mask=True, mask_gan_input=True),
                                    dict(lambda_rec=2.0, no_ganFeat_loss=True), dict(no_vgg_loss=True, no_imgCond=True),
-                                   dict(no_lsgan=True, no_ganFeat_loss=True)])
+                                   dict(no_lsgan=True, no_ganFeat_loss=True), dict(norm='batch')])
 def test_loss_flag_variants_teacher_forced(extra):
     """--lambda_rec (L1 reconstruction added to G_GAN_Feat, reference :249-251), --use_soft_mask (D sees mask_out),
     --no_ganFeat_loss / --no_vgg_loss / --no_imgCond, --no_lsgan (round 6: BCE on the discriminator's Sigmoid outputs,
@@ -1219,7 +1270,9 @@ def test_loss_flag_variants_teacher_forced(extra):
 
 
 @pytest.mark.parametrize('tag', ['tiny_two_ctx', 'tiny_two_ctx_gate_skip', 'tiny_two_ctxlabel_plain', 'tiny_two_label',
-                                 'tiny_two_label_gate'])
+                                 'tiny_two_label_gate',
+                                 # --feat_fusion early_concat | late_add | late_concat (the last with --norm batch)
+                                 'tiny_two_early_concat', 'tiny_two_late_add', 'tiny_two_late_concat_batch'])
 def test_two_stream_encoder_variants_teacher_forced(tag):
     """--which_encoder ctx (the parser default: the discriminator sees the image only) | label | ctx_label, with and without
     --use_skip / --use_output_gate, flag sets whose goldens come from the REAL reference: 12 steps, each from the oracle's

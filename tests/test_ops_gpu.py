@@ -59,6 +59,8 @@ CONV_CASES = [
     (1, 12, 70, 9, 4, 5, 1, 2, 'reflect', 'none'),       # tiny-M sliding-window wgrad 5x5, H > one row chunk
     (2, 64, 32, 32, 96, 1, 2, 0, 'zero', 'none'),        # ConvResnetBlock shortcut: 1x1 stride 2 (empty stride phases)
     (2, 16, 9, 11, 16, 1, 2, 0, 'zero', 'none'),         # 1x1 stride 2 on odd sizes
+    (2, 64, 8, 8, 32, 1, 1, 0, 'zero', 'none'),          # 1x1 stride 1: the 'concat' feature fusion (2C -> C on the latent plane)
+    (2, 256, 4, 8, 128, 1, 1, 0, 'zero', 'none'),        # the same at 32 positions per image
     (2, 70, 32, 32, 64, 7, 2, 3, 'zero', 'none'),        # box2mask stem conv7 stride 2
     (3, 128, 8, 10, 256, 4, 1, 2, 'zero', 'none'),       # PatchGAN plane 9x11 = 99 (not a multiple of 4): fast wgrad, scalar dY quads
     (2, 64, 7, 9, 64, 3, 1, 1, 'reflect', 'none'),       # odd plane 63 with reflect gather in the fast wgrad
@@ -262,6 +264,15 @@ def test_cat_blend_encode():
     assert torch.equal(out.cpu(), ref.detach())
     ga, gb = torch.autograd.grad(out, (ad, bd), gy.to(DEV))
     assert torch.equal(ga.cpu(), ga_ref) and torch.equal(gb.cpu(), gb_ref)
+    # one mask mode per tensor: cat((1-m)*a, m*b), the 'concat' feature fusion's input (Pix2Pix_NET.py:215-217)
+    ref = torch.cat(((1 - m) * a, m * b), 1)
+    ga_ref, gb_ref = torch.autograd.grad(ref, (a, b), gy)
+    out = ops.cat_channels([ad, bd], m.to(DEV), (2, 1))
+    assert torch.equal(out.cpu(), ref.detach())
+    ga, gb = torch.autograd.grad(out, (ad, bd), gy.to(DEV))
+    assert torch.equal(ga.cpu(), ga_ref) and torch.equal(gb.cpu(), gb_ref)
+    with pytest.raises(ValueError):
+        ops.cat_channels([ad, bd], m.to(DEV), (2, 1, 0))
     # blend with a channel-sliced first operand (output gate) and full (two-stream fusion)
     img = _rand(B, 9, H, W, seed=5).requires_grad_(True)
     gen = _rand(B, 3, H, W, seed=6).requires_grad_(True)

@@ -27,7 +27,9 @@ def _model(flags):
                                        ('tiny_flag_rec_no_ganfeat', 3), ('tiny_flag_no_vgg_no_imgcond', 3),
                                        ('tiny_flag_no_lsgan', 3),
                                        ('tiny_two_ctx', 2), ('tiny_two_ctx_gate_skip', 2), ('tiny_two_ctxlabel_plain', 2),
-                                       ('tiny_two_label', 2), ('tiny_two_label_gate', 2)])
+                                       ('tiny_two_label', 2), ('tiny_two_label_gate', 2),
+                                       ('tiny_flag_norm_batch', 3), ('tiny_two_early_concat', 2), ('tiny_two_late_add', 2),
+                                       ('tiny_two_late_concat_batch', 3)])
 def test_oracle_reproduces_reference_losses(tag, steps):
     g = load_golden(tag)
     flags = json.loads(str(g['flags']))
