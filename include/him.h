@@ -202,6 +202,12 @@ int him_upsample2_fwd(const float* x, float* y, int planes, int H, int W, int al
 int him_upsample2_bwd(const float* dy, float* dx, int planes, int H, int W, int align_corners, void* stream);
 int him_logsoftmax_fwd(const float* x, float* y, int B, int C, int hw, void* stream);
 int him_logsoftmax_bwd(const float* y, const float* dy, float* dx, int B, int C, int hw, void* stream);
+/* MaskTwoStreamConv_NET.py:213-221 (the generator the parser builds without --no_comb): the context stream's logits gated
+ * by the object stream's probability, comb = (1 - p) * ctx + p * obj with p, obj (B,1,hw) broadcast over ctx's C channels
+ * (products and sum rounded one by one: torch's values).  bwd: dctx (B,C,hw), dp and dobj (B,1,hw). */
+int him_gate_comb_fwd(const float* ctx, const float* p, const float* obj, float* out, int B, int C, int hw, void* stream);
+int him_gate_comb_bwd(const float* ctx, const float* p, const float* obj, const float* dout, float* dctx, float* dp,
+                      float* dobj, int B, int C, int hw, void* stream);
 size_t him_mask_loss_ws(void);
 int him_masked_nll_fwd(const float* logp, const float* label, const float* mask, float* out2, int B, int C, int hw,
                        void* ws, size_t ws_bytes, void* stream);

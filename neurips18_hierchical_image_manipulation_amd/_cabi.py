@@ -106,6 +106,8 @@ _SIGS = {
     'him_upsample2_bwd': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     'him_logsoftmax_fwd': (c_int, [P, P, c_int, c_int, c_int, P]),
     'him_logsoftmax_bwd': (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    'him_gate_comb_fwd': (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    'him_gate_comb_bwd': (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
     'him_mask_loss_ws': (c_size_t, []),
     'him_masked_nll_fwd': (c_int, [P, P, P, P, c_int, c_int, c_int, P, c_size_t, P]),
     'him_masked_nll_bwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),

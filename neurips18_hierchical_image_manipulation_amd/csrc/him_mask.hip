@@ -343,6 +343,40 @@ __global__ void logsoftmax_bwd_kernel(const float* __restrict__ y, const float* 
   }
 }
 
+// ---- object-gated combination of the two streams' logits (MaskTwoStreamConv_NET.py:213-221, the parser's default net) ---
+// comb[b,c,i] = (1 - p[b,i]) * ctx[b,c,i] + p[b,i] * obj[b,i]   with p = sigmoid(obj) broadcast over the C channels.
+// The three products / the sum are rounded one by one (no fused multiply-add): the forward is torch's, bit for bit.
+__global__ void gate_comb_fwd_kernel(const float* __restrict__ ctx, const float* __restrict__ p, const float* __restrict__ obj,
+                                     float* __restrict__ out, int B, int C, int hw) {
+  const long long total = (long long)B * C * hw;
+  GS_LOOP(i, total) {
+    const int px = (int)(i % hw);
+    const int b = (int)(i / ((long long)C * hw));
+    const float g = p[(size_t)b * hw + px];
+    out[i] = __fadd_rn(__fmul_rn(__fsub_rn(1.f, g), ctx[i]), __fmul_rn(g, obj[(size_t)b * hw + px]));
+  }
+}
+// dctx = (1 - p) * dout;  dobj = p * sum_c dout;  dp = sum_c dout * (obj - ctx)      (one thread per pixel walks the channels)
+__global__ void gate_comb_bwd_kernel(const float* __restrict__ ctx, const float* __restrict__ p, const float* __restrict__ obj,
+                                     const float* __restrict__ dout, float* __restrict__ dctx, float* __restrict__ dp,
+                                     float* __restrict__ dobj, int B, int C, int hw) {
+  const long long n = (long long)B * hw;
+  GS_LOOP(i, n) {
+    const int b = (int)(i / hw), r = (int)(i - (long long)b * hw);
+    const size_t base = (size_t)b * C * hw + r;
+    const float g = p[i], l = obj[i];
+    float sd = 0.f, sg = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float d = dout[base + (size_t)c * hw];
+      dctx[base + (size_t)c * hw] = (1.f - g) * d;
+      sd += d;
+      sg += d * (l - ctx[base + (size_t)c * hw]);
+    }
+    dobj[i] = g * sd;
+    dp[i] = sg;
+  }
+}
+
 // ---- losses ------------------------------------------------------------------------------------------------------
 // MaskReconLoss (models/mask_losses.py:12-27): NLLLoss2d(ignore_index) with the positions where mask < 0.5 ignored:
 // loss = -sum_{valid} logp[label] / #valid.  Stage 1: per-block (sum, count); stage 2 below.
@@ -545,6 +579,19 @@ int him_logsoftmax_bwd(const float* y, const float* dy, float* dx, int B, int C,
   if (B <= 0 || C <= 0 || hw <= 0) return fail(HIM_E_INVALID, "logsoftmax: B=%d C=%d hw=%d", B, C, hw);
   hipLaunchKernelGGL(logsoftmax_bwd_kernel, gs_grid((long long)B * hw), dim3(256), 0, ST, y, dy, dx, B, C, hw);
   return check_launch("logsoftmax_bwd");
+}
+
+int him_gate_comb_fwd(const float* ctx, const float* p, const float* obj, float* out, int B, int C, int hw, void* stream) {
+  if (B <= 0 || C <= 0 || hw <= 0) return fail(HIM_E_INVALID, "gate_comb: B=%d C=%d hw=%d", B, C, hw);
+  hipLaunchKernelGGL(gate_comb_fwd_kernel, gs_grid((long long)B * C * hw), dim3(256), 0, ST, ctx, p, obj, out, B, C, hw);
+  return check_launch("gate_comb_fwd");
+}
+int him_gate_comb_bwd(const float* ctx, const float* p, const float* obj, const float* dout, float* dctx, float* dp,
+                      float* dobj, int B, int C, int hw, void* stream) {
+  if (B <= 0 || C <= 0 || hw <= 0) return fail(HIM_E_INVALID, "gate_comb: B=%d C=%d hw=%d", B, C, hw);
+  hipLaunchKernelGGL(gate_comb_bwd_kernel, gs_grid((long long)B * hw), dim3(256), 0, ST, ctx, p, obj, dout, dctx, dp, dobj,
+                     B, C, hw);
+  return check_launch("gate_comb_bwd");
 }
 
 static const int LOSS_BLOCKS = 1024;

@@ -62,6 +62,40 @@ def lr_control(loss_G, loss_D_real, loss_D_fake, gan_margin=0.3):
     return float(update_g), float(update_d)
 
 
+class NLayerDiscriminator(nn.Module):
+    """One PatchGAN (reference Discriminator_NET.py:60-125) as box2mask's --which_gan patch builds it: getIntermFeat False
+    -> a flat ``model`` Sequential (keys ``model.<i>.*``), use_sigmoid True -> a trailing Sigmoid for nn.BCELoss;
+    ``forward(input, cond)`` concatenates the condition behind the input.  (MultiscaleDiscriminator below builds its
+    scales from the same blocks under its own names.)"""
+
+    def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer='instance', use_sigmoid=False, getIntermFeat=False):
+        super().__init__()
+        from ..nn import Conv2d
+        if getIntermFeat:
+            raise NotImplementedError('NLayerDiscriminator(getIntermFeat=True) is only reached through '
+                                      'MultiscaleDiscriminator in the reference; use that class')
+        if norm_layer not in ('instance', 'batch'):
+            raise NotImplementedError('normalization layer [%s] is not found' % norm_layer)
+        norm = InstanceNorm2d if norm_layer == 'instance' else BatchNorm2d
+        self.getIntermFeat, self.n_layers = False, n_layers
+        seq = [Conv2d(input_nc, ndf, 4, 2, 2), LeakyReLU(0.2)]
+        nf = ndf
+        for _ in range(1, n_layers):
+            nf_prev, nf = nf, min(nf * 2, 512)
+            seq += [Conv2d(nf_prev, nf, 4, 2, 2), norm(nf), LeakyReLU(0.2)]
+        nf_prev, nf = nf, min(nf * 2, 512)
+        seq += [Conv2d(nf_prev, nf, 4, 1, 2), norm(nf), LeakyReLU(0.2), Conv2d(nf, 1, 4, 1, 2)]
+        if use_sigmoid:
+            seq.append(Sigmoid())
+        self.model = FusedSequential(*seq)
+        self.apply(weights_init)        # reference :109
+
+    def forward(self, input, cond=None):
+        if cond is not None:
+            input = ops.cat_channels([input, cond])
+        return self.model(input)
+
+
 class MultiscaleDiscriminator(nn.Module):
     def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer='instance', use_sigmoid=False, num_D=3,
                  getIntermFeat=True, spectral_norm=False):

@@ -147,15 +147,60 @@ class DilatedResnetBlock(nn.Module):
         return ops.activation(h, 'relu')
 
 
+class _SimpleResBlock(nn.Module):
+    """Shared body of --use_simpleRes' two stages (reference MaskTwoStreamConv*_NET.py:228-306): main path conv3 -> norm ->
+    ReLU -> conv, side path one conv of the same input, then norm -> ReLU of their sum.  State-dict keys
+    ``main_path.{0,1,3}``, ``side_path``, ``output_layer.0`` as upstream."""
+
+    def __init__(self, cin, cout, norm, k2, s2, p2, ks, ss, ps):
+        super().__init__()
+        self.main_path = nn.Sequential(Conv2d(cin, cin, 3, 1, 1), norm(cin), ReLU(), Conv2d(cin, cout, k2, s2, p2))
+        self.side_path = Conv2d(cin, cout, ks, ss, ps)
+        self.output_layer = nn.Sequential(norm(cout), ReLU())
+
+    def _body(self, x):
+        m = self.main_path
+        h = m[1].apply_to(_conv(m[0], x, norm=m[1]), 'relu')
+        # both biases feed the sum that ``output_layer``'s norm centres: together they shift the plane mean only
+        s = ops.add(_conv(self.side_path, x, norm=self.output_layer[0]), _conv(m[3], h, norm=self.output_layer[0]))
+        return self.output_layer[0].apply_to(s, 'relu')
+
+
+class DownResBlock3x3(_SimpleResBlock):
+    """``downResBlock_3x3``: main ... -> conv4 s2 p1, side conv4 s2 p1.  Returns (output, input): nothing rectifies the
+    input in place here, the decoder's skip feature is the input itself."""
+
+    def __init__(self, cin, cout, norm=BatchNorm2d):
+        super().__init__(cin, cout, norm, 4, 2, 1, 4, 2, 1)
+
+    def forward(self, x):
+        return self._body(x), x
+
+
+class UpResBlock3x3(_SimpleResBlock):
+    """``upResBlock_3x3``: bilinear x2 (align_corners False), main ... -> conv3 p1, side conv1x1."""
+
+    def __init__(self, cin, cout, norm=BatchNorm2d):
+        super().__init__(cin, cout, norm, 3, 1, 1, 1, 1, 0)
+
+    def forward(self, x):
+        return self._body(ops.upsample_bilinear2(x, False))
+
+
 class MaskTwoStreamConvSwitch_NET(nn.Module):
+    """``comb`` False: MaskTwoStreamConvSwitch_NET (--no_comb, every shipped recipe).  True: the parser's default
+    MaskTwoStreamConv_NET -- the same modules (no dilated blocks), returning the object-gated combination of the two
+    streams' logits (MaskTwoStreamConv_NET.py:206-223)."""
+    comb = False
+
     def __init__(self, opt):
         super().__init__()
         g = lambda k, d: getattr(opt, k, d)  # noqa: E731
         norm = _norm_factory(g('norm_layer', 'batch'))
-        if g('use_simpleRes', False):
-            raise NotImplementedError('--use_simpleRes (downResBlock_3x3 / upResBlock_3x3) is not on the HIP path; no '
-                                      'shipped recipe uses it')
+        simple = bool(g('use_simpleRes', False))
         self.which_stream = g('which_stream', 'obj_context')
+        if 'obj' not in self.which_stream and 'context' not in self.which_stream:
+            raise AssertionError('which_stream [%s] holds neither obj nor context' % self.which_stream)   # reference :18
         self.num_layers = g('num_layers', 3)
         label_nc = g('label_nc', 35)
         input_nc = label_nc * 2 if g('cond_in', 'ctx_obj') == 'ctx_obj' else label_nc
@@ -164,11 +209,12 @@ class MaskTwoStreamConvSwitch_NET(nn.Module):
         dims = [g('conv_dim', 64), 96, 128, 256, 512]      # hard-coded in the reference (:26)
         enc = [Conv2d(input_nc, dims[0], 7, 2, 3), norm(dims[0]), ReLU()]
         for i in range(self.num_layers):
-            enc.append(ConvResnetBlock(dims[i], dims[i + 1], 2, k, norm))
+            enc.append(DownResBlock3x3(dims[i], dims[i + 1], norm) if simple else
+                       ConvResnetBlock(dims[i], dims[i + 1], 2, k, norm))
         self.conv_encoder_modules = nn.Sequential(*enc)
         latent = dims[self.num_layers]
         lat = []
-        if g('add_dilated_layers', False):     # the ADE recipe (reference MaskTwoStreamConvSwitch_NET.py:103-105)
+        if g('add_dilated_layers', False) and not self.comb:   # the ADE recipe (MaskTwoStreamConvSwitch_NET.py:103-105)
             lat += [DilatedResnetBlock(latent, (2, 2), norm), DilatedResnetBlock(latent, (4, 4), norm)]
         lat += [BNResnetBlock(latent, norm) for _ in range(int(math.floor(n_blocks / 2)))]
         self.latent_encoder = nn.Sequential(*lat)
@@ -180,7 +226,7 @@ class MaskTwoStreamConvSwitch_NET(nn.Module):
                 od = dims[self.num_layers - i - 1] if i < self.num_layers else idim // 2
                 if skip and 1 <= i <= self.num_layers:
                     idim *= 2
-                layers.append(DeconvResnetBlock(idim, od, 2, k, align, norm))
+                layers.append(UpResBlock3x3(idim, od, norm) if simple else DeconvResnetBlock(idim, od, 2, k, align, norm))
             layers.append(Conv2d(od, out_nc, 3, 1, 1))
             return nn.Sequential(*layers)
 
@@ -234,4 +280,15 @@ class MaskTwoStreamConvSwitch_NET(nn.Module):
             dec = self.obj_conv_decoder_modules
             obj_logit = _conv(dec[-1], self._decode(dec, h, None))
             obj_prob = ops.activation(obj_logit, 'sigmoid')
-        return ctx_logit, ctx_prob, obj_logit, obj_prob
+        if not self.comb:
+            return ctx_logit, ctx_prob, obj_logit, obj_prob
+        comb_logit, comb_prob = ctx_logit, ctx_prob
+        if ctx_logit is not None and obj_logit is not None:
+            comb_logit = ops.gate_comb(ctx_logit, obj_prob, obj_logit)       # (1 - p) * ctx + p * obj
+            comb_prob = ops.log_softmax_channels(comb_logit)
+        return comb_logit, comb_prob, obj_logit, obj_prob
+
+
+class MaskTwoStreamConv_NET(MaskTwoStreamConvSwitch_NET):
+    """reference models/MaskTwoStreamConv_NET.py (what TwoStreamAE_mask builds without --no_comb)."""
+    comb = True

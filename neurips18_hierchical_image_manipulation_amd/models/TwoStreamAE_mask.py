@@ -1,8 +1,10 @@
-"""box2mask trainer on the HIP kernels: the reference's ``TwoStreamAE_mask`` (models/TwoStreamAE_mask.py) for the
+"""box2mask trainer on the HIP kernels: the reference's ``TwoStreamAE_mask`` (models/TwoStreamAE_mask.py).  Defaults = the
 configuration of scripts/train_box2mask_city.sh (``--model AE_maskgen_twostream --no_comb --which_stream obj_context
 --cond_in ctx_obj --use_gan --which_gan patch_multiscale --objReconLoss bce --norm_layer batch --use_output_gate
---use_ganFeat_loss``).  ``forward(..., eval_mode=False)`` IS the training step, as in the reference (:167-254): losses,
-then the generator's Adam step, then the discriminator's, all inside the call.
+--use_ganFeat_loss``); the parser's other values of those flags run too (round 6: without --no_comb, --which_stream obj |
+context, --cond_in obj | ctx, --which_gan patch, --objReconLoss l1 | none, --use_simpleRes; --which_gan patch_res is not
+built).  ``forward(..., eval_mode=False)`` IS the training step, as in the reference (:167-254): losses, then the
+generator's Adam step, then the discriminator's, all inside the call.
 
 Departures that do not change the arithmetic: the three one-hot tensors are built straight into the 70-channel condition
 buffer; ``x * mask.repeat`` + ``torch.cat`` are one kernel; the discriminator pass on the attached fake runs with frozen D
@@ -17,9 +19,9 @@ from .. import ops
 from ..nn import frozen_params
 from ..optim import FusedAdam
 from .base_model import BaseModel
-from .Discriminator_NET import MultiscaleDiscriminator
+from .Discriminator_NET import MultiscaleDiscriminator, NLayerDiscriminator
 from .layer_util import torch_default_init
-from .MaskTwoStreamConvSwitch_NET import MaskTwoStreamConvSwitch_NET
+from .MaskTwoStreamConvSwitch_NET import MaskTwoStreamConvSwitch_NET, MaskTwoStreamConv_NET
 from .pix2pixHD_condImg_model import pick_device
 
 DEFAULTS = dict(label_nc=35, output_nc=35, num_layers=3, conv_dim=64, conv_size=4, norm_layer='batch', n_blocks=6,
@@ -45,25 +47,35 @@ class TwoStreamAE_mask(BaseModel):
     def __init__(self, opt):
         opt = complete(opt)
         super().__init__(opt)
-        if not opt.no_comb:
-            raise NotImplementedError('MaskTwoStreamConv_NET (without --no_comb) is not on the HIP path')
-        if opt.which_stream != 'obj_context' or opt.cond_in != 'ctx_obj':
-            raise NotImplementedError('box2mask HIP path: --which_stream obj_context --cond_in ctx_obj (the shipped recipe)')
-        if opt.use_gan and opt.which_gan != 'patch_multiscale':
-            raise NotImplementedError('box2mask HIP path: --which_gan patch_multiscale (LSGAN) only')
-        if opt.objReconLoss != 'bce':
-            raise NotImplementedError('box2mask HIP path: --objReconLoss bce only')
+        # every value the parser offers for these flags runs (round 6); what the reference itself cannot run fails here
+        if opt.cond_in not in ('obj', 'ctx', 'ctx_obj'):
+            raise NotImplementedError('--cond_in [%s]: obj | ctx | ctx_obj (reference construct_input_cond)' % opt.cond_in)
+        if opt.use_gan and opt.which_gan not in ('patch', 'patch_multiscale'):
+            raise NotImplementedError('box2mask HIP path: --which_gan patch | patch_multiscale (patch_res: the ConvResnetBlock '
+                                      'discriminator of Discriminator_NET.py:118-183 is not built)')
+        if opt.isTrain and not opt.use_gan:
+            # the reference's forward dies on its first step without --use_gan (loss_G_GAN_Feat is only bound inside
+            # ``if self.use_gan``, TwoStreamAE_mask.py:251): refuse at construction instead of training something else
+            raise NotImplementedError('box2mask without --use_gan: the reference fails in its first step (TwoStreamAE_mask.py:251)')
         self.device = pick_device(opt)
         self.use_gan, self.use_output_gate = bool(opt.use_gan), bool(opt.use_output_gate)
-        self.netG = torch_default_init(MaskTwoStreamConvSwitch_NET(opt)).to(self.device)   # never weights_init'ed upstream
+        self.which_stream, self.cond_in, self.which_gan = opt.which_stream, opt.cond_in, opt.which_gan
+        # --objReconLoss l1 | bce, anything else: no object reconstruction term (reference :50-55)
+        self.objReconLoss = opt.objReconLoss if opt.objReconLoss in ('l1', 'bce') else None
+        net = MaskTwoStreamConvSwitch_NET if opt.no_comb else MaskTwoStreamConv_NET      # reference :29-32
+        self.netG = torch_default_init(net(opt)).to(self.device)   # never weights_init'ed upstream
         self.loss_names = ['G_Recon_comb', 'G_Recon_obj', 'KL_loss', 'loss_G_GAN', 'loss_D_GAN', 'loss_G_GAN_Feat']
         self.reducer_G = self.reducer_D = None     # set by dist.attach_data_parallel (one process per GPU)
         if self.isTrain:
             self.old_lr = opt.lr
             self.optimizer = FusedAdam(self.netG.parameters(), lr=opt.lr, betas=(opt.beta1, opt.beta2))
             if self.use_gan:
-                self.netD = MultiscaleDiscriminator(1 + 2 * opt.label_nc, opt.ndf, opt.num_layers_D, opt.norm_layer, False, 2,
-                                                    True).to(self.device)
+                d_nc = 1 + (2 * opt.label_nc if opt.cond_in == 'ctx_obj' else opt.label_nc)       # reference :67-68
+                if opt.which_gan == 'patch':       # one PatchGAN with a Sigmoid, BCE (reference :69-76)
+                    self.netD = NLayerDiscriminator(d_nc, opt.ndf, opt.num_layers_D, opt.norm_layer, True, False)
+                else:                              # LSGAN on two scales, intermediate features kept (:85-94)
+                    self.netD = MultiscaleDiscriminator(d_nc, opt.ndf, opt.num_layers_D, opt.norm_layer, False, 2, True)
+                self.netD.to(self.device)
                 self.optimizer_D = FusedAdam(self.netD.parameters(), lr=opt.lr, betas=(opt.beta1, 0.999))
 
     @property
@@ -76,21 +88,31 @@ class TwoStreamAE_mask(BaseModel):
 
     # -- TwoStreamAE_mask.encode_input (:127-152) + construct_input_cond (:353-360) ---------------------------------
     def encode_cond(self, mask_ctx_in, mask_in, cls):
-        """cat(one-hot box mask in the object's class channel, one-hot(context label map)) -> (B, 2*label_nc, H, W)."""
+        """The generator / discriminator condition of --cond_in (reference :341-347): 'ctx_obj' cat(one-hot box mask in the
+        object's class channel, one-hot(context label map)) -> (B, 2*label_nc, H, W); 'obj' / 'ctx' one half of it."""
         nc = self.opt.label_nc
         ctx, box = self._dev(mask_ctx_in), self._dev(mask_in)
         B, _, H, W = ctx.shape
-        cond = torch.empty((B, 2 * nc, H, W), dtype=torch.float32, device=self.device)
+        halves = {'ctx_obj': 2, 'obj': 1, 'ctx': 1}[self.cond_in]
+        cond = torch.empty((B, halves * nc, H, W), dtype=torch.float32, device=self.device)
         from .._cabi import lib
         st = torch.cuda.current_stream().cuda_stream
         # class ids travel to the device once (B floats, asynchronous); both halves are written by one kernel each --
         # no host read-back of cls, no per-sample copies, no zero fill
-        cls_dev = cls.reshape(-1).to(self.device, torch.float32, non_blocking=True).contiguous()
-        lib.him_class_mask(box.data_ptr(), cls_dev.data_ptr(), cond.data_ptr(), B, nc, 2 * nc, 0, H * W, st)
-        lib.him_onehot(ctx.data_ptr(), cond.data_ptr(), B, nc, 2 * nc, nc, H * W, st)
+        if self.cond_in != 'ctx':
+            cls_dev = cls.reshape(-1).to(self.device, torch.float32, non_blocking=True).contiguous()
+            lib.him_class_mask(box.data_ptr(), cls_dev.data_ptr(), cond.data_ptr(), B, nc, halves * nc, 0, H * W, st)
+        if self.cond_in != 'obj':
+            lib.him_onehot(ctx.data_ptr(), cond.data_ptr(), B, nc, halves * nc, (halves - 1) * nc, H * W, st)
         return cond
 
     def _gan(self, preds, real):
+        """GANLoss.__call__ (reference losses.py:43-53).  patch_multiscale: MSE of each scale's last output, summed.
+        patch: ``preds`` is ONE (B,1,h,w) tensor and ``input[-1]`` there indexes the BATCH -- the BCE of the LAST sample's
+        patch map against the constant target, reproduced as it is."""
+        if self.which_gan == 'patch':
+            last = preds[-1:].contiguous()
+            return ops.bce_mean(last, torch.full_like(last, 1.0 if real else 0.0))
         loss = 0
         for p in preds:
             loss = loss + ops.mse_const(p[-1], 1.0 if real else 0.0)
@@ -106,13 +128,17 @@ class TwoStreamAE_mask(BaseModel):
         if eval_mode:
             return self._labels(comb_prob, obj_prob, label_map, gate)
         label = self._dev(label_map)
-        loss_comb = ops.masked_nll(comb_prob, label, gate)
-        obj_recon_label = obj_prob.detach()          # reconstruct()'s 'obj_recon_label': the UNGATED probability (:280-283)
-        if self.use_output_gate:
-            obj_prob = ops.mul_mask(obj_prob, gate)
-        obj_gt = self._dev(mask_obj_inst)
-        loss_obj = ops.bce_mean(obj_prob, obj_gt)
         zero = torch.zeros((), device=self.device)
+        obj_gt = self._dev(mask_obj_inst)
+        loss_comb = ops.masked_nll(comb_prob, label, gate) if 'context' in self.which_stream else zero      # :190-191
+        loss_obj = zero
+        if 'obj' not in self.which_stream:
+            obj_prob = torch.zeros_like(obj_gt)       # a constant stands in for the object stream (reference :280-281)
+        obj_recon_label = obj_prob.detach()          # reconstruct()'s 'obj_recon_label': the UNGATED probability (:280-283)
+        if 'obj' in self.which_stream and self.objReconLoss is not None:                                    # :192-195
+            if self.use_output_gate:
+                obj_prob = ops.mul_mask(obj_prob, gate)
+            loss_obj = (ops.l1_mean if self.objReconLoss == 'l1' else ops.bce_mean)(obj_prob, obj_gt)
         loss_G_GAN, loss_D, loss_feat = zero, zero, torch.zeros(1, device=self.device)
         if self.use_gan:
             m = gate if self.use_output_gate else None
@@ -120,7 +146,9 @@ class TwoStreamAE_mask(BaseModel):
             fake_d = self.netD(ops.cat_channels([obj_prob.detach(), cond], m, 1))
             self._d_real_loss, self._d_fake_loss = self._gan(real_d, True), self._gan(fake_d, False)
             loss_D = 0.5 * self._d_real_loss + 0.5 * self._d_fake_loss
-            if opt.use_ganFeat_loss:          # returned, never added to loss_G (reference :225-227)
+            if opt.use_ganFeat_loss and self.which_gan != 'patch':
+                # returned, never added to loss_G (reference :225-227); with --which_gan patch the reference's double loop
+                # walks one sample's (1,h,w) map and finds no feature pair: the term stays 0
                 with torch.no_grad():
                     fw, dw = 4.0 / (opt.num_layers_D + 1), 1.0 / 2.0
                     for i in range(2):
@@ -151,8 +179,10 @@ class TwoStreamAE_mask(BaseModel):
                 self.reducer_D.finish()
             self.optimizer_D.step()
         # [comb_recon_label, obj_recon_label] as train_box2mask.py:70-71 reads them (the label map is an int64 arg-max map)
+        comb_label = (self._comb_label(comb_prob.detach(), label, gate) if comb_prob is not None
+                      else torch.zeros_like(gate))          # reference :278-279 without the context stream
         return [loss_comb.detach(), loss_obj.detach(), 0, loss_G_GAN.detach(), loss_D.detach(), loss_feat.detach()], \
-               [self._comb_label(comb_prob.detach(), label, gate), obj_recon_label]
+               [comb_label, obj_recon_label]
 
     @staticmethod
     def _comb_label(comb_prob, label, gate):
@@ -164,8 +194,15 @@ class TwoStreamAE_mask(BaseModel):
 
     def _labels(self, comb_prob, obj_prob, label_map, gate):
         """generate()'s outputs (:298-301): reconstruct() in eval mode."""
-        return {'comb_pred_label': self._comb_label(comb_prob, self._dev(label_map), gate),
-                'obj_pred_label': obj_prob.detach()}
+        comb, obj = self._stream_outputs(comb_prob, obj_prob, gate)
+        return {'comb_pred_label': comb if comb_prob is None else self._comb_label(comb_prob, self._dev(label_map), gate),
+                'obj_pred_label': obj.detach()}
+
+    @staticmethod
+    def _stream_outputs(comb_prob, obj_prob, gate):
+        """What reconstruct() puts in a missing stream's place (reference :278-281): zeros shaped like the mask."""
+        return (torch.zeros_like(gate) if comb_prob is None else comb_prob,
+                torch.zeros_like(gate) if obj_prob is None else obj_prob)
 
     def generate(self, input_dict):
         """Reference :298-301: reconstruct() in eval mode (running BatchNorm statistics; the generator's training /
@@ -234,8 +271,12 @@ class TwoStreamAE_mask(BaseModel):
             cond = self.construct_input_cond(input_obj_cond, input_ctx)
             with torch.set_grad_enabled(not eval_mode and torch.is_grad_enabled()):
                 _, comb_prob, _, obj_prob = self.netG(cond)
-                comb_onehot = self.postprocess_output(comb_prob, gt_mask, gt_one_hot)
-            comb_label = comb_onehot.detach().argmax(1, keepdim=True)
+                if comb_prob is not None:
+                    comb_onehot = self.postprocess_output(comb_prob, gt_mask, gt_one_hot)
+            comb_label = (comb_onehot.detach().argmax(1, keepdim=True) if comb_prob is not None
+                          else torch.zeros_like(gt_mask))
+            if obj_prob is None:
+                obj_prob = torch.zeros_like(gt_mask)
         finally:
             self.netG.train(was_training)
         out = {'comb_recon_label': comb_label, 'obj_recon_label': obj_prob}
@@ -261,6 +302,8 @@ class TwoStreamAE_mask(BaseModel):
                 gt_one_hot, input_ctx, gt_mask, _, input_obj_cond = self.encode_input(
                     label_map, first('mask_ctx_in'), first('mask_out'), first('mask_in'), cls)
                 _, comb_prob, _, obj_prob = self.netG(self.construct_input_cond(input_obj_cond, input_ctx))
+                if comb_prob is None or obj_prob is None:
+                    raise NotImplementedError('evaluate() needs both streams (the reference reads both, :316-334)')
                 if self.use_output_gate:
                     obj_prob = self.mask_variable(obj_prob, gt_mask)
                 cls_id = int(cls.reshape(-1)[0])
@@ -284,12 +327,14 @@ class TwoStreamAE_mask(BaseModel):
         for i, m in enumerate(g.conv_encoder_modules):
             d['conv_encoder_%d' % i] = m
         d['latent_encoder'] = g.latent_encoder
-        for i, m in enumerate(g.obj_conv_decoder_modules):
-            d['obj_conv_decoder_%d' % i] = m
-        d['obj_latent_decoder'] = g.obj_latent_decoder
-        for i, m in enumerate(g.ctx_conv_decoder_modules):
-            d['ctx_conv_decoder_%d' % i] = m
-        d['ctx_latent_decoder'] = g.ctx_latent_decoder
+        if 'obj' in g.which_stream:
+            for i, m in enumerate(g.obj_conv_decoder_modules):
+                d['obj_conv_decoder_%d' % i] = m
+            d['obj_latent_decoder'] = g.obj_latent_decoder
+        if 'context' in g.which_stream:
+            for i, m in enumerate(g.ctx_conv_decoder_modules):
+                d['ctx_conv_decoder_%d' % i] = m
+            d['ctx_latent_decoder'] = g.ctx_latent_decoder
         return d
 
     def save(self, which_epoch):

@@ -1410,6 +1410,35 @@ def log_softmax_channels(x):
     return _LogSoftmax.apply(x)
 
 
+class _GateComb(torch.autograd.Function):
+    """(1 - p) * ctx + p * obj, p and obj (B,1,H,W) broadcast over ctx's channels (MaskTwoStreamConv_NET.py:213-221)."""
+
+    @staticmethod
+    def forward(ctx_, ctx, p, obj):
+        ctx, p, obj = ctx.contiguous(), p.contiguous(), obj.contiguous()
+        _chk(ctx, p, obj)
+        B, C, H, W = ctx.shape
+        if p.shape != (B, 1, H, W) or obj.shape != (B, 1, H, W):
+            raise ValueError('gate_comb: gate / object logits must be (B,1,H,W)')
+        out = torch.empty_like(ctx)
+        lib.him_gate_comb_fwd(_p(ctx), _p(p), _p(obj), _p(out), B, C, H * W, _stream())
+        ctx_.save_for_backward(ctx, p, obj)
+        return out
+
+    @staticmethod
+    def backward(ctx_, dout):
+        ctx, p, obj = ctx_.saved_tensors
+        dout = dout.contiguous()
+        B, C, H, W = ctx.shape
+        dctx, dp, dobj = torch.empty_like(ctx), torch.empty_like(p), torch.empty_like(obj)
+        lib.him_gate_comb_bwd(_p(ctx), _p(p), _p(obj), _p(dout), _p(dctx), _p(dp), _p(dobj), B, C, H * W, _stream())
+        return dctx, dp, dobj
+
+
+def gate_comb(ctx_logit, gate, obj_logit):
+    return _GateComb.apply(ctx_logit, gate, obj_logit)
+
+
 class _MaskedNLL(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logp, label, mask):

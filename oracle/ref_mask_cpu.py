@@ -97,23 +97,59 @@ class DilatedResnetBlock(nn.Module):  # layer_util.py:259-293: bias-free dilated
         return self.relu(out + x)
 
 
+class DownResBlock3x3(nn.Module):
+    """--use_simpleRes encoder stage (``downResBlock_3x3``, MaskTwoStreamConv*_NET.py:270-306): conv3 -> norm -> ReLU ->
+    conv4 s2 p1, plus the side path conv4 s2 p1 of the input, then norm -> ReLU.  Returns (output, input) like
+    ConvResnetBlock above: nothing modifies the input in place here, the decoder's skip is the input as it is."""
+
+    def __init__(self, cin, cout, norm):
+        super().__init__()
+        self.main_path = nn.Sequential(nn.Conv2d(cin, cin, 3, 1, 1), norm(cin), nn.ReLU(), nn.Conv2d(cin, cout, 4, 2, 1))
+        self.side_path = nn.Conv2d(cin, cout, 4, 2, 1)
+        self.output_layer = nn.Sequential(norm(cout), nn.ReLU())
+
+    def forward(self, x):
+        return self.output_layer(self.side_path(x) + self.main_path(x)), x
+
+
+class UpResBlock3x3(nn.Module):
+    """--use_simpleRes decoder stage (``upResBlock_3x3``, :228-268): bilinear x2 (F.upsample's default: align_corners
+    False), conv3 -> norm -> ReLU -> conv3 plus the side path conv1x1, then norm -> ReLU."""
+
+    def __init__(self, cin, cout, norm):
+        super().__init__()
+        self.main_path = nn.Sequential(nn.Conv2d(cin, cin, 3, 1, 1), norm(cin), nn.ReLU(), nn.Conv2d(cin, cout, 3, 1, 1))
+        self.side_path = nn.Conv2d(cin, cout, 1, 1, 0)
+        self.output_layer = nn.Sequential(norm(cout), nn.ReLU())
+
+    def forward(self, x):
+        x = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)
+        return self.output_layer(self.side_path(x) + self.main_path(x))
+
+
 class MaskTwoStreamConvSwitchNet(nn.Module):
+    """MaskTwoStreamConvSwitch_NET (--no_comb) and, with ``comb=True``, MaskTwoStreamConv_NET (the parser's default): the
+    same modules, the latter returns the object-gated combination of the two streams' logits (:206-223) and has no
+    dilated blocks."""
+
     def __init__(self, label_nc=35, output_nc=35, conv_dim=64, num_layers=3, conv_size=4, n_blocks=6,
                  cond_in='ctx_obj', which_stream='obj_context', align_corners=False, norm_layer='batch',
-                 add_dilated_layers=False):
+                 add_dilated_layers=False, comb=False, use_simpleRes=False):
         super().__init__()
+        assert 'obj' in which_stream or 'context' in which_stream              # MaskTwoStreamConv_NET.py:18
         norm = _norm(norm_layer)
         self.num_layers = num_layers
-        self.which_stream = which_stream
+        self.which_stream, self.comb = which_stream, comb
         input_nc = label_nc * 2 if cond_in == 'ctx_obj' else label_nc
         dims = [conv_dim, 96, 128, 256, 512]
         enc = [nn.Conv2d(input_nc, dims[0], 7, 2, 3), norm(dims[0]), nn.ReLU()]
         for i in range(num_layers):
-            enc.append(ConvResnetBlock(dims[i], dims[i + 1], 2, conv_size, norm))
+            enc.append(DownResBlock3x3(dims[i], dims[i + 1], norm) if use_simpleRes else
+                       ConvResnetBlock(dims[i], dims[i + 1], 2, conv_size, norm))
         self.conv_encoder_modules = nn.Sequential(*enc)
         latent = dims[num_layers]
         lat = []
-        if add_dilated_layers:              # MaskTwoStreamConvSwitch_NET.py:103-105 (--add_dilated_layers, the ADE recipe)
+        if add_dilated_layers and not comb:  # MaskTwoStreamConvSwitch_NET.py:103-105 (--add_dilated_layers, the ADE recipe)
             lat += [DilatedResnetBlock(latent, 2, norm), DilatedResnetBlock(latent, 4, norm)]
         lat += [ResnetBlock(latent, norm) for _ in range(int(math.floor(n_blocks / 2)))]
         self.latent_encoder = nn.Sequential(*lat)
@@ -125,7 +161,8 @@ class MaskTwoStreamConvSwitchNet(nn.Module):
                 od = dims[num_layers - i - 1] if i < num_layers else idim // 2
                 if skip and 1 <= i <= num_layers:
                     idim *= 2
-                layers.append(DeconvResnetBlock(idim, od, 2, conv_size, align_corners, norm))
+                layers.append(UpResBlock3x3(idim, od, norm) if use_simpleRes else
+                              DeconvResnetBlock(idim, od, 2, conv_size, align_corners, norm))
             layers.append(nn.Conv2d(od, out_nc, 3, 1, 1))
             return nn.Sequential(*layers)
 
@@ -161,7 +198,14 @@ class MaskTwoStreamConvSwitchNet(nn.Module):
         if 'obj' in self.which_stream:
             obj_logit = self._decode(self.obj_conv_decoder_modules, self.obj_latent_decoder(latent), None)
             obj_prob = torch.sigmoid(obj_logit)
-        return ctx_logit, ctx_prob, obj_logit, obj_prob
+        if not self.comb:
+            return ctx_logit, ctx_prob, obj_logit, obj_prob
+        comb_logit, comb_prob = ctx_logit, ctx_prob                          # MaskTwoStreamConv_NET.py:209-212
+        if ctx_logit is not None and obj_logit is not None:                  # :213-221 (its bmm product is never used)
+            gate = obj_prob.expand_as(ctx_prob)
+            comb_logit = (1 - gate) * ctx_logit + gate * obj_logit
+            comb_prob = F.log_softmax(comb_logit, 1)
+        return comb_logit, comb_prob, obj_logit, obj_prob
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -192,53 +236,105 @@ def lr_control(loss_D_real, loss_D_fake, gan_margin=0.3):
     return float(update_g), float(update_d)
 
 
+class NLayerDiscriminator(nn.Module):
+    """--which_gan patch: ONE PatchGAN (Discriminator_NET.py:60-125 with getIntermFeat=False: a flat ``model`` Sequential,
+    keys ``model.<i>.*``) ending in a Sigmoid (use_sigmoid = not use_lsgan, TwoStreamAE_mask.py:69-76); forward(input, cond)
+    concatenates the two."""
+
+    def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer='batch', use_sigmoid=True):
+        super().__init__()
+        norm = _norm(norm_layer)
+        seq = [nn.Conv2d(input_nc, ndf, 4, 2, 2), nn.LeakyReLU(0.2)]
+        nf = ndf
+        for _ in range(1, n_layers):
+            nf_prev, nf = nf, min(nf * 2, 512)
+            seq += [nn.Conv2d(nf_prev, nf, 4, 2, 2), norm(nf), nn.LeakyReLU(0.2)]
+        nf_prev, nf = nf, min(nf * 2, 512)
+        seq += [nn.Conv2d(nf_prev, nf, 4, 1, 2), norm(nf), nn.LeakyReLU(0.2), nn.Conv2d(nf, 1, 4, 1, 2)]
+        if use_sigmoid:
+            seq.append(nn.Sigmoid())
+        self.model = nn.Sequential(*seq)
+
+    def forward(self, x, cond):
+        return self.model(torch.cat((x, cond), 1))
+
+
 class TwoStreamAEMask(object):
-    """CPU restatement of the reference trainer with the flags of scripts/train_box2mask_city.sh
-    (which_stream obj_context, cond_in ctx_obj, use_gan patch_multiscale, objReconLoss bce, use_output_gate,
-    use_ganFeat_loss, norm_layer batch).  ``step`` = one TwoStreamAE_mask.forward(eval_mode=False): losses, then the G
-    Adam step, then the D Adam step (:237-248)."""
+    """CPU restatement of the reference trainer (models/TwoStreamAE_mask.py:14-254).  Defaults = the flags of
+    scripts/train_box2mask_city.sh (which_stream obj_context, cond_in ctx_obj, use_gan patch_multiscale, objReconLoss bce,
+    use_output_gate, use_ganFeat_loss, norm_layer batch, --no_comb); the parser's other values of those flags -- without
+    --no_comb (MaskTwoStreamConv_NET), --which_stream obj | context, --cond_in ctx | obj, --which_gan patch,
+    --objReconLoss l1 | none, --use_simpleRes -- follow the same lines.  ``step`` = one
+    TwoStreamAE_mask.forward(eval_mode=False): losses, then the G Adam step, then the D Adam step (:237-248)."""
 
     def __init__(self, label_nc=35, ndf=64, num_layers_D=3, gan_weight=0.1, rec_weight=1.0, lambda_feat=1.0, lr=0.0002,
                  beta1=0.5, beta2=0.999, use_output_gate=True, use_ganFeat_loss=True, norm_layer='batch',
-                 add_dilated_layers=False, lr_control=False):
+                 add_dilated_layers=False, lr_control=False, no_comb=True, which_stream='obj_context', cond_in='ctx_obj',
+                 which_gan='patch_multiscale', objReconLoss='bce', use_simpleRes=False):
         from oracle import ref_cpu
         self.label_nc, self.gan_weight, self.rec_weight, self.lambda_feat = label_nc, gan_weight, rec_weight, lambda_feat
         self.use_output_gate, self.use_ganFeat_loss, self.num_layers_D = use_output_gate, use_ganFeat_loss, num_layers_D
-        self.lr_control = lr_control
-        self.netG = MaskTwoStreamConvSwitchNet(label_nc, label_nc, norm_layer=norm_layer,
-                                               add_dilated_layers=add_dilated_layers)
-        self.netD = ref_cpu.MultiscaleDiscriminator(1 + 2 * label_nc, ndf, num_layers_D, num_D=2, norm=norm_layer)
-        self.gan_loss = ref_cpu.gan_loss
+        self.lr_control, self.which_stream, self.cond_in = lr_control, which_stream, cond_in
+        self.which_gan, self.objReconLoss = which_gan, objReconLoss
+        self.netG = MaskTwoStreamConvSwitchNet(label_nc, label_nc, norm_layer=norm_layer, cond_in=cond_in,
+                                               which_stream=which_stream, add_dilated_layers=add_dilated_layers,
+                                               comb=not no_comb, use_simpleRes=use_simpleRes)
+        d_nc = 1 + (2 * label_nc if cond_in == 'ctx_obj' else label_nc)      # :67-68
+        if which_gan == 'patch':                                             # :69-76 (BCE on Sigmoid outputs)
+            self.netD = NLayerDiscriminator(d_nc, ndf, num_layers_D, norm_layer, use_sigmoid=True)
+        elif which_gan == 'patch_multiscale':                                # :85-94 (LSGAN, 2 scales, features kept)
+            self.netD = ref_cpu.MultiscaleDiscriminator(d_nc, ndf, num_layers_D, num_D=2, norm=norm_layer)
+        else:
+            raise NotImplementedError('which_gan [%s] is not restated (patch | patch_multiscale)' % which_gan)
         self.optimizer = torch.optim.Adam(self.netG.parameters(), lr=lr, betas=(beta1, beta2))
         self.optimizer_D = torch.optim.Adam(self.netD.parameters(), lr=lr, betas=(beta1, 0.999))
+
+    def gan_loss(self, pred, real):
+        """GANLoss.__call__ (losses.py:43-53).  patch_multiscale: a list of per-scale lists -> MSE summed over the scales.
+        patch: ``pred`` is ONE tensor, so ``input[-1]`` there indexes the BATCH: the BCE of the LAST sample's patch map."""
+        from oracle import ref_cpu
+        if self.which_gan == 'patch_multiscale':
+            return ref_cpu.gan_loss(pred, real)
+        last = pred[-1]
+        return F.binary_cross_entropy(last, torch.full_like(last, 1.0 if real else 0.0))
+
+    def discriminate(self, x, cond):                                         # :154-159
+        if self.which_gan == 'patch_multiscale':
+            return self.netD(torch.cat((x, cond), 1))
+        return self.netD(x, cond)
 
     def step(self, batch):
         label, mask_out, mask_in = batch['label'], batch['mask_out'], batch['mask_in']
         gt_onehot, ctx, obj = encode_input(label, batch['mask_ctx_in'], mask_in, batch['cls'], self.label_nc)
-        cond = torch.cat((obj, ctx), 1)
+        cond = {'obj': obj, 'ctx': ctx, 'ctx_obj': torch.cat((obj, ctx), 1)}[self.cond_in]      # :341-347
         self.netG.train()
         _, comb_prob, _, obj_prob = self.netG(cond)
-        tgt = label[:, 0].long().clone()
-        tgt[mask_out[:, 0] < 0.5] = 255                       # MaskReconLoss (mask_losses.py:20-26)
-        loss_comb = F.nll_loss(comb_prob, tgt, ignore_index=255)
-        if self.use_output_gate:
-            obj_prob = obj_prob * mask_out
         obj_gt = batch['mask_obj_inst']
-        loss_obj = F.binary_cross_entropy(obj_prob, obj_gt)
+        loss_comb = loss_obj = torch.zeros(())
+        if 'context' in self.which_stream:                                   # :190-191
+            tgt = label[:, 0].long().clone()
+            tgt[mask_out[:, 0] < 0.5] = 255                   # MaskReconLoss (mask_losses.py:20-26)
+            loss_comb = F.nll_loss(comb_prob, tgt, ignore_index=255)
+        if 'obj' not in self.which_stream:                                   # :280-281: a constant in the object's place
+            obj_prob = torch.zeros_like(obj_gt)
+        elif self.objReconLoss != 'none':                                    # :192-195
+            if self.use_output_gate:
+                obj_prob = obj_prob * mask_out
+            loss_obj = (F.l1_loss if self.objReconLoss == 'l1' else F.binary_cross_entropy)(obj_prob, obj_gt)
         real, fake, dcond = obj_gt, obj_prob, cond
         if self.use_output_gate:
             real, fake, dcond = real * mask_out, fake * mask_out, dcond * mask_out
-        real_d = self.netD(torch.cat((real, dcond), 1))
-        fake_d = self.netD(torch.cat((fake.detach(), dcond), 1))
+        real_d = self.discriminate(real, dcond)
+        fake_d = self.discriminate(fake.detach(), dcond)
         loss_D_real, loss_D_fake = self.gan_loss(real_d, True), self.gan_loss(fake_d, False)
         loss_D = 0.5 * loss_D_real + 0.5 * loss_D_fake
         loss_feat = torch.zeros(1)
         if self.use_ganFeat_loss:                              # computed and returned, never added to loss_G (:225-227)
             fw, dw = 4.0 / (self.num_layers_D + 1), 1.0 / 2.0
-            for i in range(2):
+            for i in range(2):                                 # patch: fake_d[i] is one sample's map, len 1 -> no term
                 for j in range(len(fake_d[i]) - 1):
                     loss_feat = loss_feat + dw * fw * F.l1_loss(fake_d[i][j], real_d[i][j].detach()) * self.lambda_feat
-        loss_G_GAN = self.gan_loss(self.netD(torch.cat((fake, dcond), 1)), True)
+        loss_G_GAN = self.gan_loss(self.discriminate(fake, dcond), True)
         loss_G = loss_obj + self.rec_weight * loss_comb + self.gan_weight * loss_G_GAN
         if self.lr_control:                                    # Discriminator_NET.py:190-211, TwoStreamAE_mask.py:229-245
             g_lr, d_lr = lr_control(float(loss_D_real.detach()), float(loss_D_fake.detach()))

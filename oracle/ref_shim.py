@@ -220,6 +220,7 @@ def box2mask_trainer(**flags):
     py3 = [('.iteritems()', '.items()'), ('output_dim = input_dim/2', 'output_dim = input_dim//2')]
     _load_patched('MaskContextAE_NET', py3)
     _load_patched('MaskTwoStreamConvSwitch_NET', py3)
+    _load_patched('MaskTwoStreamConv_NET', py3)          # the parser's default (no --no_comb)
     bm = _load_patched('base_model', py3)
     sys.modules['models.base_model'] = bm
     if not hasattr(nn, 'NLLLoss2d'):

@@ -256,6 +256,60 @@ def golden_box2mask_traj(steps=6):
                         losses=rl.astype(np.float32), loss_names=np.array(ref_mask_cpu.LOSS_NAMES))
 
 
+# round 6: the box2mask flags the HIP path used to refuse, each on the box2mask_traj configuration (64x64, batch 2, ndf 16):
+# the parser's default generator (no --no_comb: MaskTwoStreamConv_NET, object-gated combination of the two streams'
+# logits), --objReconLoss l1 | none, --which_gan patch (one PatchGAN with a Sigmoid + BCE on the LAST sample's map,
+# losses.py:50-53), --which_stream obj | context, --cond_in ctx | obj, --use_simpleRes, and two mixes
+BOX2MASK_VARIANTS = {
+    'b2m_comb': dict(no_comb=False),
+    'b2m_obj_l1': dict(objReconLoss='l1'),
+    'b2m_obj_none': dict(objReconLoss='none'),
+    'b2m_gan_patch': dict(which_gan='patch'),
+    'b2m_stream_obj': dict(which_stream='obj'),
+    'b2m_stream_context': dict(which_stream='context'),
+    'b2m_cond_ctx': dict(cond_in='ctx'),
+    'b2m_cond_obj': dict(cond_in='obj'),
+    'b2m_simple_res': dict(use_simpleRes=True),
+    'b2m_comb_simple_nogate_instance': dict(no_comb=False, use_simpleRes=True, use_output_gate=False,
+                                            norm_layer='instance'),
+    'b2m_comb_patch_l1_ctx': dict(no_comb=False, which_gan='patch', objReconLoss='l1', cond_in='ctx')}
+
+
+def golden_box2mask_variants(only=None, steps=4):
+    from oracle import ref_mask_cpu
+    base = dict(ndf=16, label_nc=35, num_layers_D=3, gan_weight=0.1, lr=0.0002, beta1=0.5, beta2=0.999)
+    for tag, extra in BOX2MASK_VARIANTS.items():
+        if only and tag not in only:
+            continue
+        fl = dict(base, **extra)
+        ref = ref_shim.box2mask_trainer(**fl)
+        ora = ref_mask_cpu.TwoStreamAEMask(**fl)
+        assert list(ref.netG.state_dict().keys()) == list(ora.netG.state_dict().keys()), tag
+        assert list(ref.netD.state_dict().keys()) == list(ora.netD.state_dict().keys()), tag
+        sdG = synth.init_state_dict(ora.netG.state_dict(), 21)
+        sdD = synth.init_state_dict(ora.netD.state_dict(), 22)
+        for m in (ref, ora):
+            m.netG.load_state_dict(sdG)
+            m.netD.load_state_dict(sdD)
+        rl, ol = [], []
+        for s in range(steps):
+            b = synth.make_box2mask_batch(s, 0, 2, 64, 64, 35)
+            with torch.autograd.graph.allow_mutation_on_saved_tensors():
+                r, _ = ref.forward(b['label'], None, b['mask_ctx_in'], None, b['mask_out'], b['mask_obj_inst'], b['cls'],
+                                   b['mask_in'], eval_mode=False)
+            rl.append([float(x.detach().reshape(-1)[0]) if torch.is_tensor(x) else float(x) for x in r])
+            o = ora.step(b)
+            ol.append([o[k] for k in ref_mask_cpu.LOSS_NAMES])
+        rl, ol = np.array(rl, np.float64), np.array(ol, np.float64)
+        rel = np.abs(rl - ol) / np.maximum(np.abs(rl), 1e-12)
+        print('%s: %d steps, max rel(oracle vs reference) per step = %s' % (tag, steps, ' '.join('%.1e' % v for v in rel.max(1))))
+        assert rel[:2].max() < 2e-6 and rel.max() < 5e-3, (tag, rel)
+        np.savez_compressed(os.path.join(HERE, tag + '.npz'), flags=json.dumps(fl), B=2, H=64, W=64,
+                            losses=rl.astype(np.float32), loss_names=np.array(ref_mask_cpu.LOSS_NAMES),
+                            g_keys=np.array(list(ref.netG.state_dict().keys())),
+                            d_keys=np.array(list(ref.netD.state_dict().keys())))
+
+
 def golden_box2mask_eval():
     """The evaluation-side methods of the REAL reference's TwoStreamAE_mask on the box2mask_traj configuration (64x64,
     batch 2, ndf 16, seeded weights 21 / 22, batch 0), in this order: generate() (eval mode, fresh running statistics),
@@ -490,6 +544,8 @@ if __name__ == '__main__':
     if 'box2mask' in what:
         golden_box2mask_net()
         golden_box2mask_traj()
+    if 'box2mask_variants' in what or any(w in BOX2MASK_VARIANTS for w in what):
+        golden_box2mask_variants(None if 'box2mask_variants' in what else what)
     if 'box2mask_eval' in what:
         golden_box2mask_eval()
     if 'data_ops' in what:

@@ -297,6 +297,27 @@ def test_cat_blend_encode():
     assert torch.equal(s.cpu(), (a + a).detach())
 
 
+def test_object_gated_combination_of_stream_logits():
+    """ops.gate_comb = (1 - p) * ctx + p * obj with p, obj (B,1,H,W) broadcast over ctx's channels
+    (MaskTwoStreamConv_NET.py:213-221): forward bit-identical to torch (separately rounded products), three gradients."""
+    ops = _ops()
+    B, C, H, W = 2, 35, 9, 13
+    a = _rand(B, C, H, W, seed=1).requires_grad_(True)
+    l = _rand(B, 1, H, W, seed=2).requires_grad_(True)
+    p = torch.sigmoid(_rand(B, 1, H, W, seed=3)).requires_grad_(True)
+    g = p.expand_as(a)
+    ref = (1 - g) * a + g * l
+    gy = _rand(B, C, H, W, seed=4)
+    ga_ref, gp_ref, gl_ref = torch.autograd.grad(ref, (a, p, l), gy)
+    ad, pd, ld = (t.detach().to(DEV).requires_grad_(True) for t in (a, p, l))
+    out = ops.gate_comb(ad, pd, ld)
+    assert torch.equal(out.cpu(), ref.detach())
+    ga, gp, gl = torch.autograd.grad(out, (ad, pd, ld), gy.to(DEV))
+    assert_close('gate_comb dctx', ga, ga_ref, rtol=1e-6)
+    assert_close('gate_comb dgate', gp, gp_ref, rtol=1e-5)
+    assert_close('gate_comb dobj', gl, gl_ref, rtol=1e-5)
+
+
 def test_masked_mean_color():
     ops = _ops()
     from oracle.ref_cpu import color_embedding

@@ -124,6 +124,29 @@ def test_box2mask_ade_oracle_matches_reference_golden():
         np.testing.assert_allclose(got, t['losses'][s], rtol=5e-6, atol=1e-7)
 
 
+B2M_VARIANTS = ['b2m_comb', 'b2m_obj_l1', 'b2m_obj_none', 'b2m_gan_patch', 'b2m_stream_obj', 'b2m_stream_context',
+                'b2m_cond_ctx', 'b2m_cond_obj', 'b2m_simple_res', 'b2m_comb_simple_nogate_instance', 'b2m_comb_patch_l1_ctx']
+
+
+@pytest.mark.parametrize('tag', B2M_VARIANTS)
+def test_box2mask_flag_variants_oracle_matches_reference_golden(tag):
+    """The parser's other values of the box2mask flags (round 6): without --no_comb, --objReconLoss l1 | none, --which_gan
+    patch, --which_stream obj | context, --cond_in ctx | obj, --use_simpleRes.  Fixtures = the REAL reference's losses over
+    the first training steps (tests/golden/make_golden.py box2mask_variants); the restatement reproduces the first two."""
+    from oracle import ref_mask_cpu
+    t = load_golden(tag)
+    fl = json.loads(str(t['flags']))
+    tr = ref_mask_cpu.TwoStreamAEMask(**fl)
+    assert list(tr.netG.state_dict().keys()) == [str(k) for k in t['g_keys']]
+    assert list(tr.netD.state_dict().keys()) == [str(k) for k in t['d_keys']]
+    tr.netG.load_state_dict(synth.init_state_dict(tr.netG.state_dict(), 21))
+    tr.netD.load_state_dict(synth.init_state_dict(tr.netD.state_dict(), 22))
+    for s in range(2):
+        o = tr.step(synth.make_box2mask_batch(s, 0, 2, 64, 64, 35))
+        got = np.array([o[k] for k in ref_mask_cpu.LOSS_NAMES])
+        np.testing.assert_allclose(got, t['losses'][s], rtol=5e-6, atol=1e-7)
+
+
 def test_lr_control_rule_restatement():
     """oracle lr_control (reference models/Discriminator_NET.py:190-211): the three reachable outcomes."""
     from oracle import ref_mask_cpu
