@@ -96,6 +96,43 @@ class NLayerDiscriminator(nn.Module):
         return self.model(input)
 
 
+class NLayerResDiscriminator(nn.Module):
+    """box2mask's --which_gan patch_res (reference Discriminator_NET.py:118-183): the stride-2 stages of the PatchGAN are
+    ConvResnetBlocks (kernel 4, LeakyReLU 0.2 on the stage input, conv1x1 + norm shortcut); the stride-1 block, the
+    1-channel head and the Sigmoid follow in the same flat ``model`` Sequential (keys ``model.<i>.deep.1.weight`` ...)."""
+
+    def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer='instance', use_sigmoid=False, getIntermFeat=False,
+                 num_resnetblocks=1):
+        super().__init__()
+        from ..nn import Conv2d
+        from .MaskTwoStreamConvSwitch_NET import ConvResnetBlock
+        if getIntermFeat or num_resnetblocks != 1:
+            raise NotImplementedError('NLayerResDiscriminator: getIntermFeat / num_resnetblocks > 1 have no call site upstream')
+        if norm_layer not in ('instance', 'batch'):
+            raise NotImplementedError('normalization layer [%s] is not found' % norm_layer)
+        norm = InstanceNorm2d if norm_layer == 'instance' else BatchNorm2d
+        self.getIntermFeat, self.n_layers = False, n_layers
+        seq = [ConvResnetBlock(input_nc, ndf, 2, 4, norm, LeakyReLU(0.2))]
+        nf = ndf
+        for _ in range(1, n_layers):
+            nf_prev, nf = nf, min(nf * 2, 512)
+            seq.append(ConvResnetBlock(nf_prev, nf, 2, 4, norm, LeakyReLU(0.2)))
+        nf_prev, nf = nf, min(nf * 2, 512)
+        seq += [Conv2d(nf_prev, nf, 4, 1, 2), norm(nf), LeakyReLU(0.2), Conv2d(nf, 1, 4, 1, 2)]
+        if use_sigmoid:
+            seq.append(Sigmoid())
+        self.model = nn.Sequential(*seq)
+        self.apply(weights_init)        # reference :170
+
+    def forward(self, input, cond=None):
+        h = ops.cat_channels([input, cond]) if cond is not None else input
+        layers = list(self.model)
+        for blk in layers[:self.n_layers]:
+            h, _ = blk(h)
+        from ..nn import run_layers
+        return run_layers(layers[self.n_layers:], h)
+
+
 class MultiscaleDiscriminator(nn.Module):
     def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer='instance', use_sigmoid=False, num_D=3,
                  getIntermFeat=True, spectral_norm=False):

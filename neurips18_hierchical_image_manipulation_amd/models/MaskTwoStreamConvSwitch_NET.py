@@ -53,16 +53,17 @@ def _conv(l, x, pad_mode='zero', pad=None, norm=None):
 
 
 class ConvResnetBlock(nn.Module):
-    """relu(x) -> [conv k s] -> BN  +  shortcut(relu(x)) = conv1x1 s -> BN   (layer_util.py:128-171, num_layers 1)."""
+    """act(x) -> [conv k s] -> BN  +  shortcut(act(x)) = conv1x1 s -> BN   (layer_util.py:128-171, num_layers 1);
+    ``activation``: ReLU in the generator, LeakyReLU(0.2) in NLayerResDiscriminator (Discriminator_NET.py:136-152)."""
 
-    def __init__(self, cin, cout, stride, k, norm=BatchNorm2d):
+    def __init__(self, cin, cout, stride, k, norm=BatchNorm2d, activation=None):
         super().__init__()
         self.shortcut = None if (cin == cout and stride == 1) else nn.Sequential(Conv2d(cin, cout, 1, stride, 0),
                                                                                  norm(cout))
-        self.deep = nn.Sequential(ReLU(), Conv2d(cin, cout, k, stride, (k - 1) // 2), norm(cout))
+        self.deep = nn.Sequential(activation or ReLU(), Conv2d(cin, cout, k, stride, (k - 1) // 2), norm(cout))
 
     def forward(self, x):
-        r = ops.activation(x, 'relu')
+        r = ops.activation(x, self.deep[0].act, getattr(self.deep[0], 'slope', 0.0))
         res = r if self.shortcut is None else self.shortcut[1].apply_to(_conv(self.shortcut[0], r, norm=self.shortcut[1]))
         out = self.deep[2].apply_to(_conv(self.deep[1], r, norm=self.deep[2]), residual=res)
         return out, r

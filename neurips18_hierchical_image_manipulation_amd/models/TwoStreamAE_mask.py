@@ -2,9 +2,9 @@
 configuration of scripts/train_box2mask_city.sh (``--model AE_maskgen_twostream --no_comb --which_stream obj_context
 --cond_in ctx_obj --use_gan --which_gan patch_multiscale --objReconLoss bce --norm_layer batch --use_output_gate
 --use_ganFeat_loss``); the parser's other values of those flags run too (round 6: without --no_comb, --which_stream obj |
-context, --cond_in obj | ctx, --which_gan patch, --objReconLoss l1 | none, --use_simpleRes; --which_gan patch_res is not
-built).  ``forward(..., eval_mode=False)`` IS the training step, as in the reference (:167-254): losses, then the
-generator's Adam step, then the discriminator's, all inside the call.
+context, --cond_in obj | ctx, --which_gan patch | patch_res, --objReconLoss l1 | none, --use_simpleRes).
+``forward(..., eval_mode=False)`` IS the training step, as in the reference (:167-254): losses, then the generator's Adam
+step, then the discriminator's, all inside the call.
 
 Departures that do not change the arithmetic: the three one-hot tensors are built straight into the 70-channel condition
 buffer; ``x * mask.repeat`` + ``torch.cat`` are one kernel; the discriminator pass on the attached fake runs with frozen D
@@ -19,7 +19,7 @@ from .. import ops
 from ..nn import frozen_params
 from ..optim import FusedAdam
 from .base_model import BaseModel
-from .Discriminator_NET import MultiscaleDiscriminator, NLayerDiscriminator
+from .Discriminator_NET import MultiscaleDiscriminator, NLayerDiscriminator, NLayerResDiscriminator
 from .layer_util import torch_default_init
 from .MaskTwoStreamConvSwitch_NET import MaskTwoStreamConvSwitch_NET, MaskTwoStreamConv_NET
 from .pix2pixHD_condImg_model import pick_device
@@ -50,9 +50,9 @@ class TwoStreamAE_mask(BaseModel):
         # every value the parser offers for these flags runs (round 6); what the reference itself cannot run fails here
         if opt.cond_in not in ('obj', 'ctx', 'ctx_obj'):
             raise NotImplementedError('--cond_in [%s]: obj | ctx | ctx_obj (reference construct_input_cond)' % opt.cond_in)
-        if opt.use_gan and opt.which_gan not in ('patch', 'patch_multiscale'):
-            raise NotImplementedError('box2mask HIP path: --which_gan patch | patch_multiscale (patch_res: the ConvResnetBlock '
-                                      'discriminator of Discriminator_NET.py:118-183 is not built)')
+        if opt.use_gan and opt.which_gan not in ('patch', 'patch_res', 'patch_multiscale'):
+            # the reference builds no discriminator for any other value and fails at its first use (:69-94)
+            raise NotImplementedError('--which_gan [%s]: patch | patch_res | patch_multiscale' % opt.which_gan)
         if opt.isTrain and not opt.use_gan:
             # the reference's forward dies on its first step without --use_gan (loss_G_GAN_Feat is only bound inside
             # ``if self.use_gan``, TwoStreamAE_mask.py:251): refuse at construction instead of training something else
@@ -73,6 +73,8 @@ class TwoStreamAE_mask(BaseModel):
                 d_nc = 1 + (2 * opt.label_nc if opt.cond_in == 'ctx_obj' else opt.label_nc)       # reference :67-68
                 if opt.which_gan == 'patch':       # one PatchGAN with a Sigmoid, BCE (reference :69-76)
                     self.netD = NLayerDiscriminator(d_nc, opt.ndf, opt.num_layers_D, opt.norm_layer, True, False)
+                elif opt.which_gan == 'patch_res':  # the same with ConvResnetBlock stages (:77-84)
+                    self.netD = NLayerResDiscriminator(d_nc, opt.ndf, opt.num_layers_D, opt.norm_layer, True, False)
                 else:                              # LSGAN on two scales, intermediate features kept (:85-94)
                     self.netD = MultiscaleDiscriminator(d_nc, opt.ndf, opt.num_layers_D, opt.norm_layer, False, 2, True)
                 self.netD.to(self.device)
@@ -110,7 +112,7 @@ class TwoStreamAE_mask(BaseModel):
         """GANLoss.__call__ (reference losses.py:43-53).  patch_multiscale: MSE of each scale's last output, summed.
         patch: ``preds`` is ONE (B,1,h,w) tensor and ``input[-1]`` there indexes the BATCH -- the BCE of the LAST sample's
         patch map against the constant target, reproduced as it is."""
-        if self.which_gan == 'patch':
+        if self.which_gan != 'patch_multiscale':
             last = preds[-1:].contiguous()
             return ops.bce_mean(last, torch.full_like(last, 1.0 if real else 0.0))
         loss = 0
@@ -146,7 +148,7 @@ class TwoStreamAE_mask(BaseModel):
             fake_d = self.netD(ops.cat_channels([obj_prob.detach(), cond], m, 1))
             self._d_real_loss, self._d_fake_loss = self._gan(real_d, True), self._gan(fake_d, False)
             loss_D = 0.5 * self._d_real_loss + 0.5 * self._d_fake_loss
-            if opt.use_ganFeat_loss and self.which_gan != 'patch':
+            if opt.use_ganFeat_loss and self.which_gan == 'patch_multiscale':
                 # returned, never added to loss_G (reference :225-227); with --which_gan patch the reference's double loop
                 # walks one sample's (1,h,w) map and finds no feature pair: the term stays 0
                 with torch.no_grad():

@@ -41,14 +41,16 @@ def _norm(kind):
 
 
 class ConvResnetBlock(nn.Module):   # layer_util.py:128-171 (num_layers = 1)
-    def __init__(self, cin, cout, stride, k, norm=nn.BatchNorm2d):
+    def __init__(self, cin, cout, stride, k, norm=nn.BatchNorm2d, slope=0.0):
         super().__init__()
         self.shortcut = None if (cin == cout and stride == 1) else nn.Sequential(nn.Conv2d(cin, cout, 1, stride),
                                                                                  norm(cout))
-        self.deep = nn.Sequential(nn.ReLU(), nn.Conv2d(cin, cout, k, stride, (k - 1) // 2), norm(cout))
+        # activation_fn: nn.ReLU(True) in the generator, nn.LeakyReLU(0.2, True) in NLayerResDiscriminator
+        self.deep = nn.Sequential(nn.LeakyReLU(slope) if slope else nn.ReLU(), nn.Conv2d(cin, cout, k, stride, (k - 1) // 2),
+                                  norm(cout))
 
     def forward(self, x):
-        r = F.relu(x)                      # the in-place ReLU: both paths (and the caller's alias) see relu(x)
+        r = self.deep[0](x)                # the in-place activation: both paths (and the caller's alias) see act(x)
         res = r if self.shortcut is None else self.shortcut(r)
         return self.deep[2](self.deep[1](r)) + res, r
 
@@ -259,11 +261,38 @@ class NLayerDiscriminator(nn.Module):
         return self.model(torch.cat((x, cond), 1))
 
 
+class NLayerResDiscriminator(nn.Module):
+    """--which_gan patch_res (Discriminator_NET.py:118-183): the stride-2 stages are ConvResnetBlocks (kernel 4, LeakyReLU
+    0.2 applied in place to the stage input, conv1x1 shortcut + norm), then the stride-1 block, the 1-channel head and the
+    Sigmoid; flat ``model`` Sequential."""
+
+    def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer='batch', use_sigmoid=True):
+        super().__init__()
+        norm = _norm(norm_layer)
+        seq = [ConvResnetBlock(input_nc, ndf, 2, 4, norm, 0.2)]
+        nf = ndf
+        for _ in range(1, n_layers):
+            nf_prev, nf = nf, min(nf * 2, 512)
+            seq.append(ConvResnetBlock(nf_prev, nf, 2, 4, norm, 0.2))
+        nf_prev, nf = nf, min(nf * 2, 512)
+        seq += [nn.Conv2d(nf_prev, nf, 4, 1, 2), norm(nf), nn.LeakyReLU(0.2), nn.Conv2d(nf, 1, 4, 1, 2)]
+        if use_sigmoid:
+            seq.append(nn.Sigmoid())
+        self.model = nn.Sequential(*seq)
+
+    def forward(self, x, cond):
+        h = torch.cat((x, cond), 1)
+        for layer in self.model:
+            h = layer(h)
+            h = h[0] if isinstance(h, tuple) else h          # ConvResnetBlock here returns (output, rectified input)
+        return h
+
+
 class TwoStreamAEMask(object):
     """CPU restatement of the reference trainer (models/TwoStreamAE_mask.py:14-254).  Defaults = the flags of
     scripts/train_box2mask_city.sh (which_stream obj_context, cond_in ctx_obj, use_gan patch_multiscale, objReconLoss bce,
     use_output_gate, use_ganFeat_loss, norm_layer batch, --no_comb); the parser's other values of those flags -- without
-    --no_comb (MaskTwoStreamConv_NET), --which_stream obj | context, --cond_in ctx | obj, --which_gan patch,
+    --no_comb (MaskTwoStreamConv_NET), --which_stream obj | context, --cond_in ctx | obj, --which_gan patch | patch_res,
     --objReconLoss l1 | none, --use_simpleRes -- follow the same lines.  ``step`` = one
     TwoStreamAE_mask.forward(eval_mode=False): losses, then the G Adam step, then the D Adam step (:237-248)."""
 
@@ -282,10 +311,12 @@ class TwoStreamAEMask(object):
         d_nc = 1 + (2 * label_nc if cond_in == 'ctx_obj' else label_nc)      # :67-68
         if which_gan == 'patch':                                             # :69-76 (BCE on Sigmoid outputs)
             self.netD = NLayerDiscriminator(d_nc, ndf, num_layers_D, norm_layer, use_sigmoid=True)
+        elif which_gan == 'patch_res':                                       # :77-84
+            self.netD = NLayerResDiscriminator(d_nc, ndf, num_layers_D, norm_layer, use_sigmoid=True)
         elif which_gan == 'patch_multiscale':                                # :85-94 (LSGAN, 2 scales, features kept)
             self.netD = ref_cpu.MultiscaleDiscriminator(d_nc, ndf, num_layers_D, num_D=2, norm=norm_layer)
         else:
-            raise NotImplementedError('which_gan [%s] is not restated (patch | patch_multiscale)' % which_gan)
+            raise NotImplementedError('which_gan [%s]: patch | patch_res | patch_multiscale' % which_gan)
         self.optimizer = torch.optim.Adam(self.netG.parameters(), lr=lr, betas=(beta1, beta2))
         self.optimizer_D = torch.optim.Adam(self.netD.parameters(), lr=lr, betas=(beta1, 0.999))
 

@@ -265,6 +265,7 @@ BOX2MASK_VARIANTS = {
     'b2m_obj_l1': dict(objReconLoss='l1'),
     'b2m_obj_none': dict(objReconLoss='none'),
     'b2m_gan_patch': dict(which_gan='patch'),
+    'b2m_gan_patch_res': dict(which_gan='patch_res'),
     'b2m_stream_obj': dict(which_stream='obj'),
     'b2m_stream_context': dict(which_stream='context'),
     'b2m_cond_ctx': dict(cond_in='ctx'),

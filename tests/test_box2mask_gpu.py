@@ -161,7 +161,7 @@ def test_box2mask_teacher_forced_steps_vs_oracle():
     assert worst < 2e-5, worst
 
 
-B2M_VARIANTS = ['b2m_comb', 'b2m_obj_l1', 'b2m_obj_none', 'b2m_gan_patch', 'b2m_stream_obj', 'b2m_stream_context',
+B2M_VARIANTS = ['b2m_comb', 'b2m_obj_l1', 'b2m_obj_none', 'b2m_gan_patch', 'b2m_gan_patch_res', 'b2m_stream_obj', 'b2m_stream_context',
                 'b2m_cond_ctx', 'b2m_cond_obj', 'b2m_simple_res', 'b2m_comb_simple_nogate_instance', 'b2m_comb_patch_l1_ctx']
 
 

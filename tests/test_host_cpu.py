@@ -243,7 +243,7 @@ def test_checkpoint_keys_follow_the_reference_for_every_flag_set(tag):
                               for k, v in ref_sd.items()}, strict=True)
 
 
-@pytest.mark.parametrize('tag', ['b2m_comb', 'b2m_gan_patch', 'b2m_stream_obj', 'b2m_stream_context', 'b2m_cond_ctx',
+@pytest.mark.parametrize('tag', ['b2m_comb', 'b2m_gan_patch', 'b2m_gan_patch_res', 'b2m_stream_obj', 'b2m_stream_context', 'b2m_cond_ctx',
                                  'b2m_simple_res', 'b2m_comb_simple_nogate_instance'])
 def test_box2mask_checkpoint_keys_follow_the_reference_for_every_flag_set(tag):
     """box2mask's other flag values (round 6): the generator / discriminator modules carry the REAL reference's state-dict
@@ -254,7 +254,8 @@ def test_box2mask_checkpoint_keys_follow_the_reference_for_every_flag_set(tag):
     from neurips18_hierchical_image_manipulation_amd.models import TwoStreamAE_mask as T
     from neurips18_hierchical_image_manipulation_amd.models.MaskTwoStreamConvSwitch_NET import (
         MaskTwoStreamConvSwitch_NET, MaskTwoStreamConv_NET)
-    from neurips18_hierchical_image_manipulation_amd.models.Discriminator_NET import MultiscaleDiscriminator, NLayerDiscriminator
+    from neurips18_hierchical_image_manipulation_amd.models.Discriminator_NET import (
+        MultiscaleDiscriminator, NLayerDiscriminator, NLayerResDiscriminator)
     g = np.load(os.path.join(ROOT, 'tests', 'golden', tag + '.npz'), allow_pickle=False)
     opt = T.complete(json.loads(str(g['flags'])))
     net = (MaskTwoStreamConvSwitch_NET if opt.no_comb else MaskTwoStreamConv_NET)(opt)
@@ -262,6 +263,8 @@ def test_box2mask_checkpoint_keys_follow_the_reference_for_every_flag_set(tag):
     d_nc = 1 + (2 * opt.label_nc if opt.cond_in == 'ctx_obj' else opt.label_nc)
     if opt.which_gan == 'patch':
         netD = NLayerDiscriminator(d_nc, opt.ndf, opt.num_layers_D, opt.norm_layer, True, False)
+    elif opt.which_gan == 'patch_res':
+        netD = NLayerResDiscriminator(d_nc, opt.ndf, opt.num_layers_D, opt.norm_layer, True, False)
     else:
         netD = MultiscaleDiscriminator(d_nc, opt.ndf, opt.num_layers_D, opt.norm_layer, False, 2, True)
     assert list(netD.state_dict().keys()) == [str(k) for k in g['d_keys']]

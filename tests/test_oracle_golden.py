@@ -124,7 +124,7 @@ def test_box2mask_ade_oracle_matches_reference_golden():
         np.testing.assert_allclose(got, t['losses'][s], rtol=5e-6, atol=1e-7)
 
 
-B2M_VARIANTS = ['b2m_comb', 'b2m_obj_l1', 'b2m_obj_none', 'b2m_gan_patch', 'b2m_stream_obj', 'b2m_stream_context',
+B2M_VARIANTS = ['b2m_comb', 'b2m_obj_l1', 'b2m_obj_none', 'b2m_gan_patch', 'b2m_gan_patch_res', 'b2m_stream_obj', 'b2m_stream_context',
                 'b2m_cond_ctx', 'b2m_cond_obj', 'b2m_simple_res', 'b2m_comb_simple_nogate_instance', 'b2m_comb_patch_l1_ctx']
 
 
