@@ -32,8 +32,9 @@ def head(ngf, out_nc):
 class FeatureFusionBlock(nn.Module):
     """reference models/layer_util.py:295-330 at its one call site (Pix2Pix_NET.py:135-136: ``main_module`` an Identity).
     'add': x + y.  'concat': norm(conv1x1(ReLU(cat(x, y)))), parameters at ``conv1`` (+ ``norm1`` under --norm batch).
-    ``forward`` takes the two stream features UNMASKED plus the pooled mask m and computes the fusion of
-    ((1-m)*ctx, m*obj) (reference Pix2Pix_NET.py:215-217): the masks ride in the kernels that would copy anyway."""
+    ``forward(x, y)`` is the reference's call.  The generator passes the two stream features UNMASKED plus the pooled mask
+    (``forward(ctx, obj, m)``) and gets the fusion of ((1-m)*ctx, m*obj) (reference Pix2Pix_NET.py:215-217): the masks
+    ride in the kernels that would copy anyway."""
 
     def __init__(self, planes, fusion_type, norm=InstanceNorm2d):
         super().__init__()
@@ -44,11 +45,11 @@ class FeatureFusionBlock(nn.Module):
             self.conv1 = Conv2d(2 * planes, planes, 1)
             self.norm1 = norm(planes)
 
-    def forward(self, ctx, obj, m):
+    def forward(self, ctx, obj, m=None):
         if self.fusion_type == 'add':
-            return ops.blend(ctx, obj, m)                                    # (1-m)*ctx + m*obj in one pass
-        h = ops.cat_channels([ctx, obj], m, (2, 1))                          # cat((1-m)*ctx, m*obj)
-        return run_layers([self.conv1, self.norm1], ops.activation(h, 'relu'))
+            return ops.add(ctx, obj) if m is None else ops.blend(ctx, obj, m)   # (1-m)*ctx + m*obj in one pass
+        h = ops.cat_channels([ctx, obj]) if m is None else ops.cat_channels([ctx, obj], m, (2, 1))
+        return run_layers([self.conv1, self.norm1], ops.activation(h, 'relu'))   # cat((1-m)*ctx, m*obj) -> ReLU -> ...
 
 
 class GlobalGenerator(nn.Module):

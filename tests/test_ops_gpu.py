@@ -318,6 +318,34 @@ def test_object_gated_combination_of_stream_logits():
     assert_close('gate_comb dobj', gl, gl_ref, rtol=1e-5)
 
 
+@pytest.mark.parametrize('fusion,norm', [('add', 'instance'), ('concat', 'instance'), ('concat', 'batch')])
+def test_feature_fusion_block_both_call_forms(fusion, norm):
+    """FeatureFusionBlock (reference layer_util.py:295-330): the reference's own call ``fuser(x, y)`` on pre-masked features
+    and the generator's ``fuser(ctx, obj, m)`` (masks folded into the copy kernels) against the oracle's torch block."""
+    from oracle import ref_cpu
+    from neurips18_hierchical_image_manipulation_amd import synth
+    from neurips18_hierchical_image_manipulation_amd.models.Pix2Pix_NET import FeatureFusionBlock
+    from neurips18_hierchical_image_manipulation_amd.models.layer_util import get_norm_layer
+    B, C, H, W = 2, 16, 6, 10
+    o = ref_cpu.FeatureFusionBlock(C, fusion, ref_cpu.get_norm_layer(norm))
+    h = FeatureFusionBlock(C, fusion, get_norm_layer(norm)).to(DEV)
+    sd = synth.init_state_dict(o.state_dict(), 9)
+    o.load_state_dict(sd)
+    h.load_state_dict(sd)
+    ctx, obj = _rand(B, C, H, W, seed=1).requires_grad_(True), _rand(B, C, H, W, seed=2).requires_grad_(True)
+    m = (torch.rand(B, 1, H, W, generator=torch.Generator().manual_seed(3)) > 0.5).float()
+    ref = o((1 - m) * ctx, m * obj)
+    gy = _rand(*ref.shape, seed=4)
+    gc_ref, go_ref = torch.autograd.grad(ref, (ctx, obj), gy)
+    cd, od = ctx.detach().to(DEV).requires_grad_(True), obj.detach().to(DEV).requires_grad_(True)
+    ops = _ops()
+    for out in (h(cd, od, m.to(DEV)), h(ops.cat_channels([cd], m.to(DEV), 2), ops.mul_mask(od, m.to(DEV)))):
+        assert_close('fusion fwd', out, ref, rtol=1e-5)
+        gc, go = torch.autograd.grad(out, (cd, od), gy.to(DEV))
+        assert_close('fusion d ctx', gc, gc_ref, rtol=1e-4)
+        assert_close('fusion d obj', go, go_ref, rtol=1e-4)
+
+
 def test_masked_mean_color():
     ops = _ops()
     from oracle.ref_cpu import color_embedding
