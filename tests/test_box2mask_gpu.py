@@ -187,12 +187,14 @@ def _variant_trainers(tag):
 def test_box2mask_flag_variants_vs_reference_golden_and_oracle(tag):
     """The parser's other values of the box2mask flags (round 6), each from a fixture of the REAL reference run with that
     flag set: (1) free-running, the first two steps against the reference's losses (step 0 within 5e-6, step 1 within 5e-4);
-    (2) four teacher-forced steps from the oracle's state: losses within 2e-5, and every live parameter gradient measured
+    (2) six teacher-forced steps from the oracle's state: losses within 2e-5, and every live parameter gradient measured
     against the same step of the oracle in FLOAT64 next to the fp32 oracle's own distance from it.  On these 64x64 toy nets
     an fp32 event (ReLU gates on the other side of zero than in float64) moves the generator's gradients by 1e-4..1e-3 in
     a third of the steps on either side -- in nearly every step with --use_simpleRes, HIP path and fp32 oracle alike
-    (recorded: 1.2e-4 / 7.3e-4 / 4.9e-4 against 1.3e-4 / 6.8e-6 / 4.9e-4) -- so the bound is on the median over steps of
-    the per-step median over tensors (<= 10 x the oracle's, floor 1e-6) and on the largest single distance: 0.1 -- ONE
+    (recorded: 1.2e-4 / 7.3e-4 / 4.9e-4 against 1.3e-4 / 6.8e-6 / 4.9e-4) -- so the bound is on the median over SIX steps of
+    the per-step median over tensors (<= 10 x the oracle's, floor 1e-6: it takes an event in three of the six steps to move
+    it; recorded rate 1 step in 40 on the HIP side, 2 in 40 on the oracle's), for the --use_simpleRes nets on the largest
+    per-step median instead (5e-3; recorded <= 6.9e-4 HIP, <= 1.2e-3 oracle), and on the largest single distance: 0.1 -- ONE
     flipped ReLU gate on the 4x4 latent planes of these nets (32 values per channel and batch) rewrites that channel's
     gradient, 1 / sqrt(256 channels) = 6e-2 of the tensor (recorded: 4.0e-2 on obj_latent_decoder.2 in a step where the
     fp32 oracle had its own event of 3e-4 elsewhere); a missing or mis-scaled gradient is >= 0.5.  The blocks themselves
@@ -213,7 +215,7 @@ def test_box2mask_flag_variants_vs_reference_golden_and_oracle(tag):
         ora64 = ref_mask_cpu.TwoStreamAEMask(**json.loads(str(g['flags'])))
     to64 = lambda sd: {k: v.double() if v.is_floating_point() else v for k, v in sd.items()}  # noqa: E731
     worst, med_h, med_o, top = 0.0, [], [], 0.0
-    for s in range(4):
+    for s in range(6):
         _adopt_b2m(model, ora)
         ora64.netG.load_state_dict(to64(ora.netG.state_dict()))
         ora64.netD.load_state_dict(to64(ora.netD.state_dict()))
@@ -242,7 +244,10 @@ def test_box2mask_flag_variants_vs_reference_golden_and_oracle(tag):
           'largest %.1e' % (tag, ' '.join('%.1e' % r for r in rels), worst, ' '.join('%.1e' % m for m in med_h),
                             ' '.join('%.1e' % m for m in med_o), top))
     assert worst < 2e-5, worst
-    assert np.median(med_h) <= 10.0 * max(np.median(med_o), 1e-6), (med_h, med_o)
+    if json.loads(str(g['flags'])).get('use_simpleRes'):
+        assert max(med_h) <= 5e-3, (med_h, med_o)
+    else:
+        assert np.median(med_h) <= 10.0 * max(np.median(med_o), 1e-6), (med_h, med_o)
     assert top <= 0.1, top
 
 
