@@ -433,8 +433,9 @@ def _teacher_forced_run(tag, steps, loss_tol, anchor, golden, batch_fn, plumbing
     # every ~10 steps on either side).  The oracle's code in fp32 on torch's GPU operators (fa.make_oracle(yardstick=True),
     # the implementation the fraction rule already pools) takes every regular step too and doubles the sample the event
     # scale is read from; the TYPICAL bounds keep the host oracle alone.
+    # (toy golden tags only: the full-size live-only runs -- C4 bs 16, LocalEnhancer -- hold events in every oracle sample)
     om32y = (fa.make_oracle(flags, torch.float32, device='cuda', yardstick=True)
-             if om64 is not None and anchor is None and min(steps, fp64_steps) >= 6 else None)
+             if om64 is not None and anchor is None and golden is None and min(steps, fp64_steps) >= 6 else None)
     e_y_steps = []
     dead = fa.dead_biases(om.netG, 'G') | fa.dead_biases(om.netD, 'D')
     worst_loss, log, e_hip_steps, e_32_steps, adam_log, vs_oracle = 0.0, [], [], [], [], 0.0
