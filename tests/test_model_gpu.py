@@ -387,9 +387,9 @@ PARITY_MIN_SAMPLES, PARITY_FRACTION_OF_ORACLE = 30, 1.0 / 3.0
 # measured over 24 steps on two configurations, profiles/r06_ab_log.txt section 6) and, with atomics in the split-K weight
 # gradients, not in the same step from run to run: "HIP's largest event <= K x the oracle's largest" then fails one run
 # in ~5 on a sample in which the fp32 references happen to show none.  ONE step in twelve of a net may therefore exceed
-# the event bound, up to the largest fp32-vs-float64 event the host oracle itself has produced on these nets; 6-step
-# full-size runs get no such step (their oracle samples always hold events), and a defect that is there in every step is
-# what the TYPICAL bounds catch.
+# the event bound, up to the largest fp32-vs-float64 event the host oracle itself has produced on these nets; anchored
+# and full-size runs get no such step (their oracle samples always hold events), and a defect that is there in every
+# step is what the TYPICAL bounds catch.
 PARITY_ISOLATED_EVENT_EVERY, PARITY_EVENT_CEILING = 12, 3e-2
 
 
@@ -654,7 +654,10 @@ def _teacher_forced_run(tag, steps, loss_tol, anchor, golden, batch_fn, plumbing
             over = [s for s, st in enumerate(regular)
                     if not max(st[n]['grad'] for n in names if n.startswith(net)) <= PARITY_K_EVENT * mo]
             events.append((mh[0] / mo, net, mh[0], mh[1], mh[2], mo, over))
-            if over and (len(over) > len(regular) // PARITY_ISOLATED_EVENT_EVERY or not mh[0] <= PARITY_EVENT_CEILING):
+            # the isolated step is granted to the toy live-only runs alone (the ones whose event scale is pooled with the GPU
+            # fp32 yard-stick above); anchored and full-size runs keep "no step above the bound"
+            allowed = len(regular) // PARITY_ISOLATED_EVENT_EVERY if om32y is not None else 0
+            if over and (len(over) > allowed or not mh[0] <= PARITY_EVENT_CEILING):
                 bad.append(('event', net, mh[0], PARITY_K_EVENT * mo, 'steps over the bound: %s' % over))
         med = _median
         per_step = [dict(step=s, loss_rel=log[s][1],
