@@ -136,6 +136,20 @@ def golden_nets():
         yr, yo = r(x), o(x)
     assert torch.allclose(yr, yo, atol=1e-6)
     out.update(local_x=x.numpy(), local_y=yr.numpy())
+    # the same class with --norm batch (BatchNorm2d(affine=True), training mode: batch statistics), round 6
+    r = P.LocalEnhancer(9, 3, ngf=4, n_downsample_global=2, n_blocks_global=2, n_local_enhancers=1, n_blocks_local=2,
+                        norm_layer='batch')
+    o = ref_cpu.LocalEnhancer(9, 3, ngf=4, n_downsample_global=2, n_blocks_global=2, n_local_enhancers=1, n_blocks_local=2,
+                              norm_layer='batch')
+    sd = synth.init_state_dict(o.state_dict(), 12)
+    assert list(r.state_dict().keys()) == list(sd.keys())
+    r.load_state_dict(sd)
+    o.load_state_dict(sd)
+    with torch.no_grad():
+        yr, yo = r(x), o(x)
+    assert torch.equal(yr, yo)
+    assert all(torch.equal(a, b) for a, b in zip(r.state_dict().values(), o.state_dict().values()))   # running statistics
+    out.update(local_bn_y=yr.numpy(), local_bn_keys=np.array(list(sd.keys())))
     # spectral norm (models/sn_utils.py:8-25): sigma, u', W/sigma, d sigma / dW
     for tag, shape in (('sn_small', (16, 8, 3, 3)), ('sn_big', (512, 256, 4, 4))):
         g = torch.Generator().manual_seed(13)

@@ -71,6 +71,13 @@ def test_oracle_misc_nets():
     net.load_state_dict(synth.init_state_dict(net.state_dict(), 11))
     with torch.no_grad():
         np.testing.assert_allclose(net(torch.from_numpy(g['local_x'])).numpy(), g['local_y'], atol=2e-6)
+    # --norm batch (training mode: batch statistics), keys in the reference's order
+    net = ref_cpu.LocalEnhancer(9, 3, ngf=4, n_downsample_global=2, n_blocks_global=2, n_local_enhancers=1,
+                                n_blocks_local=2, norm_layer='batch')
+    assert list(net.state_dict().keys()) == [str(k) for k in g['local_bn_keys']]
+    net.load_state_dict(synth.init_state_dict(net.state_dict(), 12))
+    with torch.no_grad():
+        np.testing.assert_allclose(net(torch.from_numpy(g['local_x'])).numpy(), g['local_bn_y'], atol=2e-6)
     W = torch.from_numpy(g['sn_small_W']).requires_grad_(True)
     sig, u = ref_cpu.max_singular_value(W, torch.from_numpy(g['sn_small_u0']))
     np.testing.assert_allclose(sig.detach().numpy(), g['sn_small_sigma'], rtol=1e-6)
